@@ -1,0 +1,345 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the reference itself.
+
+Runs ONLY in the build container (needs /root/reference); the outputs are
+committed.  Nothing here is imported by tests at run time except weights.py.
+
+    python tests/golden/make_goldens.py            # all groups
+    python tests/golden/make_goldens.py G2 G4      # selected groups
+
+Groups follow SURVEY.md section 8(c): G1 schedule, G2 denoiser forward (+ per
+module taps), G3 DDPM.forward loss/grads, G4 DDPM.sample trajectories (NU
+checkpoint + synthetic), G5 decoders/evaluators, G6 loaders on CSV slices,
+G7 state-dict layout + EMA.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+os.chdir(os.path.join(REF, "ddpm_opt"))
+
+from ddpm_opt.diffusion import generate_cosine_schedule, init_weights  # noqa: E402
+from ddpm_opt.UNetCF import UNet1D, ResidualBlock  # noqa: E402
+import ddpm_opt.classifier_free_MSR as RMSR  # noqa: E402
+import ddpm_opt.classifier_free_CO as RCO  # noqa: E402
+import ddpm_opt.classifier_free_NU as RNU  # noqa: E402
+from weights import CONFIGS, synth_weights  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def ref_unet(cfg):
+    n = len(cfg["dims"])
+    return UNet1D(input_dim=cfg["input_dim"], proj_dim=cfg["proj_dim"], cond_dim=cfg["cond_dim"],
+                  dims=cfg["dims"], is_attn=(False,) * n, middle_attn=False, n_blocks=cfg["n_blocks"])
+
+
+def load_synth(model, seed, flavour):
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    w = synth_weights(shapes, seed, flavour)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    return shapes
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrs)} arrays")
+
+
+# ---------------------------------------------------------------- G1
+def g1():
+    out = {}
+    for T in (4, 20, 400, 500, 1000):
+        betas = generate_cosine_schedule(T)
+        out[f"T{T}_betas_f64"] = betas
+        alphas = 1.0 - betas
+        m = RMSR.DDPM(T, torch.nn.Identity(), 3, 10.0, alphas, "cpu", (1, 3))
+        for k, v in m.state_dict().items():
+            if not k.startswith("ema."):
+                out[f"T{T}_{k}"] = v.numpy()
+    save("g1_schedule.npz", **out)
+
+
+# ---------------------------------------------------------------- G2
+def module_taps(model):
+    """Forward hooks on every direct child of down/up + middle + time_emb + feature_proj."""
+    taps = {}
+
+    def hook(name):
+        def f(_m, _inp, out):
+            taps[name] = out.detach().clone().numpy()
+        return f
+    hs = [model.time_emb.register_forward_hook(hook("time_emb")),
+          model.feature_proj.register_forward_hook(hook("feature_proj")),
+          model.middle.register_forward_hook(hook("middle"))]
+    for i, m in enumerate(model.down):
+        hs.append(m.register_forward_hook(hook(f"down.{i}")))
+    for i, m in enumerate(model.up):
+        hs.append(m.register_forward_hook(hook(f"up.{i}")))
+    return taps, hs
+
+
+def g2():
+    B = 48
+    for name, cfg in CONFIGS.items():
+        for flavour, seed in (("trained", 11), ("init", 12)):
+            if flavour == "init" and name not in ("msr80", "tiny"):
+                continue
+            model = ref_unet(cfg)
+            load_synth(model, seed, flavour)
+            rs = np.random.RandomState(100 + seed)
+            D, C = cfg["input_dim"], cfg["cond_dim"]
+            x = torch.from_numpy(rs.standard_normal((B, D)).astype(np.float32))
+            cond = torch.from_numpy(rs.uniform(0, 1, (B, C)).astype(np.float32))
+            out = dict(x=x.numpy(), cond=cond.numpy())
+            want_taps = name in ("msr80", "nu3", "tiny") and flavour == "trained"
+            # (a) training-like: per-row t = ts/T, random mask;  (b)/(c) sampling-like: uniform t, mask 0 / 1
+            ts = torch.from_numpy(rs.randint(0, 20, (1, B)).astype(np.int64))
+            mask = torch.from_numpy((rs.uniform(0, 1, (B, 1)) < 0.7).astype(np.float32))
+            with torch.no_grad():
+                if want_taps:
+                    taps, hs = module_taps(model)
+                out["a_ts"] = ts.numpy(); out["a_T"] = np.int64(20); out["a_mask"] = mask.numpy()
+                out["a_eps"] = model(x, ts / 20, cond, mask).numpy()
+                if want_taps:
+                    for k, v in taps.items():
+                        out[f"a_tap.{k}"] = v
+                    for h in hs:
+                        h.remove()
+                t7 = torch.full((1, B), 7, dtype=torch.int64) / 20
+                out["b_step"] = np.int64(7)
+                out["b_eps"] = model(x, t7, cond, torch.zeros(B, 1)).numpy()
+                out["c_eps"] = model(x, t7, cond, torch.ones(B, 1)).numpy()
+            save(f"g2_unet_{name}_{flavour}.npz", **out)
+
+
+# ---------------------------------------------------------------- G3
+def g3():
+    T = 20
+    for name, B in (("tiny", 48), ("nu3", 48), ("msr80", 40)):
+        cfg = CONFIGS[name]
+        model = ref_unet(cfg)
+        alphas = 1.0 - generate_cosine_schedule(T)
+        D, C = cfg["input_dim"], cfg["cond_dim"]
+        ddpm = RMSR.DDPM(T, model, D, 10.0, alphas, torch.device("cpu"), (1, D), None, 0.1, 0.9999, 10, 5, False)
+        load_synth(ddpm.model, 21, "trained")
+        rs = np.random.RandomState(300)
+        y = torch.from_numpy(rs.uniform(0, 1, (B, D)).astype(np.float32))
+        cond = torch.from_numpy(rs.uniform(0, 1, (B, C)).astype(np.float32))
+        seed = 4321
+        torch.manual_seed(seed)
+        import random
+        random.seed(0)  # keeps the debug print (MSR.py:110) quiet: first random() = 0.844
+        loss = ddpm(y, cond)
+        loss.backward()
+        # the three draws, replayed in the reference's order (MSR.py:101,102,107)
+        torch.manual_seed(seed)
+        ts = torch.randint(low=0, high=T, size=(1, B))
+        noise = torch.randn_like(y)
+        mask = torch.bernoulli(torch.fill(torch.zeros(B), 1 - 0.1))[:, None]
+        out = dict(y=y.numpy(), cond=cond.numpy(), ts=ts.numpy(), noise=noise.numpy(), mask=mask.numpy(),
+                   loss=loss.detach().numpy(), T=np.int64(T))
+        for k, p_ in ddpm.model.named_parameters():
+            g = p_.grad.detach().numpy()
+            if name == "tiny":
+                out["grad." + k] = g
+            else:
+                out["gradnorm." + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                out["gradhead." + k] = g.reshape(-1)[:16].copy()
+        save(f"g3_loss_{name}.npz", **out)
+
+
+# ---------------------------------------------------------------- G4
+def replay_sample_noise(seed, B, D, T):
+    torch.manual_seed(seed)
+    y_T = torch.randn(B, 1, D).squeeze()
+    z = {}
+    for i in range(T - 1, -1, -1):
+        if i > 1:
+            z[i] = torch.randn(B, 1, D).squeeze()
+    return y_T, z
+
+
+def g4():
+    # (1) the shipped NU checkpoint on the first 512 test rows
+    T = 20
+    X_train, Y_train, X_test, Y_test, R_test, ccfg = RNU.nu_data_load("../datasets/3u_18mW_10000samples.csv", 400, 400)
+    K, P_sum = ccfg["K"], ccfg["P_sum"]
+    model = ref_unet(CONFIGS["nu3"])
+    alphas = 1.0 - generate_cosine_schedule(T)
+    ddpm = RNU.DDPM(T, model, K, P_sum, alphas, torch.device("cpu"), (1, 2 + K), ccfg, 0.1, 0.9999, 10, 5, False)
+    sd = torch.load("../ckpts/ddpm_nu_3u.pt", map_location="cpu")
+    ddpm.load_state_dict(sd)
+    B = 512
+    cond = torch.tensor(X_test[:B], dtype=torch.float32)
+    out = dict(cond=cond.numpy(), y_test=np.asarray(Y_test[:B], dtype=np.float32), T=np.int64(T),
+               P_sum=np.float64(P_sum))
+    for k, v in sd.items():
+        if k.startswith("model."):
+            out["w." + k[len("model."):]] = v.numpy()
+    seed = 1234
+    y_T, z = replay_sample_noise(seed, B, 2 + K, T)
+    out["y_T"] = y_T.numpy()
+    out["z"] = np.stack([z[i].numpy() for i in range(T - 1, 1, -1)])  # order: i = T-1 .. 2
+    with torch.no_grad():
+        for omega in (0.0, 1.0, 500.0):
+            torch.manual_seed(seed)
+            ddpm.record_denoise_path = False
+            y0 = ddpm.sample(cond, omega)
+            out[f"om{omega:g}_y0"] = y0.numpy()
+        # per-step eps for omega=1: eps_i_record is kept raw by the record branch (MSR.py:153-154); the NU class's
+        # own record branch references undefined globals (NU.py:176), so the byte-identical MSR class records it.
+        rec = RMSR.DDPM(T, ref_unet(CONFIGS["nu3"]), K, P_sum, alphas, torch.device("cpu"), (1, 2 + K), ccfg)
+        rec.load_state_dict(sd)
+        torch.manual_seed(seed)
+        rec.record_denoise_path = True
+        rec.sample(cond, 1.0)
+        out["om1_eps_steps"] = rec.eps_i_record.reshape(B, T, 2 + K).transpose(1, 0, 2).astype(np.float32)
+        # known answer: less ratio at omega=500 on these rows (0.91359)
+        y0 = torch.from_numpy(out["om500_y0"])
+        Xs = cond.clone()
+        for i in range(K):
+            Xs[:, 2 * i] *= 400
+            Xs[:, 2 * i + 1] *= 400
+        Yd = RNU.custom_decoder(y0, 400, 400, P_sum)
+        Yt = torch.tensor(Y_test[:B], dtype=torch.float32)
+        Yt[:, 0] *= 400; Yt[:, 1] *= 400; Yt[:, 2:] *= P_sum
+        pr, tr = RNU.rate_calc(Yd, Xs), RNU.rate_calc(Yt, Xs)
+        out["om500_pred_rate"] = pr.numpy(); out["om500_true_rate"] = tr.numpy()
+        out["om500_less_ratio"] = np.float64(torch.sum(pr) / torch.sum(tr))
+        print("NU less ratio (omega=500, 512 rows):", out["om500_less_ratio"])
+        # fp64 evaluation of the same trajectory -> error budget
+        d64 = RNU.DDPM(T, ref_unet(CONFIGS["nu3"]), K, P_sum, alphas, torch.device("cpu"), (1, 2 + K), ccfg)
+        d64.load_state_dict(sd)
+        d64 = d64.double()
+        for omega in (0.0, 1.0, 500.0):
+            y = y_T.double()
+            c64 = cond.double()
+            for i in range(T - 1, -1, -1):
+                t = (torch.full((1, B), i) / T).double()
+                e0 = d64.model(y, t, c64, torch.zeros(B, 1, dtype=torch.float64))
+                e1 = d64.model(y, t, c64, torch.ones(B, 1, dtype=torch.float64))
+                nz = z[i].double() if i > 1 else 0
+                e = (1 + omega) * e1 - omega * e0
+                y = (y - d64.betas[i] / d64.sqrt_one_minus_alphas_cumprod[i] * e) * d64.reciprocal_sqrt_alphas[i] \
+                    + (1.0 - d64.alphas_cumprod[i - 1 if i - 1 >= 0 else 0]) / (1.0 - d64.alphas_cumprod[i]) * nz
+                if i > T - 5:
+                    y = (y - torch.mean(y)) / torch.sqrt(torch.var(y))
+            out[f"om{omega:g}_y0_f64"] = y.numpy()
+    save("g4_sample_nu_ckpt.npz", **out)
+
+    # (2) synthetic weights, several configs, short T (T=8 also exercises i>T-5 and the i<=1 no-noise rule)
+    for name, B, T in (("tiny", 40, 8), ("msr80", 40, 6), ("msr3", 33, 6), ("co3", 40, 6), ("tiny", 5, 3)):
+        cfg = CONFIGS[name]
+        D, C = cfg["input_dim"], cfg["cond_dim"]
+        alphas = 1.0 - generate_cosine_schedule(T)
+        ddpm = RMSR.DDPM(T, ref_unet(cfg), D, 10.0, alphas, torch.device("cpu"), (1, D), None)
+        load_synth(ddpm.model, 31, "trained")
+        rs = np.random.RandomState(400)
+        cond = torch.from_numpy(rs.uniform(0, 1, (B, C)).astype(np.float32))
+        seed = 77
+        y_T, z = replay_sample_noise(seed, B, D, T)
+        out = dict(cond=cond.numpy(), y_T=y_T.numpy(), T=np.int64(T),
+                   z=(np.stack([z[i].numpy() for i in range(T - 1, 1, -1)]) if T > 2 else np.zeros((0, B, D), np.float32)))
+        with torch.no_grad():
+            for omega in (0.0, 1.0, 3.0):
+                torch.manual_seed(seed)
+                out[f"om{omega:g}_y0"] = ddpm.sample(cond, omega).numpy()
+        save(f"g4_sample_{name}_T{T}.npz", **out)
+
+
+# ---------------------------------------------------------------- G5
+def g5():
+    rs = np.random.RandomState(500)
+    out = {}
+    y = torch.from_numpy(rs.standard_normal((64, 3)).astype(np.float32) * 3)
+    g = torch.from_numpy(rs.uniform(0.5, 2.5, (64, 3)).astype(np.float32))
+    out["msr_y"] = y.numpy(); out["msr_gain"] = g.numpy()
+    dec = RMSR.custom_decoder(y)
+    out["msr_dec"] = dec.numpy()
+    out["msr_rate"] = torch.sum(torch.log2(1.0 + 10.0 * dec * g), dim=1).numpy()
+    y = torch.from_numpy(rs.standard_normal((64, 3)).astype(np.float32) * 8)
+    y[5] = -11.0
+    X = torch.from_numpy(rs.uniform(0.05, 4.0, (64, 9)).astype(np.float32))
+    out["co_y"] = y.numpy(); out["co_X"] = X.numpy()
+    dec = RCO.customized_real_decoder(y)
+    out["co_dec"] = dec.numpy()
+    out["co_cost"] = RCO.cost_calc(X, dec).numpy()
+    y = torch.from_numpy(rs.standard_normal((64, 5)).astype(np.float32) * 2)
+    X = torch.from_numpy(rs.uniform(0, 400, (64, 6)).astype(np.float32))
+    out["nu_y"] = y.numpy(); out["nu_X"] = X.numpy()
+    dec = RNU.custom_decoder(y, 400, 400, 18.0)
+    out["nu_dec"] = dec.numpy()
+    out["nu_rate"] = RNU.rate_calc(dec, X).numpy()
+    save("g5_decoders.npz", **out)
+
+
+# ---------------------------------------------------------------- G6
+def g6():
+    """Loader outputs on 200-row slices of the shipped CSVs (the slices are committed as data fixtures)."""
+    import pandas as pd
+    ddir = os.path.join(HERE, "data")
+    os.makedirs(ddir, exist_ok=True)
+    out = {}
+    n = 200
+    for src, dst in (("3c_10w_10000samples.csv", f"3c_10w_{n}samples.csv"),
+                     ("3u_18mW_10000samples.csv", f"3u_18mW_{n}samples.csv"),
+                     ("3nodes_2000samples_ood.csv", f"3nodes_{n}samples_ood.csv")):
+        df = pd.read_csv(os.path.join(REF, "datasets", src), header=None)
+        df.iloc[:n].to_csv(os.path.join(ddir, dst), header=False, index=False, float_format="%.17g")
+    Xtr, Ytr, Xte, Yte, cfg = RMSR.msr_data_load(os.path.join(ddir, f"3c_10w_{n}samples.csv"))
+    out.update(msr_Xtr=Xtr, msr_Ytr=Ytr, msr_Xte=Xte, msr_Yte=Yte,
+               msr_cfg=np.array([cfg["M"], cfg["W"], cfg["scaler_min"], cfg["scaler_max"]], dtype=np.float64))
+    Xtr, Ytr, Xte, Yte, Rte, cfg = RNU.nu_data_load(os.path.join(ddir, f"3u_18mW_{n}samples.csv"), 400, 400)
+    out.update(nu_Xtr=Xtr, nu_Ytr=Ytr, nu_Xte=Xte, nu_Yte=Yte, nu_Rte=Rte,
+               nu_cfg=np.array([cfg["K"], cfg["P_sum"]], dtype=np.float64))
+    Xtr, Ytr, Xte, Yte, cfg = RCO.co_data_load(os.path.join(ddir, f"3nodes_{n}samples_ood.csv"))
+    out.update(co_Xtr=Xtr, co_Ytr=Ytr, co_Xte=Xte, co_Yte=Yte,
+               co_cfg=np.array([cfg["scaler_min"], cfg["scaler_max"]], dtype=np.float64))
+    # full-file facts recorded as numbers only
+    Xtr, Ytr, Xte, Yte, cfg = RMSR.msr_data_load("../datasets/3c_10w_10000samples.csv")
+    out["msr_full_shapes"] = np.array([*Xtr.shape, *Ytr.shape, *Xte.shape, *Yte.shape])
+    out["msr_full_cfg"] = np.array([cfg["M"], cfg["W"], cfg["scaler_min"], cfg["scaler_max"]], dtype=np.float64)
+    save("g6_loaders.npz", **out)
+
+
+# ---------------------------------------------------------------- G7
+def g7():
+    layout = {}
+    for name, cfg in CONFIGS.items():
+        T = 20
+        D = cfg["input_dim"]
+        ddpm = RMSR.DDPM(T, ref_unet(cfg), D, 10.0, 1.0 - generate_cosine_schedule(T), torch.device("cpu"), (1, D), None)
+        layout[name] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in ddpm.state_dict().items()]
+    with open(os.path.join(HERE, "g7_state_layout.json"), "w") as f:
+        json.dump(layout, f)
+    print("wrote g7_state_layout.json", {k: len(v) for k, v in layout.items()})
+    # EMA: AveragedModel semantics on the tiny net, three updates
+    from ddpm_opt.ema import ExponentialMovingAverage
+    model = ref_unet(CONFIGS["tiny"])
+    load_synth(model, 41, "trained")
+    ema = ExponentialMovingAverage(model, 0.9)
+    out = {}
+    for step in range(3):
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.add_(0.01 * (step + 1))
+        ema.update_parameters(model)
+        out[f"step{step}_n"] = ema.n_averaged.numpy().copy()
+        out[f"step{step}_feature_proj.weight"] = ema.module.feature_proj.weight.detach().numpy().copy()
+        out[f"step{step}_norm.bias"] = ema.module.norm.bias.detach().numpy().copy()
+    save("g7_ema.npz", **out)
+
+
+if __name__ == "__main__":
+    groups = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7)
+    for g in (sys.argv[1:] or list(groups)):
+        groups[g]()
