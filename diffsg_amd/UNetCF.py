@@ -1,0 +1,218 @@
+"""UNet1D -- the conditional MLP "1-D U-Net" denoiser (reference: ddpm_opt/UNetCF.py:260-356).
+
+The module tree below exists only to own the parameters under the reference's state-dict keys (SURVEY.md 5.4:
+`feature_proj`, `time_emb.lin{1,2}`, `down.<i>.res.*` / `down.<i>.lin`, `middle.res{1,2}`, `up.<i>.res.*` /
+`up.<i>.lin`, `norm`, `final`) and to construct them in the reference's order, so a seeded construction gives the
+reference's initial weights and `load_state_dict(strict=True)` accepts the reference's checkpoints.  No arithmetic
+happens in Python: `forward` hands device pointers to libdiffsg_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _ParamsOnly(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("parameter holder: the arithmetic lives in libdiffsg_hip.so (call UNet1D.forward)")
+
+
+class TimeEmbedding(_ParamsOnly):
+    """UNetCF.py:17-28."""
+
+    def __init__(self, in_dim):
+        super().__init__()
+        self.in_dim = in_dim
+        self.lin1 = nn.Linear(in_dim // 4, in_dim)
+        self.lin2 = nn.Linear(in_dim, in_dim)
+
+
+class ResidualBlock(_ParamsOnly):
+    """UNetCF.py:49-81 (registration order matters for RNG parity and state-dict order)."""
+
+    def __init__(self, in_dim, out_dim, time_dim, cond_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(in_dim)
+        self.lin1 = nn.Linear(in_dim, out_dim)
+        self.norm2 = nn.LayerNorm(out_dim)
+        self.lin2 = nn.Linear(out_dim, out_dim)
+        self.norm3 = nn.LayerNorm(out_dim)
+        self.lin3 = nn.Linear(out_dim, out_dim)
+        if in_dim != out_dim:
+            self.shortcut = nn.Linear(in_dim, out_dim)
+        self.time_emb = nn.Linear(time_dim, out_dim)
+        self.cond_emb = nn.Linear(cond_dim, out_dim)
+
+
+class _ResHolder(_ParamsOnly):
+    def __init__(self, in_dim, out_dim, time_dim, cond_dim):
+        super().__init__()
+        self.res = ResidualBlock(in_dim, out_dim, time_dim, cond_dim)
+
+
+class DownBlock(_ResHolder):
+    """UNetCF.py:160-168."""
+
+
+class UpBlock(_ResHolder):
+    """UNetCF.py:182-192: the block sees cat(x, skip), i.e. in_dim + out_dim features."""
+
+    def __init__(self, in_dim, out_dim, time_dim, cond_dim):
+        super().__init__(in_dim + out_dim, out_dim, time_dim, cond_dim)
+
+
+class MiddleBlock(_ParamsOnly):
+    """UNetCF.py:206-215."""
+
+    def __init__(self, dim, time_dim, cond_dim):
+        super().__init__()
+        self.res1 = ResidualBlock(dim, dim, time_dim, cond_dim)
+        self.res2 = ResidualBlock(dim, dim, time_dim, cond_dim)
+
+
+class _LinHolder(_ParamsOnly):
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.lin = nn.Linear(in_dim, out_dim)
+
+
+class Upsample(_LinHolder):
+    """UNetCF.py:230-233."""
+
+
+class Downsample(_LinHolder):
+    """UNetCF.py:245-248."""
+
+
+class _Native:
+    """Owner of the dsg_handle; never copied or pickled with the module."""
+
+    def __init__(self):
+        self.handle = None
+        self.bound_key = None
+
+    def __deepcopy__(self, memo):
+        return _Native()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.handle = None
+        self.bound_key = None
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().dsg_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+class UNet1D(nn.Module):
+
+    def __init__(self, input_dim=3, proj_dim=16, cond_dim=4,
+                 dims=(8, 4, 2),
+                 is_attn=(False, False, False),
+                 middle_attn=False,
+                 n_blocks=2):
+        super().__init__()
+        if any(is_attn) or middle_attn:
+            raise NotImplementedError("AttentionBlock is never enabled by the reference's call sites and is not built")
+        self.cfg = dict(input_dim=int(input_dim), proj_dim=int(proj_dim), cond_dim=int(cond_dim),
+                        dims=tuple(int(d) for d in dims), n_blocks=int(n_blocks))
+        time_dim = proj_dim * 4
+        n_res = len(dims)
+        self.feature_proj = nn.Linear(input_dim, proj_dim)
+        self.time_emb = TimeEmbedding(time_dim)
+
+        down = []
+        width = proj_dim
+        for i in range(n_res):
+            down += [DownBlock(width, width, time_dim, cond_dim) for _ in range(n_blocks)]
+            down.append(Downsample(width, dims[i]))
+            width = dims[i]
+            if i == n_res - 1:
+                down += [DownBlock(width, width, time_dim, cond_dim) for _ in range(n_blocks)]
+        self.down = nn.ModuleList(down)
+        self.middle = MiddleBlock(width, time_dim, cond_dim)
+        up = []
+        for i in reversed(range(n_res)):
+            up += [UpBlock(width, width, time_dim, cond_dim) for _ in range(n_blocks + 1)]
+            nxt = dims[i - 1] if i > 0 else proj_dim
+            up.append(Upsample(width, nxt))
+            width = nxt
+            if i == 0:
+                up += [UpBlock(width, width, time_dim, cond_dim) for _ in range(n_blocks + 1)]
+        self.up = nn.ModuleList(up)
+        self.norm = nn.LayerNorm(width)
+        self.final = nn.Linear(width, input_dim)
+        self._native = _Native()
+
+    # ------------------------------------------------------------------ native plumbing
+    def native_handle(self):
+        """Create (once) the dsg handle and (re)bind the current parameter tensors; returns the raw handle."""
+        L = _lib.lib()
+        nat = self._native
+        params = list(self.state_dict(keep_vars=True).items())
+        if not params[0][1].is_cuda:
+            raise RuntimeError("UNet1D: parameters are not on a HIP device; libdiffsg_hip has no CPU path "
+                               "(move the model with .to('cuda'))")
+        if nat.handle is None:
+            c = self.cfg
+            d = _lib.UNetDesc()
+            d.input_dim, d.proj_dim, d.cond_dim, d.n_blocks = c["input_dim"], c["proj_dim"], c["cond_dim"], c["n_blocks"]
+            d.n_res = len(c["dims"])
+            for i, v in enumerate(c["dims"]):
+                d.dims[i] = v
+            with torch.cuda.device(params[0][1].device):
+                hd = L.dsg_create(ctypes.byref(d))
+            if not hd:
+                raise RuntimeError("libdiffsg_hip: " + L.dsg_last_error().decode())
+            nat.handle = hd
+            n = L.dsg_param_count(hd)
+            names = [L.dsg_param_name(hd, i).decode() for i in range(n)]
+            if names != [k for k, _ in params]:
+                raise RuntimeError("state-dict layout mismatch between UNet1D and libdiffsg_hip")
+            for i, (k, v) in enumerate(params):
+                if v.numel() != L.dsg_param_numel(hd, i):
+                    raise RuntimeError(f"size mismatch for {k}")
+        key = tuple((v.data_ptr(), v._version) for _, v in params)
+        if key != nat.bound_key:
+            for k, v in params:
+                if v.dtype != torch.float32 or not v.is_contiguous():
+                    raise RuntimeError(f"{k}: parameters must be contiguous float32")
+            arr = (ctypes.c_void_p * len(params))(*[v.data_ptr() for _, v in params])
+            with torch.cuda.device(params[0][1].device):
+                _lib.check(L.dsg_bind_weights(nat.handle, arr, len(params), _lib.stream_ptr()))
+            nat.bound_key = key
+        return nat.handle
+
+    def forward(self, x, t, cond, cond_mask):
+        """
+        :param x: (batch_size, input_dim)
+        :param t: (1, batch_size) time value already divided by T
+        :param cond: (batch_size, cond_dim)
+        :param cond_mask: (batch_size, 1)
+        :return: estimated noise (batch_size, input_dim).  Inference only: gradients flow through DDPM.forward.
+        """
+        hd = self.native_handle()
+        B = x.shape[0]
+        x = x.detach().to(torch.float32).contiguous()
+        cond = cond.detach().to(torch.float32).contiguous()
+        tv = t.detach().to(torch.float32).reshape(-1).contiguous()
+        mk = cond_mask.detach().to(torch.float32).reshape(-1).contiguous()
+        if tv.numel() != B or mk.numel() != B or cond.shape[0] != B:
+            raise ValueError("t, cond and cond_mask must have one entry per row of x")
+        if x.shape[1] != self.cfg["input_dim"] or cond.shape[1] != self.cfg["cond_dim"]:
+            raise ValueError("x / cond feature size does not match the model")
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().dsg_unet_forward(hd, _lib.ptr(x), _lib.ptr(tv), _lib.ptr(cond), _lib.ptr(mk),
+                                                   _lib.ptr(out), B, _lib.stream_ptr()))
+        return out

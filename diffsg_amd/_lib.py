@@ -1,0 +1,99 @@
+"""ctypes binding of libdiffsg_hip.so (C ABI: include/diffsg.h).
+
+There is deliberately no fallback: if the HIP library cannot be loaded, or no MI355X is visible, every compute entry
+point raises.  PyTorch is used only for device memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffsg_hip.so")
+SOURCES = [os.path.join(_HERE, "csrc", "dsg_api.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "dsg_kernels.hpp"),
+           os.path.join(os.path.dirname(_HERE), "include", "diffsg.h")]
+
+MAX_RES = 8
+
+
+class UNetDesc(ctypes.Structure):
+    _fields_ = [("input_dim", ctypes.c_int), ("proj_dim", ctypes.c_int), ("cond_dim", ctypes.c_int),
+                ("n_res", ctypes.c_int), ("dims", ctypes.c_int * MAX_RES), ("n_blocks", ctypes.c_int)]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU)."""
+    deps = [p for p in SOURCES + HEADERS if os.path.exists(p)]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(p) for p in deps)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+           "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "dsg_create": (ctypes.c_void_p, [ctypes.POINTER(UNetDesc)]),
+    "dsg_destroy": (None, [ctypes.c_void_p]),
+    "dsg_last_error": (ctypes.c_char_p, []),
+    "dsg_param_count": (ctypes.c_int, [ctypes.c_void_p]),
+    "dsg_param_name": (ctypes.c_char_p, [ctypes.c_void_p, ctypes.c_int]),
+    "dsg_param_numel": (ctypes.c_longlong, [ctypes.c_void_p, ctypes.c_int]),
+    "dsg_bind_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
+    "dsg_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "dsg_unet_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
+    "dsg_sample": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong,
+                                  ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_void_p]),
+    "dsg_ema_update": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_longlong,
+                                      ctypes.c_void_p]),
+    "dsg_op_count": (ctypes.c_int, [ctypes.c_void_p]),
+    "dsg_op_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
+                                   ctypes.POINTER(ctypes.c_double)]),
+    "dsg_time_op": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                   ctypes.c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback for this path")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export what diffsg.h declares
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError("libdiffsg_hip: " + lib().dsg_last_error().decode())
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,140 @@
+"""Classifier-free-guidance DDPM for Computation Offloading (reference: ddpm_opt/classifier_free_CO.py).
+
+Entry points kept: `DDPM`, `co_data_load`, `train_ddpm_co`, `cost_calc`, `customized_real_decoder`, `load_test_co`;
+constants of the reference as defaults (UNet1D(proj 64, dims (64,32,16,8), n_blocks 3), lr 5e-3,
+MultiStepLR [15,80,150], omega 500).
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import torch
+import torch.optim as optim
+import torch.utils.data as data
+
+from .ddpm import DDPMCore
+from .diffusion import generate_cosine_schedule, init_weights
+from .UNetCF import UNet1D
+
+DEFAULT_DATASET = "../datasets/3nodes_50000samples_new.csv"
+
+
+class DDPM(DDPMCore):
+    """classifier_free_CO.py:55-98: positional order (T, model, node_num, alphas, device, data_size, ...)."""
+
+    def __init__(self, T, model, node_num, alphas, device, data_size, custom_config=None, uncond_prob=0.1,
+                 ema_decay=0.9999, ema_start=1000, ema_update_rate=5, debug=False):
+        super().__init__()
+        self.node_num = node_num
+        self._setup(T, model, alphas, device, data_size, custom_config, uncond_prob, ema_decay, ema_start,
+                    ema_update_rate, debug)
+
+
+def data_preprocess_co(X):
+    """utils/dataset.py:26-51: (6 per-node + 7 common raw features) -> 3 cost features per node
+    (local cost, offload transition cost, ideal offload execution cost)."""
+    node_num = (X.shape[1] - 7) // 6
+    F_t, kappa, Pt, PI, theta, Bw, N0 = (X[:, -7 + i] for i in range(7))
+    col = lambda i, j: X[:, 6 * i + j]
+    interference = sum(Pt * col(i, 3) ** 2 for i in range(node_num))
+    out = np.zeros((X.shape[0], node_num * 3))
+    for i in range(node_num):
+        d, c, f, hgain, a = col(i, 0), col(i, 1), col(i, 2), col(i, 3), col(i, 4)
+        r_u = Bw * np.log2(1.0 + Pt * hgain ** 2 / (N0 + interference))
+        out[:, 3 * i] = a * c / f + (1.0 - a) * kappa * f ** 2 * c
+        out[:, 3 * i + 1] = a * d / r_u + (1.0 - a) * Pt * d / r_u
+        out[:, 3 * i + 2] = a * c / F_t + (1.0 - a) * PI * c / F_t
+    return out
+
+
+_COMMON = np.array([[2.5e9, 1e-28, 0.3, 0.1, 1.0, 10e5, 7.96159e-13]], dtype=float)  # F_t kappa Pt PI theta B N0
+
+
+def co_data_load(dataset_path):
+    """classifier_free_CO.py:158-200.  Rows with any simplified feature >= 10 are dropped; the 70/30 split sizes
+    come from the PRE-filter row count (:198-199)."""
+    src = np.array(pd.read_csv(dataset_path, header=None))
+    rows = src.shape[0]
+    node_num = (src.shape[1] - 1) // 7
+    X, Y = src[:, :6 * node_num], src[:, -node_num:]
+    X = data_preprocess_co(np.concatenate((X, np.tile(_COMMON, (rows, 1))), axis=1))
+    keep = np.all(X < 10.0, axis=1)
+    X, Y = X[keep], Y[keep]
+    lo, hi = np.min(X), np.max(X)
+    X = (X - lo) / (hi - lo)
+    custom_config = {'sfn': 3, 'cfn': 0, 'cdim': 1, 'scaler_min': lo, 'scaler_max': hi}
+    n_tr, n_te = int(rows * 0.7), int(rows * 0.3)
+    return X[:n_tr], Y[:n_tr], X[-n_te:], Y[-n_te:], custom_config
+
+
+def build_model(node_num, cond_dim, device, T=20, custom_config=None):
+    """classifier_free_CO.py:216-227."""
+    alphas = 1.0 - generate_cosine_schedule(T)
+    model = UNet1D(input_dim=node_num, proj_dim=64, cond_dim=cond_dim, dims=(64, 32, 16, 8),
+                   is_attn=(False, False, False, False), middle_attn=False, n_blocks=3)
+    return DDPM(T, model, node_num, alphas, device, (1, node_num), custom_config, 0.1, 0.9999, 10, 5, False)
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device: this build of DiffSG has no CPU path")
+    return torch.device("cuda:0")
+
+
+def train_ddpm_co(dataset_path=DEFAULT_DATASET, epochs=200, T=20, use_ema=False, warmup_epoch=5, batch_size=512,
+                  lr=0.005, milestones=(15, 80, 150), log=print):
+    """classifier_free_CO.py:203-252."""
+    X_train, Y_train, _, _, custom_config = co_data_load(dataset_path)
+    dataset = data.TensorDataset(torch.tensor(X_train, dtype=torch.float32), torch.tensor(Y_train, dtype=torch.float32))
+    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True)
+    node_num = Y_train.shape[1]
+    device = _device()
+    diffusion_model = build_model(node_num, custom_config['sfn'] * node_num, device, T, custom_config)
+    diffusion_model.apply(init_weights)
+    diffusion_model.to(device)
+    optimizer = optim.Adam(diffusion_model.parameters(), lr=lr)
+    scheduler = optim.lr_scheduler.MultiStepLR(optimizer, list(milestones))
+    from .train import run_epochs
+    run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log)
+    return diffusion_model
+
+
+def cost_calc(X, Y):
+    """classifier_free_CO.py:255-278."""
+    from .decode import co_cost
+    return co_cost(X, Y)
+
+
+def customized_real_decoder(Y_pred):
+    """classifier_free_CO.py:281-290."""
+    from .decode import co_decode
+    return co_decode(Y_pred)
+
+
+@torch.no_grad()
+def load_test_co(ckpt_path, dataset_path=DEFAULT_DATASET, T=20, omega=500.0, batch_size=512, log=print):
+    """classifier_free_CO.py:293-356."""
+    X_train, Y_train, X_test, Y_test, custom_config = co_data_load(dataset_path)
+    node_num = Y_train.shape[1]
+    device = _device()
+    diffusion_model = build_model(node_num, custom_config['sfn'] * node_num, device, T, custom_config)
+    diffusion_model.load_state_dict(torch.load(ckpt_path, map_location="cpu"))
+    diffusion_model.to(device)
+    X = torch.tensor(X_test, dtype=torch.float32)
+    Y_pred = torch.cat([diffusion_model.sample(X[i:i + batch_size].to(device), omega) for i in range(0, len(X), batch_size)])
+    Xt = X.to(device) * (custom_config['scaler_max'] - custom_config['scaler_min']) + custom_config['scaler_min']
+    Yt = torch.tensor(Y_test, dtype=torch.float32, device=device)
+    Yd = customized_real_decoder(Y_pred)
+    pred_cost, true_cost = cost_calc(Xt, Yd), cost_calc(Xt, Yt)
+    weights = 2 ** torch.arange(node_num - 1, -1, -1, device=device)
+    pred_cls = ((Yd > 0.1).long() * weights).sum(dim=1)
+    true_cls = ((Yt > 0.1).long() * weights).sum(dim=1)
+    terrible = ((pred_cost / true_cost > 1.2) & (pred_cost > 10.0)).sum()
+    out = {"exceeded_ratio": float(torch.sum(pred_cost) / torch.sum(true_cost)),
+           "avg_cost_diff": float(torch.mean(pred_cost - true_cost)),
+           "terrible": int(terrible), "accuracy": int((pred_cls == true_cls).sum()), "n": int(X.shape[0])}
+    log(f"exceeded ratio: {out['exceeded_ratio']}")
+    log(f"avg cost diff:\n {out['avg_cost_diff']}")
+    log(f"terrible samples num: {out['terrible']}/{out['n']}.")
+    log(f"accuracy: {out['accuracy']}/{out['n']}")
+    return out

@@ -1,0 +1,687 @@
+// DiffSG denoiser hot path -- gfx950 (MI355X / CDNA4) device code.
+//
+// Every activation lives in the "fragment layout" of v_mfma_f32_32x32x2_f32 so that a chain of
+// Linear layers never moves data across lanes:
+//
+//   a wave owns a TILE of 32 batch rows.  Lane l = 32*h + j holds row j; a width-w tensor is w/8
+//   GROUPS of 8 features; group G is one float4 per lane holding features 8G + 4h + {0,1,2,3}.
+//
+//   * as MFMA B operand  (B[k][j], lane holds k = h):  element p of group G is k-step p of G;
+//   * the MFMA result D[i][j] for an output tile nt has out-feature i = (r&3) + 8(r>>2) + 4h in
+//     accumulator register r, i.e. registers 4q..4q+3 of tile nt ARE group 4nt+q of the output.
+//
+//   So the accumulator of one Linear is, register for register, the B operand of the next one, and
+//   LayerNorm / SiLU / bias / residual are plain per-register VALU work (row statistics need one
+//   exchange between the two lane halves).  Weights are pre-packed once (k_pack_linear) into the
+//   matching A-operand order so that every weight fetch is one coalesced 1 KiB float4 wave load.
+//
+// In HBM a tensor is [tile][group][lane(64)][4] floats (1 KiB per tile-group, fully coalesced) plus
+// per-row LayerNorm statistics (mean, M2) written by the producer.
+//
+// Reference semantics: /root/reference/ddpm_opt/UNetCF.py (cited per kernel below).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 32;          // batch rows per wave tile
+constexpr int kWavesPerBlock = 4;  // one wave per SIMD
+constexpr float kLnEps = 1e-5f;    // nn.LayerNorm default (UNetCF.py:60)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// Swish, UNetCF.py:14: x * sigmoid(x)
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+
+#define DSG_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
+
+// One k-group (4 k-steps) into NT output tiles.  wbase points at packed[(nt*KG + g)*256 + lane*4].
+template <int NT>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[NT], const float* __restrict__ wp, size_t nt_stride,
+                                           float b0, float b1, float b2, float b3) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float4 w = ld4(wp + nt * nt_stride);
+        DSG_MFMA(acc[nt], w.x, b0);
+        DSG_MFMA(acc[nt], w.y, b1);
+        DSG_MFMA(acc[nt], w.z, b2);
+        DSG_MFMA(acc[nt], w.w, b3);
+    }
+}
+
+// acc <- per-feature vector (padded to NT*32 floats) in accumulator order.
+template <int NT>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[NT], const float* __restrict__ vec, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = ld4(vec + 32 * nt + 8 * q + 4 * h);
+            acc[nt][4 * q + 0] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
+        }
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_add(f32x16 (&acc)[NT], const float* __restrict__ vec, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = ld4(vec + 32 * nt + 8 * q + 4 * h);
+            acc[nt][4 * q + 0] += b.x; acc[nt][4 * q + 1] += b.y; acc[nt][4 * q + 2] += b.z; acc[nt][4 * q + 3] += b.w;
+        }
+}
+
+// Row statistics of an accumulator-resident tensor of true width N: mean and M2 = sum (x-mean)^2.
+template <int N, int NT>
+__device__ __forceinline__ void acc_stats(const f32x16 (&acc)[NT], int h, float& mean, float& m2) {
+    constexpr int NG = (N + 7) / 8;
+    float s = 0.f;
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (8 * G + 4 * h + p < N) s += acc[G >> 2][4 * (G & 3) + p];
+    mean = xhalf_sum(s) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (8 * G + 4 * h + p < N) {
+                const float d = acc[G >> 2][4 * (G & 3) + p] - mean;
+                q = fmaf(d, d, q);
+            }
+    m2 = xhalf_sum(q);
+}
+
+// B operands for a chain whose input is an accumulator: act = silu(LN(acc)), then MFMA into `out`.
+// ResidualBlock stages 2 and 3 (UNetCF.py:92,94).
+template <int N, int NT>
+__device__ __forceinline__ void chain_from_acc(f32x16 (&out)[NT], const f32x16 (&in)[NT], const float* __restrict__ wp,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               float mean, float rstd, int lane, int h) {
+    constexpr int NG = (N + 7) / 8;
+    const size_t nt_stride = (size_t)NG * 256;
+#pragma unroll
+    for (int G = 0; G < NG; ++G) {
+        const float4 gm = ld4(gamma + 8 * G + 4 * h);
+        const float4 bt = ld4(beta + 8 * G + 4 * h);
+        const float b0 = silu(fmaf((in[G >> 2][4 * (G & 3) + 0] - mean) * rstd, gm.x, bt.x));
+        const float b1 = silu(fmaf((in[G >> 2][4 * (G & 3) + 1] - mean) * rstd, gm.y, bt.y));
+        const float b2 = silu(fmaf((in[G >> 2][4 * (G & 3) + 2] - mean) * rstd, gm.z, bt.z));
+        const float b3 = silu(fmaf((in[G >> 2][4 * (G & 3) + 3] - mean) * rstd, gm.w, bt.w));
+        mfma_group<NT>(out, wp + (size_t)G * 256 + lane * 4, nt_stride, b0, b1, b2, b3);
+    }
+}
+
+// A fragment-layout tensor in HBM.
+struct Seg {
+    const float* data;   // [tiles][groups][64][4]
+    const float* stats;  // [tiles*32][2] = (mean, M2) per row, may be null when unused
+    int groups;          // ceil(width/8)
+    int width;           // true feature count
+};
+
+// ---------------------------------------------------------------------------------------------
+// ResidualBlock forward (UNetCF.py:83-95), one wave per 32-row tile:
+//   h1 = W1 silu(LN1(x)) + [b1 + time bias]           time bias row chosen by step (sampling) or ts[row]
+//   h2 = W2 silu(LN2(h1)) + [b2 + bc] + Wc silu(cond)  cond term skipped for tiles < uncond_tiles
+//   out = W3 silu(LN3(h2)) + b3 + shortcut(x)          shortcut = identity or Linear(cat) (UNetCF.py:72-75)
+// x is the concatenation of up to two HBM tensors (skip concat, UNetCF.py:351, never materialised).
+// ---------------------------------------------------------------------------------------------
+struct BlockArgs {
+    Seg in0, in1;
+    const float* W1;      // packed [NT][KG][256], KG = in0.groups + in1.groups
+    const float* gamma1;  // [KG*8] group order
+    const float* beta1;
+    const float* tbias;   // [entries][tb_stride]; this block's slice starts at tbias (+ entry*tb_stride)
+    const int* step_ptr;  // device step counter (sampling) or null
+    const int* ts;        // per-row entry index (training / generic forward) or null
+    int tb_stride;
+    const float* W2;      // packed [NT][NG][256]
+    const float* gamma2;
+    const float* beta2;
+    const float* c2;      // b2 + bc, padded NT*32
+    const float* Wc;      // packed [NT][CG][256]
+    const float* condfrag;  // [tiles_per_pass][CG][64][4] = silu(cond * mask)
+    int cond_groups;
+    const float* W3;
+    const float* gamma3;
+    const float* beta3;
+    const float* c3;      // b3 (+ b_shortcut)
+    const float* Wsc;     // packed [NT][KG][256] or null (identity)
+    float* out;           // [tiles][NG][64][4]
+    float* out_stats;     // [tiles*32][2]
+    float* save_h1;       // training: pre-LN2 / pre-LN3 tensors for the backward pass, or null
+    float* save_h2;
+    int ntiles;           // all passes
+    int tiles_per_pass;
+    int uncond_tiles;     // tiles [0, uncond_tiles) skip the condition term (Swish(0) = 0)
+    int nrows;            // valid rows per pass
+};
+
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {
+    constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int h = lane >> 5, j = lane & 31;
+    const int ptile = tile % a.tiles_per_pass;
+    const int KG = a.in0.groups + a.in1.groups;
+
+    // ---- LN1 statistics from the producers' per-row (mean, M2), combined over the concat (Chan)
+    float mean1, rstd1;
+    {
+        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
+        float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
+        if (a.in1.groups) {
+            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
+            const float n1 = (float)a.in1.width, nt_ = n + n1;
+            const float d = s1.x - mean;
+            m2 = m2 + s1.y + d * d * (n * n1 / nt_);
+            mean = mean + d * (n1 / nt_);
+            n = nt_;
+        }
+        mean1 = mean;
+        rstd1 = rsqrtf(m2 / n + kLnEps);
+    }
+
+    // ---- stage 1
+    f32x16 acc1[NT];
+    {
+        int entry = 0;
+        if (a.ts) {
+            int row = ptile * 32 + j;
+            row = row < a.nrows ? row : a.nrows - 1;
+            entry = a.ts[row];
+        } else if (a.step_ptr) {
+            entry = *a.step_ptr;
+        }
+        acc_init<NT>(acc1, a.tbias + (size_t)entry * a.tb_stride, h);
+    }
+    {
+        const size_t nt_stride = (size_t)KG * 256;
+        const float* xp = a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4;
+        for (int g = 0; g < a.in0.groups; ++g) {
+            const float4 xv = ld4(xp + (size_t)g * 256);
+            const float4 gm = ld4(a.gamma1 + 8 * g + 4 * h), bt = ld4(a.beta1 + 8 * g + 4 * h);
+            mfma_group<NT>(acc1, a.W1 + (size_t)g * 256 + lane * 4, nt_stride,
+                           silu(fmaf((xv.x - mean1) * rstd1, gm.x, bt.x)), silu(fmaf((xv.y - mean1) * rstd1, gm.y, bt.y)),
+                           silu(fmaf((xv.z - mean1) * rstd1, gm.z, bt.z)), silu(fmaf((xv.w - mean1) * rstd1, gm.w, bt.w)));
+        }
+        if (a.in1.groups) {
+            const float* sp = a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4;
+            for (int g = 0; g < a.in1.groups; ++g) {
+                const int gg = a.in0.groups + g;
+                const float4 xv = ld4(sp + (size_t)g * 256);
+                const float4 gm = ld4(a.gamma1 + 8 * gg + 4 * h), bt = ld4(a.beta1 + 8 * gg + 4 * h);
+                mfma_group<NT>(acc1, a.W1 + (size_t)gg * 256 + lane * 4, nt_stride,
+                               silu(fmaf((xv.x - mean1) * rstd1, gm.x, bt.x)), silu(fmaf((xv.y - mean1) * rstd1, gm.y, bt.y)),
+                               silu(fmaf((xv.z - mean1) * rstd1, gm.z, bt.z)), silu(fmaf((xv.w - mean1) * rstd1, gm.w, bt.w)));
+            }
+        }
+    }
+    if (a.save_h1) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+            st4(a.save_h1 + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc1[G >> 2][4 * (G & 3)], acc1[G >> 2][4 * (G & 3) + 1], acc1[G >> 2][4 * (G & 3) + 2],
+                            acc1[G >> 2][4 * (G & 3) + 3]));
+    }
+
+    // ---- stage 2 (+ condition embedding accumulated into the same chain)
+    f32x16 acc2[NT];
+    {
+        float mean, m2;
+        acc_stats<N, NT>(acc1, h, mean, m2);
+        const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+        acc_init<NT>(acc2, a.c2, h);
+        chain_from_acc<N, NT>(acc2, acc1, a.W2, a.gamma2, a.beta2, mean, rstd, lane, h);
+    }
+    if (tile >= a.uncond_tiles) {
+        const size_t nt_stride = (size_t)a.cond_groups * 256;
+        const float* cp = a.condfrag + (size_t)ptile * a.cond_groups * 256 + lane * 4;
+        for (int g = 0; g < a.cond_groups; ++g) {
+            const float4 cv = ld4(cp + (size_t)g * 256);
+            mfma_group<NT>(acc2, a.Wc + (size_t)g * 256 + lane * 4, nt_stride, cv.x, cv.y, cv.z, cv.w);
+        }
+    }
+    if (a.save_h2) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+            st4(a.save_h2 + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc2[G >> 2][4 * (G & 3)], acc2[G >> 2][4 * (G & 3) + 1], acc2[G >> 2][4 * (G & 3) + 2],
+                            acc2[G >> 2][4 * (G & 3) + 3]));
+    }
+
+    // ---- stage 3 (+ shortcut)
+    f32x16 (&acc3)[NT] = acc1;  // h1 is dead
+    {
+        float mean, m2;
+        acc_stats<N, NT>(acc2, h, mean, m2);
+        const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+        acc_init<NT>(acc3, a.c3, h);
+        chain_from_acc<N, NT>(acc3, acc2, a.W3, a.gamma3, a.beta3, mean, rstd, lane, h);
+    }
+    if (SCLIN) {
+        const size_t nt_stride = (size_t)KG * 256;
+        const float* xp = a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4;
+        for (int g = 0; g < a.in0.groups; ++g) {
+            const float4 xv = ld4(xp + (size_t)g * 256);
+            mfma_group<NT>(acc3, a.Wsc + (size_t)g * 256 + lane * 4, nt_stride, xv.x, xv.y, xv.z, xv.w);
+        }
+        if (a.in1.groups) {
+            const float* sp = a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4;
+            for (int g = 0; g < a.in1.groups; ++g) {
+                const float4 xv = ld4(sp + (size_t)g * 256);
+                mfma_group<NT>(acc3, a.Wsc + (size_t)(a.in0.groups + g) * 256 + lane * 4, nt_stride, xv.x, xv.y, xv.z, xv.w);
+            }
+        }
+    } else {
+        const float* xp = a.in0.data + (size_t)tile * NG * 256 + lane * 4;
+#pragma unroll
+        for (int G = 0; G < NG; ++G) {
+            const float4 xv = ld4(xp + (size_t)G * 256);
+            acc3[G >> 2][4 * (G & 3) + 0] += xv.x; acc3[G >> 2][4 * (G & 3) + 1] += xv.y;
+            acc3[G >> 2][4 * (G & 3) + 2] += xv.z; acc3[G >> 2][4 * (G & 3) + 3] += xv.w;
+        }
+    }
+
+    // ---- store + statistics for the consumer's LayerNorm
+    {
+        float mean, m2;
+        acc_stats<N, NT>(acc3, h, mean, m2);
+        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+            st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2],
+                            acc3[G >> 2][4 * (G & 3) + 3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plain Linear with optional LayerNorm+SiLU prologue and row-major I/O at the network boundary:
+//   feature_proj (UNetCF.py:328)   row-major y[B][D] -> fragment x0          (both passes read the same y)
+//   Down/Upsample (UNetCF.py:230-257)  fragment -> fragment
+//   final (UNetCF.py:356)          fragment -> LN -> SiLU -> Linear -> row-major eps[pass][B][D]
+// ---------------------------------------------------------------------------------------------
+struct LinArgs {
+    Seg in;                 // fragment input (IN_FRAG)
+    const float* in_rm;     // row-major input [nrows][in_width] (IN_ROWMAJOR)
+    int in_width;
+    int in_groups;
+    const float* W;         // packed [NT][KG][256]
+    const float* bias;      // padded NT*32
+    const float* gamma;     // LN prologue (LNACT)
+    const float* beta;
+    float* out;             // fragment out
+    float* out_stats;
+    float* out_rm;          // row-major out [npass][nrows][out_width]
+    int out_width;
+    int ntiles, tiles_per_pass, nrows;
+};
+
+enum { IN_FRAG = 0, IN_ROWMAJOR = 1 };
+enum { OUT_FRAG = 0, OUT_ROWMAJOR = 1 };
+
+template <int NT, int INMODE, int OUTMODE, bool LNACT>
+__global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int h = lane >> 5, j = lane & 31;
+    const int ptile = tile % a.tiles_per_pass;
+    const int pass = tile / a.tiles_per_pass;
+    const int row = ptile * 32 + j;
+    const int KG = a.in_groups;
+    const size_t nt_stride = (size_t)KG * 256;
+
+    f32x16 acc[NT];
+    acc_init<NT>(acc, a.bias, h);
+
+    float mean = 0.f, rstd = 1.f;
+    if (LNACT) {
+        const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)tile * 32 + j];
+        mean = s.x;
+        rstd = rsqrtf(s.y / (float)a.in.width + kLnEps);
+    }
+    for (int g = 0; g < KG; ++g) {
+        float4 xv;
+        if (INMODE == IN_FRAG) {
+            xv = ld4(a.in.data + ((size_t)tile * KG + g) * 256 + lane * 4);
+        } else {
+            float v[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int f = 8 * g + 4 * h + p;
+                v[p] = (row < a.nrows && f < a.in_width) ? a.in_rm[(size_t)row * a.in_width + f] : 0.f;
+            }
+            xv = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (LNACT) {
+            const float4 gm = ld4(a.gamma + 8 * g + 4 * h), bt = ld4(a.beta + 8 * g + 4 * h);
+            xv.x = silu(fmaf((xv.x - mean) * rstd, gm.x, bt.x)); xv.y = silu(fmaf((xv.y - mean) * rstd, gm.y, bt.y));
+            xv.z = silu(fmaf((xv.z - mean) * rstd, gm.z, bt.z)); xv.w = silu(fmaf((xv.w - mean) * rstd, gm.w, bt.w));
+        }
+        mfma_group<NT>(acc, a.W + (size_t)g * 256 + lane * 4, nt_stride, xv.x, xv.y, xv.z, xv.w);
+    }
+
+    if (OUTMODE == OUT_FRAG) {
+        const int NG = (a.out_width + 7) / 8;
+        // statistics over the true width
+        float s = 0.f;
+#pragma unroll
+        for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (8 * G + 4 * h + p < a.out_width) s += acc[G >> 2][4 * (G & 3) + p];
+        const float m = xhalf_sum(s) / (float)a.out_width;
+        float q = 0.f;
+#pragma unroll
+        for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (8 * G + 4 * h + p < a.out_width) {
+                    const float d = acc[G >> 2][4 * (G & 3) + p] - m;
+                    q = fmaf(d, d, q);
+                }
+        q = xhalf_sum(q);
+        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
+#pragma unroll
+        for (int G = 0; G < NT * 4; ++G)
+            if (G < NG)
+                st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                    make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2],
+                                acc[G >> 2][4 * (G & 3) + 3]));
+    } else {
+        if (row < a.nrows) {
+            float* o = a.out_rm + ((size_t)pass * a.nrows + row) * a.out_width;
+#pragma unroll
+            for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int f = 8 * G + 4 * h + p;
+                    if (f < a.out_width) o[f] = acc[G >> 2][4 * (G & 3) + p];
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing: nn.Linear.weight [N][Ktot] row-major -> MFMA A-fragment order
+//   packed[((nt*KG + g)*64 + lane)*4 + p] = W[32nt + (lane&31)][col(g) + 4(lane>>5) + p]
+// The K axis may be the concatenation of two tensors (widths w0, w1) that are padded to a multiple of 8
+// separately, matching the two input segments of k_resblock.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack_linear(const float* __restrict__ W, int N, int Ktot, int w0, int w1, float* __restrict__ out, int NT) {
+    const int g0 = (w0 + 7) / 8, g1 = (w1 + 7) / 8, KG = g0 + g1;
+    const size_t total = (size_t)NT * KG * 256;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int p = idx & 3, lane = (idx >> 2) & 63;
+        const size_t tg = idx >> 8;
+        const int g = tg % KG, nt = tg / KG;
+        const int n = 32 * nt + (lane & 31);
+        int k, ok;
+        if (g < g0) { k = 8 * g + 4 * (lane >> 5) + p; ok = k < w0; }
+        else { const int kk = 8 * (g - g0) + 4 * (lane >> 5) + p; ok = kk < w1; k = w0 + kk; }
+        out[idx] = (ok && n < N && k < Ktot) ? W[(size_t)n * Ktot + k] : 0.f;
+    }
+}
+
+// dst[i] (group-padded over two segments) = a[k] (+ b[k]) ; zero in the padding.  Used for biases and LN params.
+__global__ void k_pad_vec(const float* __restrict__ a, const float* __restrict__ b, int w0, int w1, float* __restrict__ dst, int npad) {
+    const int g0 = (w0 + 7) / 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x) {
+        const int g = i >> 3, e = i & 7;
+        int k, ok;
+        if (g < g0) { k = 8 * g + e; ok = k < w0; }
+        else { const int kk = 8 * (g - g0) + e; ok = kk < w1; k = w0 + kk; }
+        float v = 0.f;
+        if (ok) { v = a[k]; if (b) v += b[k]; }
+        dst[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time path, hoisted out of the per-row work (it depends only on the step / ts value):
+//   TimeEmbedding.forward (UNetCF.py:35-44)  -> st[e] = Swish(temb(t_e))   (Swish from UNetCF.py:91)
+//   per block b:  tb[e][off_b + n] = lin1.bias[n] + time_emb.bias[n] + time_emb.weight[n] . st[e]
+// so that stage 1 of every ResidualBlock starts its accumulator from tb (UNetCF.py:90-91).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one workgroup (256 threads) per entry e; tvals[e] is t (already divided by T)
+__global__ __launch_bounds__(256) void k_time_embed(const float* __restrict__ tvals, const float* __restrict__ freq, int half,
+                                                    const float* __restrict__ W1, const float* __restrict__ b1,
+                                                    const float* __restrict__ W2, const float* __restrict__ b2, int td,
+                                                    float* __restrict__ st) {
+    extern __shared__ float sm[];
+    float* e = sm;            // [2*half]
+    float* h1 = sm + 2 * half;  // [td]
+    const int ent = blockIdx.x;
+    const float t = tvals[ent];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const float ang = t * freq[i];
+        e[i] = sinf(ang);
+        e[half + i] = cosf(ang);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K1 = 2 * half;
+    for (int n = wave; n < td; n += nw) {
+        float s = 0.f;
+        for (int k = lane; k < K1; k += 64) s = fmaf(W1[(size_t)n * K1 + k], e[k], s);
+        s = wave_sum(s) + b1[n];
+        if (lane == 0) h1[n] = silu(s);
+    }
+    __syncthreads();
+    for (int n = wave; n < td; n += nw) {
+        float s = 0.f;
+        for (int k = lane; k < td; k += 64) s = fmaf(W2[(size_t)n * td + k], h1[k], s);
+        s = wave_sum(s) + b2[n];
+        if (lane == 0) st[(size_t)ent * td + n] = silu(s);
+    }
+}
+
+struct TimeBlockDesc {
+    const float* Wt;   // [N][td]
+    const float* bt;   // [N]
+    const float* b1;   // lin1.bias [N]
+    int N;
+    int off;           // offset of this block's slice inside a table row (multiple of 32)
+};
+
+__global__ __launch_bounds__(256) void k_time_table(const float* __restrict__ st, int td, const TimeBlockDesc* __restrict__ blocks,
+                                                    int nblocks, float* __restrict__ tb, int tb_stride) {
+    extern __shared__ float sm[];
+    const int ent = blockIdx.x;
+    for (int i = threadIdx.x; i < td; i += blockDim.x) sm[i] = st[(size_t)ent * td + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int b = blockIdx.y; b < nblocks; b += gridDim.y) {
+        const TimeBlockDesc d = blocks[b];
+        const int npad = (d.N + 31) / 32 * 32;
+        for (int n = wave; n < npad; n += nw) {
+            float v = 0.f;
+            if (n < d.N) {
+                float s = 0.f;
+                for (int k = lane; k < td; k += 64) s = fmaf(d.Wt[(size_t)n * td + k], sm[k], s);
+                v = wave_sum(s) + d.bt[n] + d.b1[n];
+            }
+            if (lane == 0) tb[(size_t)ent * tb_stride + d.off + n] = v;
+        }
+    }
+}
+
+// condfrag[tile][g][lane][p] = silu(cond[row][8g+4h+p] * mask[row])   (UNetCF.py:330 and :93)
+__global__ void k_cond_frag(const float* __restrict__ cond, const float* __restrict__ mask, int nrows, int C, int CG,
+                            float* __restrict__ out, int ntiles) {
+    const size_t total = (size_t)ntiles * CG * 256;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int p = idx & 3, lane = (idx >> 2) & 63;
+        const size_t tg = idx >> 8;
+        const int g = tg % CG;
+        const int tile = tg / CG;
+        const int row = tile * 32 + (lane & 31), f = 8 * g + 4 * (lane >> 5) + p;
+        float v = 0.f;
+        if (row < nrows && f < C) {
+            v = cond[(size_t)row * C + f];
+            if (mask) v *= mask[row];
+            v = silu(v);
+        }
+        out[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reverse-step update (DDPM.sample, classifier_free_MSR.py:129-134), op order kept:
+//   eps = (1+omega)*eps1 - omega*eps0 ;  y <- (y - c1*eps)*c2 + c3*z
+// z comes from a caller tensor (parity mode) or from Philox4x32-10 + Box-Muller (throughput mode).
+// coef[step] = {c1 = betas/sqrt(1-acp), c2 = 1/sqrt(alpha), c3 = (1-acp[i-1])/(1-acp[i]), has_noise}.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void normal4(uint64_t seed, uint32_t stream, uint64_t idx4, float (&z)[4]) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), stream, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float u0 = ((r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((r[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float s, c;
+    sincosf(6.28318530717958647692f * u1, &s, &c);
+    z[0] = ra * c; z[1] = ra * s;
+    sincosf(6.28318530717958647692f * u3, &s, &c);
+    z[2] = rb * c; z[3] = rb * s;
+}
+
+struct UpdateArgs {
+    const float* eps;     // [2][n] : eps0 then eps1
+    float* y;             // [n] in/out
+    const float* z;       // [nnoise][n] or null (Philox)
+    const float* coef;    // [T][4]
+    const int* step_ptr;
+    int T;
+    float omega;
+    unsigned long long seed;
+    size_t n;
+};
+
+__global__ __launch_bounds__(256) void k_update(const UpdateArgs a) {
+    const int step = *a.step_ptr;
+    const float c1 = a.coef[4 * step], c2 = a.coef[4 * step + 1], c3 = a.coef[4 * step + 2];
+    const bool noisy = a.coef[4 * step + 3] != 0.f;
+    const float w1 = 1.0f + a.omega;
+    const size_t n4 = (a.n + 3) / 4;
+    const float* zrow = (a.z && noisy) ? a.z + (size_t)(a.T - 1 - step) * a.n : nullptr;
+    for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
+        float zz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (noisy && !zrow) normal4(a.seed, (uint32_t)step, i4, zz);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const size_t i = i4 * 4 + p;
+            if (i < a.n) {
+                if (zrow) zz[p] = zrow[i];
+                const float e = __fsub_rn(__fmul_rn(w1, a.eps[a.n + i]), __fmul_rn(a.omega, a.eps[i]));
+                const float v = __fmul_rn(__fsub_rn(a.y[i], __fmul_rn(c1, e)), c2);
+                a.y[i] = noisy ? __fadd_rn(v, __fmul_rn(c3, zz[p])) : v;
+            }
+        }
+    }
+}
+
+// y_T ~ N(0, 1) on device (throughput mode; the reference draws it on the host, MSR.py:115)
+__global__ void k_randn(float* __restrict__ y, size_t n, unsigned long long seed, unsigned stream) {
+    const size_t n4 = (n + 3) / 4;
+    for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
+        float zz[4];
+        normal4(seed, stream, i4, zz);
+        for (int p = 0; p < 4; ++p)
+            if (i4 * 4 + p < n) y[i4 * 4 + p] = zz[p];
+    }
+}
+
+__global__ void k_step_advance(int* step_ptr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr -= 1; }
+
+// ---------------------------------------------------------------------------------------------
+// Early-step renormalisation (MSR.py:136-137): y <- (y - mean(y)) / sqrt(var(y)), unbiased var over ALL B*D
+// elements.  Deterministic two-pass reduction with float64 partials (fixed grid, fixed order).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRedBlocks = 512;
+
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_renorm_sum(const float* __restrict__ y, size_t n, double* __restrict__ part) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += (double)y[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_renorm_sqdiff(const float* __restrict__ y, size_t n, const double* __restrict__ part,
+                                                       double* __restrict__ part2) {
+    __shared__ double sm[4];
+    double tot = 0.0;
+    for (int i = 0; i < kRedBlocks; ++i) tot += part[i];
+    const double mean = tot / (double)n;
+    double s = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double d = (double)y[i] - mean;
+        s += d * d;
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) part2[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_renorm_apply(float* __restrict__ y, size_t n, const double* __restrict__ part,
+                                                      const double* __restrict__ part2) {
+    double tot = 0.0, tot2 = 0.0;
+    for (int i = 0; i < kRedBlocks; ++i) { tot += part[i]; tot2 += part2[i]; }
+    const float mean = (float)(tot / (double)n);
+    const float sd = sqrtf((float)(tot2 / (double)(n - 1)));
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = (y[i] - mean) / sd;
+}
+
+// EMA (ema.py:11-12): avg = decay*avg + (1-decay)*p over one flat range
+// (`om` = 1 - decay evaluated in double on the host, then rounded, as torch does with the Python scalar)
+__global__ void k_ema(float* __restrict__ avg, const float* __restrict__ p, float decay, float om, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        avg[i] = __fadd_rn(__fmul_rn(decay, avg[i]), __fmul_rn(om, p[i]));
+}
+
+}  // namespace dsg

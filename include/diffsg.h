@@ -1,0 +1,78 @@
+/* diffsg.h -- C ABI of the MI355X-native DiffSG denoising hot path (libdiffsg_hip.so).
+ *
+ * The reference (qiyu3816/DiffSG) has no FFI: its seam is the Python object API.  Every entry point below is what
+ * a ctypes binding for that seam needs, and names the reference code it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to float32 (row-major, contiguous) unless stated; the library borrows them for
+ *     the duration of the call and owns only its packed-weight arena and workspace (allocated in dsg_create /
+ *     dsg_reserve / lazily on the first call of a new batch size, never while a graph is being captured);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, the calls do not synchronise;
+ *   - int functions return 0 on success, non-zero on error; dsg_last_error() gives the message (thread local);
+ *   - a handle is bound to the device that was current in dsg_create and is used by one host thread at a time.
+ */
+#ifndef DIFFSG_H_
+#define DIFFSG_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsg_handle dsg_handle;
+
+/* UNet1D constructor arguments (ddpm_opt/UNetCF.py:262-266); is_attn / middle_attn are always False in the
+ * reference's call sites (classifier_free_MSR.py:202-203, _CO.py:218-219, _NU.py:230-231) and are not supported. */
+typedef struct {
+    int input_dim;
+    int proj_dim;
+    int cond_dim;
+    int n_res;      /* len(dims), <= 8 */
+    int dims[8];
+    int n_blocks;
+} dsg_unet_desc;
+
+dsg_handle* dsg_create(const dsg_unet_desc* desc);
+void dsg_destroy(dsg_handle* h);
+const char* dsg_last_error(void);
+
+/* Parameter table in UNet1D.state_dict() order: replaces nn.Module parameter registration,
+ * UNetCF.py:272-316.  dsg_bind_weights takes one device pointer per entry, in this order, and packs the weights
+ * into MFMA fragment order on `stream`; call it again after the tensors change (optimizer step, load_state_dict). */
+int dsg_param_count(const dsg_handle* h);
+const char* dsg_param_name(const dsg_handle* h, int i);
+long long dsg_param_numel(const dsg_handle* h, int i);
+int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* stream);
+
+/* Pre-size the workspace for up to `max_rows` batch rows and `max_entries` time-table rows. */
+int dsg_reserve(dsg_handle* h, int max_rows, int max_entries);
+
+/* eps[B][D] = UNet1D.forward(x[B][D], t[B], cond[B][C], cond_mask[B])   (UNetCF.py:318-356).
+ * t holds the already-divided time value per row, as the reference passes it (classifier_free_MSR.py:109,126). */
+int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float* cond, const float* cond_mask,
+                     float* out, int B, void* stream);
+
+/* y0[B][D] = DDPM.sample(cond, omega)   (classifier_free_MSR.py:114-155), T reverse steps, two denoiser passes each.
+ *   coef  [T][4] per step i: { betas[i]/sqrt_one_minus_alphas_cumprod[i], reciprocal_sqrt_alphas[i],
+ *                              (1-alphas_cumprod[max(i-1,0)])/(1-alphas_cumprod[i]), i > 1 ? 1 : 0 }  (float32,
+ *         computed by the caller from the registered buffers so that their float64->float32 casts are kept);
+ *   y_T   [B][D] start state, or NULL to draw it on the device (Philox, `seed`);
+ *   noise [T-2][B][D] the z of steps i = T-1 .. 2 in that order, or NULL to draw on the device;
+ *   flags DSG_SAMPLE_NO_GRAPH: launch eagerly instead of replaying the captured per-step hipGraph. */
+#define DSG_SAMPLE_NO_GRAPH 1
+int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed,
+               float omega, const float* coef, int T, float* out, int B, int flags, void* stream);
+
+/* avg = decay*avg + one_minus_decay*p over n floats   (ddpm_opt/ema.py:11-12). */
+int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_decay, long long n, void* stream);
+
+/* Measurement hooks for bench.py: the per-step operator list and a timed replay of one operator's kernel with HIP
+ * events on `stream` (rows = B rows, both passes, as inside dsg_sample). */
+int dsg_op_count(const dsg_handle* h);
+/* name: >= 64 bytes.  flops/bytes are ALGORITHMIC per batch row per reverse step (both passes). */
+int dsg_op_info(const dsg_handle* h, int op, char* name, double* flops_per_row, double* bytes_per_row);
+int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSG_H_ */
