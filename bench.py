@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- DDPM reverse-sampling throughput on MSR-80c (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A *step* is one reverse step of DDPM.sample (classifier_free_MSR.py:124-137) over one synthetic batch:
+2 denoiser forwards (unconditional + conditional) + CFG combine + ancestral update (+ the global renorm on the first
+4 steps), B = 65 536 rows x D = C = 80, float32, weights = `init_weights` state (seed 0), cond ~ U[0,1), noise from the
+device Philox stream; inputs are resident in HBM before the timed region.  Reverse sampling shards by rows with no
+collective: every rank runs its own B-row batch (weak scaling) and `value` counts the B-row steps the
+whole job finished per second.
+
+Printed JSON (rank 0): the driver contract keys plus
+  roofline      dominant kernel (k_resblock of the proj_dim-wide up blocks): algorithmic FLOP per launch / mean launch
+                time from HIP events recorded around each launch on the launch stream in a second, eager run of the
+                same K steps; peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  `step` gives the same for a whole
+                step against both roofs (the fp32 FLOP roof binds, not HBM).
+  cpu_baseline  the CPU oracle (oracle/ddpm_oracle.py, the bit-checked restatement of the reference) timed on this
+                box's host cores on a bounded sample, converted to the same unit.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (fp32 vector = fp32 MFMA)
+PEAK_HBM_GBS = 8000.0     # spec; 6290 measured
+MSR80 = dict(input_dim=80, proj_dim=128, cond_dim=80, dims=(64, 32, 16, 8), n_blocks=2)
+# algorithmic work per sample-step with the time path hoisted and the uncond cond-GEMMs elided
+F_ALG = 2 * (2 * 566_400 + 100_480)   # FLOP / row / step
+BYT_ALG = 4 * (3 * 80 + 80)           # B / row / step
+
+
+def build_model(device, T, seed=0):
+    from diffsg_amd import UNet1D, generate_cosine_schedule, init_weights
+    from diffsg_amd.classifier_free_MSR import DDPM
+    torch.manual_seed(seed)
+    model = UNet1D(**MSR80, is_attn=(False,) * 4)
+    ddpm = DDPM(T, model, 80, 20.0, 1.0 - generate_cosine_schedule(T), device, (1, 80), None, 0.1, 0.9999, 10, 5, False)
+    ddpm.apply(init_weights)
+    return ddpm.to(device)
+
+
+def cpu_baseline(sample_rows=4096, steps=2, B_ref=65536):
+    """Oracle timed on the host: `steps` reverse steps of a `sample_rows`-row batch.  The thread count is the best
+    of {all cores, 32, 16, 8} on a one-step probe (hundreds of small ATen ops oversubscribe a 128-core host)."""
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nt in sorted({ncpu, min(ncpu, 32), min(ncpu, 16), min(ncpu, 8)}, reverse=True):
+        r = _cpu_baseline_run(nt, sample_rows, 1, B_ref)
+        if best is None or r["row_steps_per_s"] > best["row_steps_per_s"]:
+            best = r
+    return _cpu_baseline_run(best["cores"], sample_rows, steps, B_ref)
+
+
+def _cpu_baseline_run(nthreads, sample_rows, steps, B_ref):
+    torch.set_num_threads(nthreads)
+    from oracle import ddpm_oracle as O
+    from weights import synth_weights
+    T = 20
+    plan = O.unet_plan(MSR80["input_dim"], MSR80["proj_dim"], MSR80["cond_dim"], MSR80["dims"], MSR80["n_blocks"])
+    p = {k: torch.from_numpy(v) for k, v in synth_weights(O.state_shapes(plan), 0, "init").items()}
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    g = torch.Generator().manual_seed(0)
+    cond = torch.rand(sample_rows, 80, generator=g)
+    y = torch.randn(sample_rows, 80, generator=g)
+    z = torch.randn(sample_rows, 80, generator=g)
+    with torch.no_grad():
+        O.sample_step(p, plan, bufs, T, 10, y, cond, 1.0, z)  # warm-up
+        t0 = time.perf_counter()
+        for i in range(steps):
+            y, _ = O.sample_step(p, plan, bufs, T, 10 - i, y, cond, 1.0, z)
+        dt = time.perf_counter() - t0
+    row_steps = sample_rows * steps / dt
+    return {"value": row_steps / B_ref, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} reverse steps of a {sample_rows}x80 batch (T=20, omega=1) with oracle/ddpm_oracle.py on "
+                      f"{torch.get_num_threads()} torch threads = {row_steps:.0f} row-steps/s, scaled to B={B_ref}",
+            "row_steps_per_s": row_steps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=65536, help="rows per GPU")
+    ap.add_argument("--omega", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    K, W, B = a.steps, max(a.warmup, 1), a.batch
+    ddpm_k = build_model(dev, K)
+    ddpm_w = build_model(dev, W)
+    ddpm_w.model = ddpm_k.model          # one denoiser (one native handle, one captured graph) for both schedules
+    g = torch.Generator().manual_seed(rank)
+    cond = torch.rand(B, 80, generator=g).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ddpm_w.sample(cond, a.omega, seed=1)  # W untimed warm-up steps (also builds tables, captures the step graph)
+    barrier()
+    t0 = time.perf_counter()
+    y0 = ddpm_k.sample(cond, a.omega, seed=2)   # exactly K timed steps
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(y0).all()
+
+    if rank == 0:
+        # roofline of the dominant kernel: eager re-run of the same K steps with HIP events around every launch
+        ddpm_k.sample(cond, a.omega, seed=2, profile=True)
+        torch.cuda.synchronize()
+        prof = ddpm_k.op_profile()
+        name, fl, by, ms, calls = max(prof, key=lambda r: r[3])
+        dom = [r for r in prof if r[1] == fl and r[0].split(".")[0] == name.split(".")[0]]
+        ms_sum, n_calls = sum(r[3] for r in dom), sum(r[4] for r in dom)
+        avg_ms = ms_sum / n_calls
+        ach = fl * B / (avg_ms * 1e-3) / 1e12
+        step_ms = dt / K * 1e3
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "ddpm_reverse_sample_steps_per_sec_msr80c", "value": world * K / dt, "unit": "steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"MSR-80c CFG reverse sampling, batch {B} x D=C=80 per GPU, UNet1D(proj 128, dims "
+                                   f"(64,32,16,8), n_blocks 2), omega={a.omega:g}, device Philox noise; rows sharded, no collective",
+                       "batch_per_gpu": B, "solution_dim": 80, "parallelism": f"rows x{world}"},
+            "row_steps_per_s": world * K * B / dt,
+            "roofline": {"bound": "mfma", "kernel": f"k_resblock<128,linear-shortcut> ({len(dom)} launches/step: "
+                                                    f"{', '.join(r[0] for r in dom)})",
+                         "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS,
+                         "traffic": traffic, "avg_launch_ms": avg_ms, "flop_per_launch": fl * B,
+                         "share_of_step": ms_sum / sum(r[3] for r in prof)},
+            "step_roofline": {"f_alg_per_row": F_ALG, "achieved_tflops": F_ALG * B / (step_ms * 1e-3) / 1e12,
+                              "frac_f32_mfma": F_ALG * B / (step_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                              "achieved_gbs_alg": BYT_ALG * B / (step_ms * 1e-3) / 1e9,
+                              "frac_hbm": BYT_ALG * B / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "op_ms_per_step": {r[0]: r[3] / K for r in prof},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,8 @@ _SIGS = {
     "dsg_op_count": (ctypes.c_int, [ctypes.c_void_p]),
     "dsg_op_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_double)]),
+    "dsg_op_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(ctypes.c_int)]),
     "dsg_time_op": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                    ctypes.c_void_p]),
 }

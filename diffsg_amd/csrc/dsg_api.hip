@@ -110,15 +110,14 @@ struct dsg_handle {
     float* freq = nullptr;      // [proj/2]
     double* red = nullptr;      // [2][kRedBlocks]
     int* step_dev = nullptr;
+    CallParams* call_dev = nullptr;
+    std::vector<double> op_ms;   // DSG_SAMPLE_PROFILE: summed HIP-event time per op
+    std::vector<int> op_calls;
     hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream)
 
     // cached step graphs
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
-    int g_rows = -1, g_T = -1;
-    float g_omega = 0.f;
-    const float* g_noise = nullptr;
-    const float* g_coef = nullptr;
-    unsigned long long g_seed = 0;
+    int g_rows = -1;
 };
 
 namespace {
@@ -483,6 +482,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
               hipMalloc(&h->freq, (d.proj_dim / 2) * sizeof(float)) == hipSuccess &&
               hipMalloc(&h->red, 2 * kRedBlocks * sizeof(double)) == hipSuccess &&
               hipMalloc(&h->step_dev, 64) == hipSuccess &&
+              hipMalloc(&h->call_dev, sizeof(CallParams)) == hipSuccess &&
               hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
     if (ok) {
         // freq[k] = exp(k * -(ln 1e4 / (half-1))) in float32 (UNetCF.py:37-38)
@@ -505,6 +505,7 @@ void dsg_destroy(dsg_handle* h) {
     if (h->freq) hipFree(h->freq);
     if (h->red) hipFree(h->red);
     if (h->step_dev) hipFree(h->step_dev);
+    if (h->call_dev) hipFree(h->call_dev);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     delete h;
 }
@@ -593,8 +594,17 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
     return 0;
 }
 
-static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, bool renorm, hipStream_t s) {
-    run_unet(h, c, s);
+static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, bool renorm, hipStream_t s,
+                        hipEvent_t* ev = nullptr) {
+    if (ev) {  // DSG_SAMPLE_PROFILE: one event pair per operator launch
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            HIPCK(hipEventRecord(ev[2 * i], s));
+            launch_op(h, h->ops[i], c, s);
+            HIPCK(hipEventRecord(ev[2 * i + 1], s));
+        }
+    } else {
+        run_unet(h, c, s);
+    }
     const unsigned ublocks = (unsigned)(((u.n + 3) / 4 + 255) / 256 < 2048 ? ((u.n + 3) / 4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_update, dim3(ublocks), dim3(256), 0, s, u);
     if (renorm) {
@@ -604,6 +614,15 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
     }
     hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, s, h->step_dev);
     HIPCK(hipGetLastError());
+    if (ev) {
+        HIPCK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            float ms = 0.f;
+            HIPCK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            h->op_ms[i] += ms;
+            h->op_calls[i] += 1;
+        }
+    }
     return 0;
 }
 
@@ -627,19 +646,31 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
     const int start = T - 1;
     HIPCK(hipMemcpyAsync(h->step_dev, &start, sizeof(int), hipMemcpyHostToDevice, s));
 
+    const CallParams cp{noise, coef, omega, T, seed};
+    HIPCK(hipMemcpyAsync(h->call_dev, &cp, sizeof cp, hipMemcpyHostToDevice, s));
+    HIPCK(hipStreamSynchronize(s));  // `start` and `cp` are host temporaries
+
     RunCtx c{B, 2, tpp, h->ywork, h->eps, h->step_dev, nullptr};
     UpdateArgs u;
-    u.eps = h->eps; u.y = h->ywork; u.z = noise; u.coef = coef; u.step_ptr = h->step_dev; u.T = T; u.omega = omega;
-    u.seed = seed; u.n = n;
+    u.eps = h->eps; u.y = h->ywork; u.cp = h->call_dev; u.step_ptr = h->step_dev; u.n = n;
 
     const int n_renorm = T < 4 ? T : 4;  // steps i > T-5 (MSR.py:136)
-    if (flags & DSG_SAMPLE_NO_GRAPH) {
+    if (flags & DSG_SAMPLE_PROFILE) {
+        const size_t nops = h->ops.size();
+        h->op_ms.assign(nops, 0.0);
+        h->op_calls.assign(nops, 0);
+        std::vector<hipEvent_t> ev(2 * nops);
+        for (auto& e : ev) HIPCK(hipEventCreate(&e));
+        int rc = 0;
+        for (int k = 0; k < T && !rc; ++k) rc = enqueue_step(h, c, u, k < n_renorm, s, ev.data());
+        for (auto& e : ev) hipEventDestroy(e);
+        if (rc) return 1;
+    } else if (flags & DSG_SAMPLE_NO_GRAPH) {
         for (int k = 0; k < T; ++k)
             if (enqueue_step(h, c, u, k < n_renorm, s)) return 1;
     } else {
-        const bool reuse = h->gexec[0] && h->g_rows == B && h->g_T == T && h->g_omega == omega && h->g_noise == noise &&
-                           h->g_coef == coef && h->g_seed == seed;
-        if (!reuse) {
+        // the per-step graph depends only on the workspace (batch size); everything per call is in device memory
+        if (!(h->gexec[0] && h->g_rows == B)) {
             for (int i = 0; i < 2; ++i)
                 if (h->gexec[i]) { hipGraphExecDestroy(h->gexec[i]); h->gexec[i] = nullptr; }
             for (int variant = 0; variant < 2; ++variant) {  // 0: with renorm, 1: without
@@ -653,7 +684,7 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
                 hipGraphDestroy(g);
                 if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
             }
-            h->g_rows = B; h->g_T = T; h->g_omega = omega; h->g_noise = noise; h->g_coef = coef; h->g_seed = seed;
+            h->g_rows = B;
         }
         for (int k = 0; k < T; ++k) HIPCK(hipGraphLaunch(h->gexec[k < n_renorm ? 0 : 1], s));
     }
@@ -671,6 +702,13 @@ int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_deca
 }
 
 int dsg_op_count(const dsg_handle* h) { return h ? (int)h->ops.size() : 0; }
+
+int dsg_op_profile(const dsg_handle* h, int op, double* ms_total, int* calls) {
+    if (!h || op < 0 || op >= (int)h->op_ms.size()) return fail("dsg_op_profile: no profile for op %d (run dsg_sample with DSG_SAMPLE_PROFILE)", op);
+    if (ms_total) *ms_total = h->op_ms[op];
+    if (calls) *calls = h->op_calls[op];
+    return 0;
+}
 
 int dsg_op_info(const dsg_handle* h, int op, char* name, double* flops_per_row, double* bytes_per_row) {
     if (!h || op < 0 || op >= (int)h->ops.size()) return fail("bad op index");

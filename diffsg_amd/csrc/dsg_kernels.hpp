@@ -578,34 +578,40 @@ __device__ __forceinline__ void normal4(uint64_t seed, uint32_t stream, uint64_t
     z[2] = rb * c; z[3] = rb * s;
 }
 
+// Per-call parameters live in device memory so that the captured per-step graph does not depend on them.
+struct CallParams {
+    const float* z;       // [T-2][n] noise of steps T-1 .. 2, or null (Philox)
+    const float* coef;    // [T][4]
+    float omega;
+    int T;
+    unsigned long long seed;
+};
+
 struct UpdateArgs {
     const float* eps;     // [2][n] : eps0 then eps1
     float* y;             // [n] in/out
-    const float* z;       // [nnoise][n] or null (Philox)
-    const float* coef;    // [T][4]
+    const CallParams* cp;
     const int* step_ptr;
-    int T;
-    float omega;
-    unsigned long long seed;
     size_t n;
 };
 
 __global__ __launch_bounds__(256) void k_update(const UpdateArgs a) {
     const int step = *a.step_ptr;
-    const float c1 = a.coef[4 * step], c2 = a.coef[4 * step + 1], c3 = a.coef[4 * step + 2];
-    const bool noisy = a.coef[4 * step + 3] != 0.f;
-    const float w1 = 1.0f + a.omega;
+    const CallParams cp = *a.cp;
+    const float c1 = cp.coef[4 * step], c2 = cp.coef[4 * step + 1], c3 = cp.coef[4 * step + 2];
+    const bool noisy = cp.coef[4 * step + 3] != 0.f;
+    const float omega = cp.omega, w1 = 1.0f + cp.omega;
     const size_t n4 = (a.n + 3) / 4;
-    const float* zrow = (a.z && noisy) ? a.z + (size_t)(a.T - 1 - step) * a.n : nullptr;
+    const float* zrow = (cp.z && noisy) ? cp.z + (size_t)(cp.T - 1 - step) * a.n : nullptr;
     for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
         float zz[4] = {0.f, 0.f, 0.f, 0.f};
-        if (noisy && !zrow) normal4(a.seed, (uint32_t)step, i4, zz);
+        if (noisy && !zrow) normal4(cp.seed, (uint32_t)step, i4, zz);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const size_t i = i4 * 4 + p;
             if (i < a.n) {
                 if (zrow) zz[p] = zrow[i];
-                const float e = __fsub_rn(__fmul_rn(w1, a.eps[a.n + i]), __fmul_rn(a.omega, a.eps[i]));
+                const float e = __fsub_rn(__fmul_rn(w1, a.eps[a.n + i]), __fmul_rn(omega, a.eps[i]));
                 const float v = __fmul_rn(__fsub_rn(a.y[i], __fmul_rn(c1, e)), c2);
                 a.y[i] = noisy ? __fadd_rn(v, __fmul_rn(c3, zz[p])) : v;
             }

@@ -65,13 +65,16 @@ class DDPMCore(nn.Module):
         return torch.stack((c1, c2, c3, c4), dim=1).contiguous()
 
     @torch.no_grad()
-    def sample(self, cond, omega=1.0, *, y_T=None, noise=None, seed=None, host_rng=False, use_graph=True):
+    def sample(self, cond, omega=1.0, *, y_T=None, noise=None, seed=None, host_rng=False, use_graph=True,
+               profile=False):
         """Guided reverse sampling; returns y_0 of shape (B, D).
 
         Beyond the reference's `(cond, omega)`:
           y_T, noise  inject the start state (B, D) and the per-step z (T-2, B, D; steps i = T-1 .. 2) for parity runs;
           host_rng    draw them with torch.randn on the host exactly as the reference does (same stream for a seed);
-          seed        seed of the device Philox stream (default: drawn from torch's global generator).
+          seed        seed of the device Philox stream (default: drawn from torch's global generator);
+          use_graph   replay the captured per-step hipGraph (default) or launch every kernel eagerly;
+          profile     eager launch with HIP events around every operator (read back with `op_profile()`).
         """
         if not cond.is_cuda:
             raise RuntimeError("DDPM.sample: `cond` is not on a HIP device; libdiffsg_hip has no CPU path")
@@ -95,7 +98,7 @@ class DDPMCore(nn.Module):
         out = torch.empty(B, D, device=dev, dtype=torch.float32)
         if self.record_denoise_path:
             raise NotImplementedError("record_denoise_path (MSR.py:139-154) is SURVEY 8(f)-3, not built yet")
-        flags = 0 if use_graph else 1
+        flags = 2 if profile else (0 if use_graph else 1)
         # T <= 2 has no noisy step (MSR.py:129): a null pointer (= device Philox) is then never dereferenced
         zptr = _lib.ptr(noise) if (noise is not None and noise.numel()) else _lib.ptr(None)
         with torch.cuda.device(dev):
@@ -103,6 +106,20 @@ class DDPMCore(nn.Module):
                                              _lib.ptr(out), B, flags, _lib.stream_ptr()))
         # the call only enqueues: keep its inputs alive until the next call on this object
         self._keepalive = (cond, y_T, noise, coef)
+        return out
+
+    def op_profile(self):
+        """[(name, algorithmic flops/row/step, algorithmic bytes/row/step, ms_total, launches)] of the last
+        `sample(..., profile=True)` call (dsg_op_info / dsg_op_profile)."""
+        import ctypes
+        L, hd = _lib.lib(), self.model.native_handle()
+        out = []
+        for i in range(L.dsg_op_count(hd)):
+            name = ctypes.create_string_buffer(64)
+            fl, by, ms, calls = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+            _lib.check(L.dsg_op_info(hd, i, name, ctypes.byref(fl), ctypes.byref(by)))
+            _lib.check(L.dsg_op_profile(hd, i, ctypes.byref(ms), ctypes.byref(calls)))
+            out.append((name.value.decode(), fl.value, by.value, ms.value, calls.value))
         return out
 
     def forward(self, y, cond):

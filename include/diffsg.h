@@ -59,6 +59,9 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
  *   noise [T-2][B][D] the z of steps i = T-1 .. 2 in that order, or NULL to draw on the device;
  *   flags DSG_SAMPLE_NO_GRAPH: launch eagerly instead of replaying the captured per-step hipGraph. */
 #define DSG_SAMPLE_NO_GRAPH 1
+/*         DSG_SAMPLE_PROFILE: eager launch with one HIP-event pair around every operator launch on `stream`
+ *         (synchronises once per step); read the totals back with dsg_op_profile. */
+#define DSG_SAMPLE_PROFILE 2
 int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed,
                float omega, const float* coef, int T, float* out, int B, int flags, void* stream);
 
@@ -71,6 +74,8 @@ int dsg_op_count(const dsg_handle* h);
 /* name: >= 64 bytes.  flops/bytes are ALGORITHMIC per batch row per reverse step (both passes). */
 int dsg_op_info(const dsg_handle* h, int op, char* name, double* flops_per_row, double* bytes_per_row);
 int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* stream);
+/* Summed HIP-event time (ms) and launch count of operator `op` over the last DSG_SAMPLE_PROFILE call. */
+int dsg_op_profile(const dsg_handle* h, int op, double* ms_total, int* calls);
 
 #ifdef __cplusplus
 }
