@@ -1,6 +1,8 @@
 // Host side of libdiffsg_hip.so: builds the operator plan of UNet1D (UNetCF.py:262-356), owns the packed-weight
-// arena and the fragment-layout workspace, and enqueues the kernels of dsg_kernels.hpp.  C ABI: include/diffsg.h.
+// arena and the fragment-layout workspaces, and enqueues the kernels of dsg_kernels.hpp / dsg_train.hpp.
+// C ABI: include/diffsg.h.
 #include "dsg_kernels.hpp"
+#include "dsg_train.hpp"
 #include "../../include/diffsg.h"
 
 #include <math.h>
@@ -40,6 +42,7 @@ inline int groups_of(int w) { return cdiv(w, 8); }
 struct Param {
     std::string name;
     long long numel;
+    long long off;  // offset in the flat state-dict-order buffer (gradient bucket)
     const float* ptr = nullptr;
 };
 
@@ -57,16 +60,26 @@ struct ResP {              // ResidualBlock (UNetCF.py:49-95)
     int tb_off = 0;        // slice of the time table row
     // packed (arena offsets, floats)
     size_t W1p, g1p, b1p, W2p, g2p, b2p, c2p, Wcp, W3p, g3p, b3p, c3p, Wscp;
+    size_t W1T, W2T, W3T, WscT;  // transposed packs (data gradients)
+    // training workspace (per-tile float offsets)
+    size_t h1, h2, du1, du2, du3, dh1, dh2, rs1, rs2, rs3;
+    long long dtb_off;     // slab scratch: dTB_b [N][T]
 };
 
 struct LinOpP {            // feature_proj / Down/Upsample / final
     LinearP l;
     NormP ln;              // final only
     bool lnact = false;
-    size_t Wp, bp, gp, betap;
+    size_t Wp, bp, gp, betap, WT;
+    size_t du, rs;         // final only (training)
 };
 
-struct TensorInfo { int width; size_t data_off, stats_off; };  // per-tile float offsets
+struct TensorInfo {
+    int width;
+    size_t data_off, stats_off;   // forward workspace, per-tile float offsets
+    size_t ga, gb;                // training workspace: gradients from the chain / skip consumer
+    bool is_skip;
+};
 
 enum OpKind { OP_PROJ, OP_RES, OP_LIN, OP_FINAL };
 struct Op {
@@ -83,6 +96,7 @@ struct dsg_handle {
     dsg_unet_desc d;
     int td = 0;  // time_dim = 4*proj
     std::vector<Param> params;
+    long long total_params = 0;
     std::vector<ResP> res;
     std::vector<LinOpP> lin;
     std::vector<TensorInfo> tensors;
@@ -95,9 +109,13 @@ struct dsg_handle {
     float* arena = nullptr;
     size_t arena_floats = 0;
     TimeBlockDesc* tdesc_dev = nullptr;
+    PackDesc* pack_dev = nullptr;
+    int pack_n = 0;
+    long long pack_blocks = 0;
+    std::vector<const float*> bound_ptrs;
     bool bound = false;
 
-    // workspace
+    // forward workspace
     int cap_rows = 0, cap_entries = 0;
     float* ws = nullptr;        // activations
     float* condfrag = nullptr;
@@ -111,19 +129,36 @@ struct dsg_handle {
     double* red = nullptr;      // [2][kRedBlocks]
     int* step_dev = nullptr;
     CallParams* call_dev = nullptr;
+    hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream)
     std::vector<double> op_ms;   // DSG_SAMPLE_PROFILE: summed HIP-event time per op
     std::vector<int> op_calls;
-    hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream)
 
     // cached step graphs
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     int g_rows = -1;
+
+    // training workspace
+    size_t tr_per_tile = 0;      // floats per tile
+    size_t tr_yt_frag = 0, tr_deps = 0;
+    int tr_rows = 0, tr_T = 0, tr_chunks = 0;
+    float* tr_ws = nullptr;
+    float* tr_slabs = nullptr;   // [chunks][slab_stride]
+    float* tr_gsum = nullptr;    // [slab_stride]
+    size_t slab_stride = 0;
+    int* tr_ts = nullptr;        // [rows]
+    float* tr_yt_rm = nullptr;   // [rows][D]
+    float* tr_tsave = nullptr;   // emb | h1pre | h1s | tpre | d_st | d_h1s
+    WgradDesc* wg_desc_dev = nullptr; WgradUnit* wg_unit_dev = nullptr; int wg_units = 0;
+    ColsumDesc* cs_desc_dev = nullptr; ColsumUnit* cs_unit_dev = nullptr; int cs_units = 0;
 };
 
 namespace {
 
 int add_param(dsg_handle* h, const std::string& name, long long numel) {
-    h->params.push_back(Param{name, numel});
+    Param p;
+    p.name = name; p.numel = numel; p.off = h->total_params;
+    h->total_params += numel;
+    h->params.push_back(p);
     return (int)h->params.size() - 1;
 }
 LinearP add_linear(dsg_handle* h, const std::string& prefix, int K, int N) {
@@ -158,20 +193,21 @@ int add_res(dsg_handle* h, const std::string& prefix, int in0, int in1, int N) {
     h->res.push_back(r);
     return (int)h->res.size() - 1;
 }
-int add_tensor(dsg_handle* h, int width) {
+int add_tensor(dsg_handle* h, int width, bool is_skip) {
     TensorInfo t;
     t.width = width;
+    t.is_skip = is_skip;
     t.data_off = h->per_tile_floats;
     h->per_tile_floats += (size_t)groups_of(width) * 256;
     t.stats_off = h->per_tile_floats;
     h->per_tile_floats += 64;
+    t.ga = t.gb = 0;
     h->tensors.push_back(t);
     return (int)h->tensors.size() - 1;
 }
 
 bool width_supported(int n) { return n == 4 || n == 8 || n == 16 || n == 32 || n == 64 || n == 128; }
 
-// Arena carving -----------------------------------------------------------------------------------------
 struct Carver {
     size_t off = 0;
     size_t take(size_t floats) { size_t o = off; off += (floats + 63) / 64 * 64; return o; }
@@ -181,7 +217,7 @@ void carve(dsg_handle* h) {
     Carver c;
     const int CG = groups_of(h->d.cond_dim);
     for (auto& r : h->res) {
-        const int NT = cdiv(r.N, 32), NG = groups_of(r.N), KG = groups_of(r.in0) + groups_of(r.in1);
+        const int NT = cdiv(r.N, 32), NG = groups_of(r.N), KG = groups_of(r.in0) + groups_of(r.in1), OT1 = cdiv(KG, 4);
         r.W1p = c.take((size_t)NT * KG * 256);
         r.g1p = c.take((size_t)KG * 8 + 32);
         r.b1p = c.take((size_t)KG * 8 + 32);
@@ -191,6 +227,10 @@ void carve(dsg_handle* h) {
         r.W3p = c.take((size_t)NT * NG * 256);
         r.g3p = c.take(NT * 32); r.b3p = c.take(NT * 32); r.c3p = c.take(NT * 32);
         r.Wscp = r.sclin ? c.take((size_t)NT * KG * 256) : 0;
+        r.W1T = c.take((size_t)OT1 * NG * 256);
+        r.W2T = c.take((size_t)NT * NG * 256);
+        r.W3T = c.take((size_t)NT * NG * 256);
+        r.WscT = r.sclin ? c.take((size_t)OT1 * NG * 256) : 0;
     }
     for (auto& l : h->lin) {
         const int NT = cdiv(l.l.N, 32), KG = groups_of(l.l.K);
@@ -198,21 +238,55 @@ void carve(dsg_handle* h) {
         l.bp = c.take(NT * 32);
         l.gp = l.lnact ? c.take((size_t)KG * 8 + 32) : 0;
         l.betap = l.lnact ? c.take((size_t)KG * 8 + 32) : 0;
+        l.WT = c.take((size_t)cdiv(KG, 4) * groups_of(l.l.N) * 256);
     }
     h->arena_floats = c.off;
+    // training workspace layout (per-tile float offsets)
+    size_t o = 0;
+    auto take = [&](size_t f) { size_t r = o; o += f; return r; };
+    for (auto& t : h->tensors) {
+        t.ga = take((size_t)groups_of(t.width) * 256);
+        t.gb = t.is_skip ? take((size_t)groups_of(t.width) * 256) : 0;
+    }
+    for (auto& r : h->res) {
+        const size_t NGf = (size_t)groups_of(r.N) * 256, KGf = (size_t)(groups_of(r.in0) + groups_of(r.in1)) * 256;
+        r.h1 = take(NGf); r.h2 = take(NGf); r.du1 = take(KGf); r.du2 = take(NGf); r.du3 = take(NGf);
+        r.dh1 = take(NGf); r.dh2 = take(NGf); r.rs1 = take(64); r.rs2 = take(64); r.rs3 = take(64);
+    }
+    for (auto& l : h->lin)
+        if (l.lnact) { l.du = take((size_t)groups_of(l.l.K) * 256); l.rs = take(64); }
+    h->tr_yt_frag = take((size_t)groups_of(h->d.input_dim) * 256);
+    h->tr_deps = take((size_t)groups_of(h->d.input_dim) * 256);
+    h->tr_per_tile = o;
 }
 
-int free_workspace(dsg_handle* h) {
+void free_graphs(dsg_handle* h) {
     for (int i = 0; i < 2; ++i)
-        if (h->gexec[i]) { hipGraphExecDestroy(h->gexec[i]); h->gexec[i] = nullptr; }
+        if (h->gexec[i]) { (void)hipGraphExecDestroy(h->gexec[i]); h->gexec[i] = nullptr; }
     h->g_rows = -1;
+}
+
+void free_train_workspace(dsg_handle* h) {
+    void* ptrs[] = {h->tr_ws, h->tr_slabs, h->tr_gsum, h->tr_ts, h->tr_yt_rm, h->tr_tsave, h->wg_desc_dev, h->wg_unit_dev,
+                    h->cs_desc_dev, h->cs_unit_dev};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->tr_ws = h->tr_slabs = h->tr_gsum = h->tr_yt_rm = h->tr_tsave = nullptr;
+    h->tr_ts = nullptr;
+    h->wg_desc_dev = nullptr; h->wg_unit_dev = nullptr; h->cs_desc_dev = nullptr; h->cs_unit_dev = nullptr;
+    h->wg_units = h->cs_units = 0;
+    h->tr_rows = h->tr_T = 0;
+}
+
+void free_workspace(dsg_handle* h) {
+    free_graphs(h);
+    free_train_workspace(h);  // its descriptors point into the forward workspace
     void* ptrs[] = {h->ws, h->condfrag, h->tb, h->st, h->tvals, h->ts_ident, h->eps, h->ywork};
     for (void* p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     h->ws = h->condfrag = h->tb = h->st = h->tvals = h->eps = h->ywork = nullptr;
     h->ts_ident = nullptr;
     h->cap_rows = h->cap_entries = 0;
-    return 0;
 }
 
 __global__ void k_iota(int* p, int n) {
@@ -224,8 +298,6 @@ __global__ void k_linspace_t(float* p, int T) {  // t = i / T in float32, as `to
 
 int ensure_workspace(dsg_handle* h, int rows, int entries) {
     if (rows <= h->cap_rows && entries <= h->cap_entries) return 0;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)cs;
     const int nrows = rows > h->cap_rows ? rows : h->cap_rows;
     const int nent = entries > h->cap_entries ? entries : h->cap_entries;
     HIPCK(hipDeviceSynchronize());
@@ -267,6 +339,22 @@ void launch_res(int N, bool sclin, const BlockArgs& a, hipStream_t s) {
         case 128: launch_res_n<128>(sclin, a, s); break;
     }
 }
+template <int N>
+void launch_res_bwd_n(bool sclin, const BlockBwdArgs& a, hipStream_t s) {
+    const dim3 grid(cdiv(a.ntiles, kWavesPerBlock)), block(256);
+    if (sclin) hipLaunchKernelGGL((k_resblock_bwd<N, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_resblock_bwd<N, false>), grid, block, 0, s, a);
+}
+void launch_res_bwd(int N, bool sclin, const BlockBwdArgs& a, hipStream_t s) {
+    switch (N) {
+        case 4: launch_res_bwd_n<4>(sclin, a, s); break;
+        case 8: launch_res_bwd_n<8>(sclin, a, s); break;
+        case 16: launch_res_bwd_n<16>(sclin, a, s); break;
+        case 32: launch_res_bwd_n<32>(sclin, a, s); break;
+        case 64: launch_res_bwd_n<64>(sclin, a, s); break;
+        case 128: launch_res_bwd_n<128>(sclin, a, s); break;
+    }
+}
 template <int NT>
 void launch_lin_nt(int inmode, int outmode, bool lnact, const LinArgs& a, hipStream_t s) {
     const dim3 grid(cdiv(a.ntiles, kWavesPerBlock)), block(256);
@@ -282,6 +370,20 @@ void launch_lin(int N, int inmode, int outmode, bool lnact, const LinArgs& a, hi
         case 4: launch_lin_nt<4>(inmode, outmode, lnact, a, s); break;
     }
 }
+template <int OT>
+void launch_lin_bwd_ot(bool lnbwd, const LinBwdArgs& a, hipStream_t s) {
+    const dim3 grid(cdiv(a.ntiles, kWavesPerBlock)), block(256);
+    if (lnbwd) hipLaunchKernelGGL((k_linear_bwd<OT, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_linear_bwd<OT, false>), grid, block, 0, s, a);
+}
+void launch_lin_bwd(int K, bool lnbwd, const LinBwdArgs& a, hipStream_t s) {
+    switch (cdiv(K, 32)) {
+        case 1: launch_lin_bwd_ot<1>(lnbwd, a, s); break;
+        case 2: launch_lin_bwd_ot<2>(lnbwd, a, s); break;
+        case 3: launch_lin_bwd_ot<3>(lnbwd, a, s); break;
+        case 4: launch_lin_bwd_ot<4>(lnbwd, a, s); break;
+    }
+}
 
 struct RunCtx {
     int nrows;           // rows per pass
@@ -291,39 +393,44 @@ struct RunCtx {
     float* eps_out;      // row-major [npass][nrows][D]
     const int* step_ptr; // or null
     const int* ts;       // or null
+    bool train;          // save h1/h2 for the backward pass
 };
 
-Seg seg_of(const dsg_handle* h, int tid, size_t cap_tiles) {
+size_t cap_tiles_of(const dsg_handle* h) { return (size_t)cdiv(h->cap_rows, 32) * 2; }
+size_t tr_tiles_of(const dsg_handle* h) { return (size_t)cdiv(h->tr_rows, 32); }
+
+Seg seg_of(const dsg_handle* h, int tid) {
     const TensorInfo& t = h->tensors[tid];
+    const size_t cap = cap_tiles_of(h);
     Seg s;
-    s.data = h->ws + t.data_off * cap_tiles;
-    s.stats = h->ws + t.stats_off * cap_tiles;
+    s.data = h->ws + t.data_off * cap;
+    s.stats = h->ws + t.stats_off * cap;
     s.groups = groups_of(t.width);
     s.width = t.width;
     return s;
 }
+float* trp(const dsg_handle* h, size_t off) { return h->tr_ws + off * tr_tiles_of(h); }
 
 void fill_block_args(const dsg_handle* h, const Op& op, const RunCtx& c, BlockArgs& a) {
-    const size_t cap_tiles = (size_t)cdiv(h->cap_rows, 32) * 2;
     const int tpp = cdiv(c.nrows, 32);
     const ResP& r = h->res[op.p];
     const float* A = h->arena;
     memset(&a, 0, sizeof a);
-    a.in0 = seg_of(h, op.in0, cap_tiles);
-    if (op.in1 >= 0) a.in1 = seg_of(h, op.in1, cap_tiles);
+    a.in0 = seg_of(h, op.in0);
+    if (op.in1 >= 0) a.in1 = seg_of(h, op.in1);
     a.W1 = A + r.W1p; a.gamma1 = A + r.g1p; a.beta1 = A + r.b1p;
     a.tbias = h->tb + r.tb_off; a.step_ptr = c.step_ptr; a.ts = c.ts; a.tb_stride = h->tb_stride;
     a.W2 = A + r.W2p; a.gamma2 = A + r.g2p; a.beta2 = A + r.b2p; a.c2 = A + r.c2p;
     a.Wc = A + r.Wcp; a.condfrag = h->condfrag; a.cond_groups = groups_of(h->d.cond_dim);
     a.W3 = A + r.W3p; a.gamma3 = A + r.g3p; a.beta3 = A + r.b3p; a.c3 = A + r.c3p;
     a.Wsc = r.sclin ? A + r.Wscp : nullptr;
-    const Seg o = seg_of(h, op.out, cap_tiles);
+    const Seg o = seg_of(h, op.out);
     a.out = const_cast<float*>(o.data); a.out_stats = const_cast<float*>(o.stats);
+    if (c.train) { a.save_h1 = trp(h, r.h1); a.save_h2 = trp(h, r.h2); }
     a.ntiles = tpp * c.npass; a.tiles_per_pass = tpp; a.uncond_tiles = c.uncond_tiles; a.nrows = c.nrows;
 }
 
 void fill_lin_args(const dsg_handle* h, const Op& op, const RunCtx& c, LinArgs& a) {
-    const size_t cap_tiles = (size_t)cdiv(h->cap_rows, 32) * 2;
     const int tpp = cdiv(c.nrows, 32);
     const LinOpP& l = h->lin[op.p];
     const float* A = h->arena;
@@ -333,11 +440,11 @@ void fill_lin_args(const dsg_handle* h, const Op& op, const RunCtx& c, LinArgs& 
     a.out_width = l.l.N;
     a.ntiles = tpp * c.npass; a.tiles_per_pass = tpp; a.nrows = c.nrows;
     if (op.kind == OP_PROJ) a.in_rm = c.y;
-    else a.in = seg_of(h, op.in0, cap_tiles);
+    else a.in = seg_of(h, op.in0);
     if (op.kind == OP_FINAL) {
         a.gamma = A + l.gp; a.beta = A + l.betap; a.out_rm = c.eps_out;
     } else {
-        const Seg o = seg_of(h, op.out, cap_tiles);
+        const Seg o = seg_of(h, op.out);
         a.out = const_cast<float*>(o.data); a.out_stats = const_cast<float*>(o.stats);
     }
 }
@@ -360,12 +467,17 @@ void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     for (const Op& op : h->ops) launch_op(h, op, c, s);
 }
 
-// time path for `entries` t values already in h->tvals
-void run_time_path(dsg_handle* h, int entries, hipStream_t s) {
+// time path for `entries` t values already in h->tvals (saves for the backward when `train`)
+void run_time_path(dsg_handle* h, int entries, hipStream_t s, bool train = false) {
     const int half = h->d.proj_dim / 2, td = h->td;
     const Param* P = h->params.data();
+    float *emb = nullptr, *h1pre = nullptr, *h1s = nullptr, *tpre = nullptr;
+    if (train) {
+        emb = h->tr_tsave; h1pre = emb + (size_t)h->tr_T * 2 * half; h1s = h1pre + (size_t)h->tr_T * td;
+        tpre = h1s + (size_t)h->tr_T * td;
+    }
     hipLaunchKernelGGL(k_time_embed, dim3(entries), dim3(256), (2 * half + td) * sizeof(float), s, h->tvals, h->freq, half,
-                       P[h->temb_l1w].ptr, P[h->temb_l1b].ptr, P[h->temb_l2w].ptr, P[h->temb_l2b].ptr, td, h->st);
+                       P[h->temb_l1w].ptr, P[h->temb_l1b].ptr, P[h->temb_l2w].ptr, P[h->temb_l2b].ptr, td, h->st, emb, h1pre, h1s, tpre);
     const int nb = (int)h->res.size();
     hipLaunchKernelGGL(k_time_table, dim3(entries, nb < 8 ? nb : 8), dim3(256), td * sizeof(float), s, h->st, td, h->tdesc_dev,
                        nb, h->tb, h->tb_stride);
@@ -375,6 +487,138 @@ int check_bound(const dsg_handle* h) {
     if (!h) return fail("null handle");
     if (!h->bound) return fail("dsg_bind_weights has not been called");
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// training workspace + descriptor tables
+// ------------------------------------------------------------------------------------------------------
+int ensure_train_workspace(dsg_handle* h, int rows, int T) {
+    if (ensure_workspace(h, rows, T)) return 1;
+    if (h->tr_ws && rows <= h->tr_rows && T == h->tr_T) return 0;
+    HIPCK(hipDeviceSynchronize());
+    const int nrows = rows > h->tr_rows ? rows : h->tr_rows;
+    free_train_workspace(h);
+    h->tr_rows = nrows; h->tr_T = T;
+    const size_t tiles = tr_tiles_of(h);
+    const int D = h->d.input_dim, td = h->td, half = h->d.proj_dim / 2;
+    // slab = [flat parameter gradients | dTB_b [N_b][T] for every block]
+    long long so = h->total_params;
+    for (auto& r : h->res) { r.dtb_off = so; so += (long long)r.N * T; }
+    h->slab_stride = (size_t)((so + 63) / 64 * 64);
+    const int max_chunks = 32;
+    HIPCK(hipMalloc(&h->tr_ws, tiles * h->tr_per_tile * sizeof(float)));
+    HIPCK(hipMemset(h->tr_ws, 0, tiles * h->tr_per_tile * sizeof(float)));
+    HIPCK(hipMalloc(&h->tr_slabs, (size_t)max_chunks * h->slab_stride * sizeof(float)));
+    HIPCK(hipMemset(h->tr_slabs, 0, (size_t)max_chunks * h->slab_stride * sizeof(float)));
+    HIPCK(hipMalloc(&h->tr_gsum, h->slab_stride * sizeof(float)));
+    HIPCK(hipMalloc(&h->tr_ts, (size_t)nrows * sizeof(int)));
+    HIPCK(hipMalloc(&h->tr_yt_rm, (size_t)nrows * D * sizeof(float)));
+    HIPCK(hipMalloc(&h->tr_tsave, ((size_t)T * 2 * half + (size_t)5 * T * td) * sizeof(float)));
+    return 0;
+}
+
+// Descriptors depend on the batch size of THIS call (tile counts, row masks) and on T: rebuilt per call (host only,
+// one upload); cheap next to the step.
+int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
+    const float* A = h->arena;
+    const Param* P = h->params.data();
+    const int DG = groups_of(h->d.input_dim);
+    const int tiles = cdiv(B, 32);
+    h->tr_chunks = tiles < 32 ? tiles : 32;
+    std::vector<WgradDesc> wd;
+    std::vector<ColsumDesc> cd;
+    auto gseg = [&](const float* data, int width) { Seg sg; sg.data = data; sg.stats = nullptr; sg.groups = groups_of(width); sg.width = width; return sg; };
+    auto none = [&]() { Seg sg; sg.data = nullptr; sg.stats = nullptr; sg.groups = 0; sg.width = 0; return sg; };
+    auto wgrad = [&](const float* G0, const float* G1, int N, int amode, Seg a0, Seg a1, const float* rs, const float* gm,
+                     const float* bt, long long out_off, int ld) {
+        WgradDesc d;
+        memset(&d, 0, sizeof d);
+        d.G0 = G0; d.G1 = G1; d.N = N; d.NG = groups_of(N); d.amode = amode; d.a0 = a0; d.a1 = a1; d.rs = rs; d.gamma = gm; d.beta = bt;
+        d.ts = h->tr_ts; d.onehot_n = T; d.out_off = out_off; d.ld = ld;
+        d.KG = amode == A_ONEHOT ? groups_of(T) : a0.groups + a1.groups;
+        d.nrows = B;
+        wd.push_back(d);
+    };
+    auto colsum = [&](const float* P0, const float* P1, int groups, Seg x0, Seg x1, const float* rs, int w0, int w1, long long o1,
+                      long long o1b, long long o2) {
+        ColsumDesc d;
+        memset(&d, 0, sizeof d);
+        d.P0 = P0; d.P1 = P1; d.groups = groups; d.x0 = x0; d.x1 = x1; d.rs = rs; d.w0 = w0; d.w1 = w1;
+        d.out_off = o1; d.out_off_b = o1b; d.out2_off = o2;
+        cd.push_back(d);
+    };
+    auto grad_a = [&](int tid) { return (const float*)trp(h, h->tensors[tid].ga); };
+    auto grad_b = [&](int tid) { return h->tensors[tid].is_skip ? (const float*)trp(h, h->tensors[tid].gb) : (const float*)nullptr; };
+
+    for (const Op& op : h->ops) {
+        if (op.kind == OP_RES) {
+            const ResP& r = h->res[op.p];
+            const Seg in0 = seg_of(h, op.in0), in1 = op.in1 >= 0 ? seg_of(h, op.in1) : none();
+            const float *ga = grad_a(op.out), *gb = grad_b(op.out);
+            const float *dh1 = trp(h, r.dh1), *dh2 = trp(h, r.dh2);
+            const int in = r.in0 + r.in1;
+            wgrad(dh1, nullptr, r.N, A_LNSILU, in0, in1, trp(h, r.rs1), A + r.g1p, A + r.b1p, P[r.l1.w].off, in);
+            if (r.sclin) wgrad(ga, gb, r.N, A_RAW, in0, in1, nullptr, nullptr, nullptr, P[r.sc.w].off, in);
+            wgrad(dh2, nullptr, r.N, A_LNSILU, gseg(trp(h, r.h1), r.N), none(), trp(h, r.rs2), A + r.g2p, A + r.b2p, P[r.l2.w].off, r.N);
+            wgrad(dh2, nullptr, r.N, A_RAW, gseg(h->condfrag, h->d.cond_dim), none(), nullptr, nullptr, nullptr, P[r.ce.w].off, h->d.cond_dim);
+            wgrad(ga, gb, r.N, A_LNSILU, gseg(trp(h, r.h2), r.N), none(), trp(h, r.rs3), A + r.g3p, A + r.b3p, P[r.l3.w].off, r.N);
+            wgrad(dh1, nullptr, r.N, A_ONEHOT, none(), none(), nullptr, nullptr, nullptr, r.dtb_off, T);
+            colsum(trp(h, r.du1), nullptr, in0.groups + in1.groups, in0, in1, trp(h, r.rs1), r.in0, r.in1, P[r.n1.b].off, -1, P[r.n1.w].off);
+            colsum(trp(h, r.du2), nullptr, groups_of(r.N), gseg(trp(h, r.h1), r.N), none(), trp(h, r.rs2), r.N, 0, P[r.n2.b].off, -1, P[r.n2.w].off);
+            colsum(trp(h, r.du3), nullptr, groups_of(r.N), gseg(trp(h, r.h2), r.N), none(), trp(h, r.rs3), r.N, 0, P[r.n3.b].off, -1, P[r.n3.w].off);
+            colsum(dh1, nullptr, groups_of(r.N), none(), none(), nullptr, r.N, 0, P[r.l1.b].off, P[r.te.b].off, -1);
+            colsum(dh2, nullptr, groups_of(r.N), none(), none(), nullptr, r.N, 0, P[r.l2.b].off, P[r.ce.b].off, -1);
+            colsum(ga, gb, groups_of(r.N), none(), none(), nullptr, r.N, 0, P[r.l3.b].off, r.sclin ? P[r.sc.b].off : -1, -1);
+        } else {
+            const LinOpP& l = h->lin[op.p];
+            if (op.kind == OP_FINAL) {
+                const float* deps = trp(h, h->tr_deps);
+                const Seg in = seg_of(h, op.in0);
+                wgrad(deps, nullptr, l.l.N, A_LNSILU, in, none(), trp(h, l.rs), A + l.gp, A + l.betap, P[l.l.w].off, l.l.K);
+                colsum(deps, nullptr, DG, none(), none(), nullptr, l.l.N, 0, P[l.l.b].off, -1, -1);
+                colsum(trp(h, l.du), nullptr, in.groups, in, none(), trp(h, l.rs), l.l.K, 0, P[l.ln.b].off, -1, P[l.ln.w].off);
+            } else {
+                const float *ga = grad_a(op.out), *gb = grad_b(op.out);
+                const Seg a0 = op.kind == OP_PROJ ? gseg(trp(h, h->tr_yt_frag), l.l.K) : seg_of(h, op.in0);
+                wgrad(ga, gb, l.l.N, A_RAW, a0, none(), nullptr, nullptr, nullptr, P[l.l.w].off, l.l.K);
+                colsum(ga, gb, groups_of(l.l.N), none(), none(), nullptr, l.l.N, 0, P[l.l.b].off, -1, -1);
+            }
+        }
+    }
+    std::vector<WgradUnit> wu;
+    for (size_t i = 0; i < wd.size(); ++i)
+        for (int kb = 0; kb < cdiv(wd[i].KG, 16); ++kb)
+            for (int c = 0; c < h->tr_chunks; ++c) wu.push_back(WgradUnit{(int)i, kb, c, 0});
+    std::vector<ColsumUnit> cu;
+    for (size_t i = 0; i < cd.size(); ++i)
+        for (int g = 0; g < cd[i].groups; ++g)
+            for (int c = 0; c < h->tr_chunks; ++c) cu.push_back(ColsumUnit{(int)i, g, c, 0});
+    if (!h->wg_desc_dev) {
+        HIPCK(hipMalloc(&h->wg_desc_dev, wd.size() * sizeof(WgradDesc)));
+        HIPCK(hipMalloc(&h->cs_desc_dev, cd.size() * sizeof(ColsumDesc)));
+    }
+    if (h->wg_units != (int)wu.size() || !h->wg_unit_dev) {
+        if (h->wg_unit_dev) (void)hipFree(h->wg_unit_dev);
+        HIPCK(hipMalloc(&h->wg_unit_dev, wu.size() * sizeof(WgradUnit)));
+    }
+    if (h->cs_units != (int)cu.size() || !h->cs_unit_dev) {
+        if (h->cs_unit_dev) (void)hipFree(h->cs_unit_dev);
+        HIPCK(hipMalloc(&h->cs_unit_dev, cu.size() * sizeof(ColsumUnit)));
+    }
+    h->wg_units = (int)wu.size(); h->cs_units = (int)cu.size();
+    HIPCK(hipMemcpyAsync(h->wg_desc_dev, wd.data(), wd.size() * sizeof(WgradDesc), hipMemcpyHostToDevice, s));
+    HIPCK(hipMemcpyAsync(h->cs_desc_dev, cd.data(), cd.size() * sizeof(ColsumDesc), hipMemcpyHostToDevice, s));
+    HIPCK(hipMemcpyAsync(h->wg_unit_dev, wu.data(), wu.size() * sizeof(WgradUnit), hipMemcpyHostToDevice, s));
+    HIPCK(hipMemcpyAsync(h->cs_unit_dev, cu.data(), cu.size() * sizeof(ColsumUnit), hipMemcpyHostToDevice, s));
+    HIPCK(hipStreamSynchronize(s));  // host vectors go out of scope
+    return 0;
+}
+
+void small_gemm(const float* A, long long ai, long long al, const float* B, long long bl, long long bj, float* C, long long ci,
+                long long cj, int M, int N, int L, int acc, hipStream_t s) {
+    const long long total = (long long)M * N;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_small_gemm, dim3(blocks), dim3(256), 0, s, A, ai, al, B, bl, bj, C, ci, cj, M, N, L, acc);
 }
 
 }  // namespace
@@ -412,7 +656,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         h->temb_l1w = t1.w; h->temb_l1b = t1.b; h->temb_l2w = t2.w; h->temb_l2b = t2.b;
     }
     std::vector<int> skips;
-    int cur = add_tensor(h, d.proj_dim);
+    int cur = add_tensor(h, d.proj_dim, true);
     h->ops.push_back(Op{OP_PROJ, 0, -1, -1, cur, "feature_proj"});
     skips.push_back(cur);
     int w = d.proj_dim, idx = 0;
@@ -420,7 +664,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
     auto push_down_res = [&](int width) {
         snprintf(nm, sizeof nm, "down.%d.res", idx);
         const int p = add_res(h, nm, width, 0, width);
-        const int out = add_tensor(h, width);
+        const int out = add_tensor(h, width, true);
         h->ops.push_back(Op{OP_RES, p, cur, -1, out, nm});
         cur = out; skips.push_back(cur); ++idx;
     };
@@ -429,7 +673,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         snprintf(nm, sizeof nm, "down.%d.lin", idx);
         LinOpP l; l.l = add_linear(h, nm, w, d.dims[i]);
         h->lin.push_back(l);
-        const int out = add_tensor(h, d.dims[i]);
+        const int out = add_tensor(h, d.dims[i], true);
         h->ops.push_back(Op{OP_LIN, (int)h->lin.size() - 1, cur, -1, out, nm});
         cur = out; skips.push_back(cur); ++idx;
         w = d.dims[i];
@@ -439,7 +683,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
     for (int m = 1; m <= 2; ++m) {
         snprintf(nm, sizeof nm, "middle.res%d", m);
         const int p = add_res(h, nm, w, 0, w);
-        const int out = add_tensor(h, w);
+        const int out = add_tensor(h, w, false);
         h->ops.push_back(Op{OP_RES, p, cur, -1, out, nm});
         cur = out;
     }
@@ -448,7 +692,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         snprintf(nm, sizeof nm, "up.%d.res", idx);
         const int sk = skips.back(); skips.pop_back();
         const int p = add_res(h, nm, width, h->tensors[sk].width, width);
-        const int out = add_tensor(h, width);
+        const int out = add_tensor(h, width, false);
         h->ops.push_back(Op{OP_RES, p, cur, sk, out, nm});
         cur = out; ++idx;
     };
@@ -458,7 +702,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         snprintf(nm, sizeof nm, "up.%d.lin", idx);
         LinOpP l; l.l = add_linear(h, nm, w, nw);
         h->lin.push_back(l);
-        const int out = add_tensor(h, nw);
+        const int out = add_tensor(h, nw, false);
         h->ops.push_back(Op{OP_LIN, (int)h->lin.size() - 1, cur, -1, out, nm});
         cur = out; ++idx;
         w = nw;
@@ -474,7 +718,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         h->ops.push_back(Op{OP_FINAL, (int)h->lin.size() - 1, cur, -1, -1, "final"});
     }
     for (const ResP& r : h->res)
-        if (r.in1 && r.in1 != r.in0) { fail("internal: skip width mismatch"); delete h; return nullptr; }
+        if ((r.in1 && r.in1 != r.in0) || (r.sclin != (r.in1 != 0))) { fail("internal: unexpected block shape"); delete h; return nullptr; }
     carve(h);
     bool ok = hipMalloc(&h->arena, h->arena_floats * sizeof(float)) == hipSuccess &&
               hipMemset(h->arena, 0, h->arena_floats * sizeof(float)) == hipSuccess &&
@@ -498,15 +742,12 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
 
 void dsg_destroy(dsg_handle* h) {
     if (!h) return;
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     free_workspace(h);
-    if (h->arena) hipFree(h->arena);
-    if (h->tdesc_dev) hipFree(h->tdesc_dev);
-    if (h->freq) hipFree(h->freq);
-    if (h->red) hipFree(h->red);
-    if (h->step_dev) hipFree(h->step_dev);
-    if (h->call_dev) hipFree(h->call_dev);
-    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+    void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     delete h;
 }
 
@@ -517,56 +758,79 @@ const char* dsg_param_name(const dsg_handle* h, int i) {
 long long dsg_param_numel(const dsg_handle* h, int i) {
     return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].numel : -1;
 }
+long long dsg_param_total(const dsg_handle* h) { return h ? h->total_params : 0; }
 
 int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* stream) {
     if (!h) return fail("null handle");
     if (n != (int)h->params.size()) return fail("dsg_bind_weights: got %d pointers, the model has %d tensors", n, (int)h->params.size());
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (!ptrs[i]) return fail("dsg_bind_weights: null pointer for %s", h->params[i].name.c_str());
-        h->params[i].ptr = ptrs[i];
-    }
     hipStream_t s = (hipStream_t)stream;
-    const Param* P = h->params.data();
-    float* A = h->arena;
-    auto pack = [&](const LinearP& l, int w0, int w1, size_t off) {
-        const int NT = cdiv(l.N, 32);
-        const size_t total = (size_t)NT * (groups_of(w0) + groups_of(w1)) * 256;
-        hipLaunchKernelGGL(k_pack_linear, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s,
-                           P[l.w].ptr, l.N, l.K, w0, w1, A + off, NT);
-    };
-    auto padv = [&](const float* a, const float* b, int w0, int w1, size_t off, int npad) {
-        hipLaunchKernelGGL(k_pad_vec, dim3(cdiv(npad, 256)), dim3(256), 0, s, a, b, w0, w1, A + off, npad);
-    };
-    std::vector<TimeBlockDesc> td(h->res.size());
-    for (size_t i = 0; i < h->res.size(); ++i) {
-        const ResP& r = h->res[i];
-        const int NT = cdiv(r.N, 32), KG = groups_of(r.in0) + groups_of(r.in1);
-        pack(r.l1, r.in0, r.in1, r.W1p);
-        padv(P[r.n1.w].ptr, nullptr, r.in0, r.in1, r.g1p, KG * 8 + 32);
-        padv(P[r.n1.b].ptr, nullptr, r.in0, r.in1, r.b1p, KG * 8 + 32);
-        pack(r.l2, r.N, 0, r.W2p);
-        padv(P[r.n2.w].ptr, nullptr, r.N, 0, r.g2p, NT * 32);
-        padv(P[r.n2.b].ptr, nullptr, r.N, 0, r.b2p, NT * 32);
-        padv(P[r.l2.b].ptr, P[r.ce.b].ptr, r.N, 0, r.c2p, NT * 32);
-        pack(r.ce, h->d.cond_dim, 0, r.Wcp);
-        pack(r.l3, r.N, 0, r.W3p);
-        padv(P[r.n3.w].ptr, nullptr, r.N, 0, r.g3p, NT * 32);
-        padv(P[r.n3.b].ptr, nullptr, r.N, 0, r.b3p, NT * 32);
-        padv(P[r.l3.b].ptr, r.sclin ? P[r.sc.b].ptr : nullptr, r.N, 0, r.c3p, NT * 32);
-        if (r.sclin) pack(r.sc, r.in0, r.in1, r.Wscp);
-        td[i] = TimeBlockDesc{P[r.te.w].ptr, P[r.te.b].ptr, P[r.l1.b].ptr, r.N, r.tb_off};
-    }
-    for (const LinOpP& l : h->lin) {
-        const int NT = cdiv(l.l.N, 32), KG = groups_of(l.l.K);
-        pack(l.l, l.l.K, 0, l.Wp);
-        padv(P[l.l.b].ptr, nullptr, l.l.N, 0, l.bp, NT * 32);
-        if (l.lnact) {
-            padv(P[l.ln.w].ptr, nullptr, l.l.K, 0, l.gp, KG * 8 + 32);
-            padv(P[l.ln.b].ptr, nullptr, l.l.K, 0, l.betap, KG * 8 + 32);
+    const bool same = h->bound && h->bound_ptrs.size() == (size_t)n && memcmp(h->bound_ptrs.data(), ptrs, n * sizeof(float*)) == 0;
+    if (!same) {
+        // (re)build the pack descriptor table: ONE grouped launch re-packs everything after each optimizer step
+        for (int i = 0; i < n; ++i) h->params[i].ptr = ptrs[i];
+        h->bound_ptrs.assign(ptrs, ptrs + n);
+        const Param* P = h->params.data();
+        float* A = h->arena;
+        std::vector<PackDesc> pd;
+        long long blk = 0;
+        auto push = [&](int kind, const float* a, const float* b, size_t off, int N, int Ktot, int w0, int w1, int T, long long total) {
+            PackDesc d;
+            d.a = a; d.b = b; d.dst = A + off; d.kind = kind; d.N = N; d.Ktot = Ktot; d.w0 = w0; d.w1 = w1; d.T = T; d.total = total;
+            d.blk_begin = blk;
+            blk += (total + kPackPerBlock - 1) / kPackPerBlock;
+            pd.push_back(d);
+        };
+        auto pack = [&](const LinearP& l, int w0, int w1, size_t off) {
+            const int NT = cdiv(l.N, 32);
+            push(0, P[l.w].ptr, nullptr, off, l.N, l.K, w0, w1, NT, (long long)NT * (groups_of(w0) + groups_of(w1)) * 256);
+        };
+        auto packT = [&](const LinearP& l, int w0, int w1, size_t off) {
+            const int OT = cdiv(groups_of(w0) + groups_of(w1), 4);
+            push(1, P[l.w].ptr, nullptr, off, l.N, l.K, w0, w1, OT, (long long)OT * groups_of(l.N) * 256);
+        };
+        auto padv = [&](const float* a, const float* b, int w0, int w1, size_t off, int npad) { push(2, a, b, off, 0, 0, w0, w1, 0, npad); };
+        std::vector<TimeBlockDesc> td(h->res.size());
+        for (size_t i = 0; i < h->res.size(); ++i) {
+            const ResP& r = h->res[i];
+            const int NT = cdiv(r.N, 32), KG = groups_of(r.in0) + groups_of(r.in1);
+            pack(r.l1, r.in0, r.in1, r.W1p);
+            padv(P[r.n1.w].ptr, nullptr, r.in0, r.in1, r.g1p, KG * 8 + 32);
+            padv(P[r.n1.b].ptr, nullptr, r.in0, r.in1, r.b1p, KG * 8 + 32);
+            pack(r.l2, r.N, 0, r.W2p);
+            padv(P[r.n2.w].ptr, nullptr, r.N, 0, r.g2p, NT * 32);
+            padv(P[r.n2.b].ptr, nullptr, r.N, 0, r.b2p, NT * 32);
+            padv(P[r.l2.b].ptr, P[r.ce.b].ptr, r.N, 0, r.c2p, NT * 32);
+            pack(r.ce, h->d.cond_dim, 0, r.Wcp);
+            pack(r.l3, r.N, 0, r.W3p);
+            padv(P[r.n3.w].ptr, nullptr, r.N, 0, r.g3p, NT * 32);
+            padv(P[r.n3.b].ptr, nullptr, r.N, 0, r.b3p, NT * 32);
+            padv(P[r.l3.b].ptr, r.sclin ? P[r.sc.b].ptr : nullptr, r.N, 0, r.c3p, NT * 32);
+            if (r.sclin) { pack(r.sc, r.in0, r.in1, r.Wscp); packT(r.sc, r.in0, r.in1, r.WscT); }
+            packT(r.l1, r.in0, r.in1, r.W1T);
+            packT(r.l2, r.N, 0, r.W2T);
+            packT(r.l3, r.N, 0, r.W3T);
+            td[i] = TimeBlockDesc{P[r.te.w].ptr, P[r.te.b].ptr, P[r.l1.b].ptr, r.N, r.tb_off};
         }
+        for (const LinOpP& l : h->lin) {
+            const int NT = cdiv(l.l.N, 32), KG = groups_of(l.l.K);
+            pack(l.l, l.l.K, 0, l.Wp);
+            packT(l.l, l.l.K, 0, l.WT);
+            padv(P[l.l.b].ptr, nullptr, l.l.N, 0, l.bp, NT * 32);
+            if (l.lnact) {
+                padv(P[l.ln.w].ptr, nullptr, l.l.K, 0, l.gp, KG * 8 + 32);
+                padv(P[l.ln.b].ptr, nullptr, l.l.K, 0, l.betap, KG * 8 + 32);
+            }
+        }
+        if (!h->pack_dev) HIPCK(hipMalloc(&h->pack_dev, pd.size() * sizeof(PackDesc)));
+        h->pack_n = (int)pd.size();
+        h->pack_blocks = blk;
+        HIPCK(hipMemcpyAsync(h->pack_dev, pd.data(), pd.size() * sizeof(PackDesc), hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(h->tdesc_dev, td.data(), td.size() * sizeof(TimeBlockDesc), hipMemcpyHostToDevice, s));
+        HIPCK(hipStreamSynchronize(s));  // pd / td are host temporaries
     }
-    HIPCK(hipMemcpyAsync(h->tdesc_dev, td.data(), td.size() * sizeof(TimeBlockDesc), hipMemcpyHostToDevice, s));
-    HIPCK(hipStreamSynchronize(s));  // td is a host temporary
+    hipLaunchKernelGGL(k_pack_grouped, dim3((unsigned)h->pack_blocks), dim3(256), 0, s, h->pack_dev, h->pack_n);
     HIPCK(hipGetLastError());
     h->bound = true;
     return 0;
@@ -588,7 +852,7 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
     const int tpp = cdiv(B, 32), CG = groups_of(h->d.cond_dim);
     hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tpp * CG * 256, 256)), dim3(256), 0, s, cond, cond_mask, B, h->d.cond_dim, CG,
                        h->condfrag, tpp);
-    RunCtx c{B, 1, 0, x, out, nullptr, h->ts_ident};
+    RunCtx c{B, 1, 0, x, out, nullptr, h->ts_ident, false};
     run_unet(h, c, s);
     HIPCK(hipGetLastError());
     return 0;
@@ -645,12 +909,11 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
     else hipLaunchKernelGGL(k_randn, dim3(2048), dim3(256), 0, s, h->ywork, n, seed, 0xFFFFFFFFu);
     const int start = T - 1;
     HIPCK(hipMemcpyAsync(h->step_dev, &start, sizeof(int), hipMemcpyHostToDevice, s));
-
     const CallParams cp{noise, coef, omega, T, seed};
     HIPCK(hipMemcpyAsync(h->call_dev, &cp, sizeof cp, hipMemcpyHostToDevice, s));
     HIPCK(hipStreamSynchronize(s));  // `start` and `cp` are host temporaries
 
-    RunCtx c{B, 2, tpp, h->ywork, h->eps, h->step_dev, nullptr};
+    RunCtx c{B, 2, tpp, h->ywork, h->eps, h->step_dev, nullptr, false};
     UpdateArgs u;
     u.eps = h->eps; u.y = h->ywork; u.cp = h->call_dev; u.step_ptr = h->step_dev; u.n = n;
 
@@ -663,7 +926,7 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
         for (auto& e : ev) HIPCK(hipEventCreate(&e));
         int rc = 0;
         for (int k = 0; k < T && !rc; ++k) rc = enqueue_step(h, c, u, k < n_renorm, s, ev.data());
-        for (auto& e : ev) hipEventDestroy(e);
+        for (auto& e : ev) (void)hipEventDestroy(e);
         if (rc) return 1;
     } else if (flags & DSG_SAMPLE_NO_GRAPH) {
         for (int k = 0; k < T; ++k)
@@ -671,8 +934,7 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
     } else {
         // the per-step graph depends only on the workspace (batch size); everything per call is in device memory
         if (!(h->gexec[0] && h->g_rows == B)) {
-            for (int i = 0; i < 2; ++i)
-                if (h->gexec[i]) { hipGraphExecDestroy(h->gexec[i]); h->gexec[i] = nullptr; }
+            free_graphs(h);
             for (int variant = 0; variant < 2; ++variant) {  // 0: with renorm, 1: without
                 hipGraph_t g = nullptr;
                 HIPCK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
@@ -681,7 +943,7 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
                 if (rc) return 1;
                 if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
                 e = hipGraphInstantiate(&h->gexec[variant], g, nullptr, nullptr, 0);
-                hipGraphDestroy(g);
+                (void)hipGraphDestroy(g);
                 if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
             }
             h->g_rows = B;
@@ -689,6 +951,115 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
         for (int k = 0; k < T; ++k) HIPCK(hipGraphLaunch(h->gexec[k < n_renorm ? 0 : 1], s));
     }
     HIPCK(hipMemcpyAsync(out, h->ywork, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// training step
+// ------------------------------------------------------------------------------------------------------
+int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* ts, const float* noise, const float* cond_mask,
+                   const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat, float* loss_out, int B, void* stream) {
+    if (check_bound(h)) return 1;
+    if (B < 1 || T < 1) return fail("B and T must be >= 1");
+    if (!y || !cond || !ts || !noise || !sqrt_acp || !sqrt_1m_acp || !grads_flat || !loss_out)
+        return fail("dsg_train_step: null pointer argument");
+    if (ensure_train_workspace(h, B, T)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (build_train_descs(h, B, T, s)) return 1;
+    const int D = h->d.input_dim, C = h->d.cond_dim, CG = groups_of(C), DG = groups_of(D), tiles = cdiv(B, 32);
+    const int td = h->td, half = h->d.proj_dim / 2;
+    const float* A = h->arena;
+    const Param* P = h->params.data();
+
+    // ---- forward
+    HIPCK(hipMemcpyAsync(h->tr_ts, ts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_linspace_t, dim3(cdiv(T, 256)), dim3(256), 0, s, h->tvals, T);
+    run_time_path(h, T, s, true);
+    hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tiles * CG * 256, 256)), dim3(256), 0, s, cond, cond_mask, B, C, CG, h->condfrag, tiles);
+    hipLaunchKernelGGL(k_qsample, dim3(cdiv(tiles * DG * 256, 256)), dim3(256), 0, s, y, noise, h->tr_ts, sqrt_acp, sqrt_1m_acp, B, D,
+                       h->tr_yt_rm, trp(h, h->tr_yt_frag), tiles);
+    RunCtx c{B, 1, 0, h->tr_yt_rm, h->eps, nullptr, h->tr_ts, true};
+    run_unet(h, c, s);
+    hipLaunchKernelGGL(k_loss_grad, dim3(kRedBlocks), dim3(256), 0, s, h->eps, noise, B, D, trp(h, h->tr_deps), tiles, h->red);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, s, h->red, kRedBlocks, (double)B * (double)D, loss_out);
+
+    // ---- backward: activation gradients in reverse operator order
+    for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
+        const Op& op = h->ops[oi];
+        if (op.kind == OP_PROJ) continue;
+        if (op.kind == OP_RES) {
+            const ResP& r = h->res[op.p];
+            BlockBwdArgs a;
+            memset(&a, 0, sizeof a);
+            a.in0 = seg_of(h, op.in0);
+            if (op.in1 >= 0) a.in1 = seg_of(h, op.in1);
+            a.h1 = trp(h, r.h1); a.h2 = trp(h, r.h2);
+            a.gout_a = trp(h, h->tensors[op.out].ga);
+            a.gout_b = h->tensors[op.out].is_skip ? trp(h, h->tensors[op.out].gb) : nullptr;
+            a.W3T = A + r.W3T; a.W2T = A + r.W2T; a.W1T = A + r.W1T; a.WscT = r.sclin ? A + r.WscT : nullptr;
+            a.gamma1 = A + r.g1p; a.beta1 = A + r.b1p; a.gamma2 = A + r.g2p; a.beta2 = A + r.b2p; a.gamma3 = A + r.g3p; a.beta3 = A + r.b3p;
+            a.gin0 = trp(h, h->tensors[op.in0].ga);
+            a.gin1 = op.in1 >= 0 ? trp(h, h->tensors[op.in1].gb) : nullptr;
+            a.du1 = trp(h, r.du1); a.du2 = trp(h, r.du2); a.du3 = trp(h, r.du3); a.dh1 = trp(h, r.dh1); a.dh2 = trp(h, r.dh2);
+            a.rs1 = trp(h, r.rs1); a.rs2 = trp(h, r.rs2); a.rs3 = trp(h, r.rs3);
+            a.ntiles = tiles;
+            launch_res_bwd(r.N, r.sclin, a, s);
+        } else {
+            const LinOpP& l = h->lin[op.p];
+            LinBwdArgs a;
+            memset(&a, 0, sizeof a);
+            if (op.kind == OP_FINAL) {
+                a.gout_a = trp(h, h->tr_deps);
+                a.gamma = A + l.gp; a.beta = A + l.betap; a.du = trp(h, l.du); a.rs = trp(h, l.rs);
+            } else {
+                a.gout_a = trp(h, h->tensors[op.out].ga);
+                a.gout_b = h->tensors[op.out].is_skip ? trp(h, h->tensors[op.out].gb) : nullptr;
+            }
+            a.out_groups = groups_of(l.l.N);
+            a.WT = A + l.WT;
+            a.in = seg_of(h, op.in0);
+            a.gin = trp(h, h->tensors[op.in0].ga);
+            a.ntiles = tiles;
+            launch_lin_bwd(l.l.K, op.kind == OP_FINAL, a, s);
+        }
+    }
+    // ---- weight / bias / LayerNorm gradients: two grouped launches into per-chunk slabs, then a fixed-order reduce
+    hipLaunchKernelGGL(k_wgrad, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_slabs, h->slab_stride, tiles,
+                       h->tr_chunks);
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->cs_units, 4)), dim3(256), 0, s, h->cs_desc_dev, h->cs_unit_dev, h->cs_units, h->tr_slabs,
+                       h->slab_stride, tiles, h->tr_chunks, B);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((h->slab_stride + 255) / 256 < 4096 ? (h->slab_stride + 255) / 256 : 4096)), dim3(256),
+                       0, s, h->tr_slabs, h->slab_stride, h->tr_chunks, h->tr_gsum, h->slab_stride);
+
+    // ---- time path backward on the [T x .] tables (TimeEmbedding, UNetCF.py:35-44, and the per-block time_emb Linear)
+    {
+        float* G = h->tr_gsum;
+        float* emb = h->tr_tsave;
+        float* h1pre = emb + (size_t)T * 2 * half;
+        float* h1s = h1pre + (size_t)T * td;
+        float* tpre = h1s + (size_t)T * td;
+        float* d_st = tpre + (size_t)T * td;
+        float* d_h1s = d_st + (size_t)T * td;
+        bool first = true;
+        for (const ResP& r : h->res) {
+            const float* dtb = G + r.dtb_off;  // [N][T]
+            // d time_emb.weight[n][k] = sum_e dTB[n][e] * st[e][k]
+            small_gemm(dtb, T, 1, h->st, td, 1, G + P[r.te.w].off, td, 1, r.N, td, T, 0, s);
+            // d st[e][k] += sum_n dTB[n][e] * Wt[n][k]
+            small_gemm(dtb, 1, T, P[r.te.w].ptr, td, 1, d_st, td, 1, T, td, r.N, first ? 0 : 1, s);
+            first = false;
+        }
+        const unsigned eb = (unsigned)cdiv(T * td, 256);
+        hipLaunchKernelGGL(k_mul_silu_grad, dim3(eb), dim3(256), 0, s, d_st, tpre, (size_t)T * td);          // d temb (pre-Swish)
+        small_gemm(d_st, 1, td, h1s, td, 1, G + P[h->temb_l2w].off, td, 1, td, td, T, 0, s);                   // d lin2.weight
+        hipLaunchKernelGGL(k_col_sum_small, dim3(cdiv(td, 256)), dim3(256), 0, s, d_st, T, td, (long long)td, G + P[h->temb_l2b].off);
+        small_gemm(d_st, td, 1, P[h->temb_l2w].ptr, td, 1, d_h1s, td, 1, T, td, td, 0, s);                     // d h1 (post-Swish)
+        hipLaunchKernelGGL(k_mul_silu_grad, dim3(eb), dim3(256), 0, s, d_h1s, h1pre, (size_t)T * td);
+        small_gemm(d_h1s, 1, td, emb, 2 * half, 1, G + P[h->temb_l1w].off, 2 * half, 1, td, 2 * half, T, 0, s);  // d lin1.weight
+        hipLaunchKernelGGL(k_col_sum_small, dim3(cdiv(td, 256)), dim3(256), 0, s, d_h1s, T, td, (long long)td, G + P[h->temb_l1b].off);
+    }
+    HIPCK(hipMemcpyAsync(grads_flat, h->tr_gsum, (size_t)h->total_params * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCK(hipGetLastError());
     return 0;
 }
 
@@ -738,7 +1109,7 @@ int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* st
     hipStream_t s = (hipStream_t)stream;
     const int zero = 0;
     HIPCK(hipMemcpyAsync(h->step_dev, &zero, sizeof(int), hipMemcpyHostToDevice, s));
-    RunCtx c{B, 2, cdiv(B, 32), h->ywork, h->eps, h->step_dev, nullptr};
+    RunCtx c{B, 2, cdiv(B, 32), h->ywork, h->eps, h->step_dev, nullptr, false};
     hipEvent_t e0, e1;
     HIPCK(hipEventCreate(&e0));
     HIPCK(hipEventCreate(&e1));
@@ -749,8 +1120,8 @@ int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* st
     HIPCK(hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCK(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     *ms_avg = ms / iters;
     return 0;
 }

@@ -12,7 +12,7 @@
 //
 //   So the accumulator of one Linear is, register for register, the B operand of the next one, and
 //   LayerNorm / SiLU / bias / residual are plain per-register VALU work (row statistics need one
-//   exchange between the two lane halves).  Weights are pre-packed once (k_pack_linear) into the
+//   exchange between the two lane halves).  Weights are pre-packed (k_pack_grouped) into the
 //   matching A-operand order so that every weight fetch is one coalesced 1 KiB float4 wave load.
 //
 // In HBM a tensor is [tile][group][lane(64)][4] floats (1 KiB per tile-group, fully coalesced) plus
@@ -418,36 +418,72 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // Weight packing: nn.Linear.weight [N][Ktot] row-major -> MFMA A-fragment order
-//   packed[((nt*KG + g)*64 + lane)*4 + p] = W[32nt + (lane&31)][col(g) + 4(lane>>5) + p]
+//   kind 0  packed[((nt*KG + g)*64 + lane)*4 + p] = W[32nt + (lane&31)][col(g) + 4(lane>>5) + p]
+//   kind 1  the transposed operator (data gradient dX = W^T g):
+//           packed[((ot*NGin + g)*64 + lane)*4 + p] = W[8g + 4(lane>>5) + p][col(32ot + (lane&31))]
+//   kind 2  per-feature vectors (biases, LayerNorm gamma/beta, merged biases a+b) padded in group order
 // The K axis may be the concatenation of two tensors (widths w0, w1) that are padded to a multiple of 8
 // separately, matching the two input segments of k_resblock.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_pack_linear(const float* __restrict__ W, int N, int Ktot, int w0, int w1, float* __restrict__ out, int NT) {
-    const int g0 = (w0 + 7) / 8, g1 = (w1 + 7) / 8, KG = g0 + g1;
-    const size_t total = (size_t)NT * KG * 256;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int p = idx & 3, lane = (idx >> 2) & 63;
-        const size_t tg = idx >> 8;
+// One launch packs everything (dsg_bind_weights runs after every optimizer step): block -> descriptor by binary search.
+struct PackDesc {
+    const float* a;       // weight [N][Ktot], or vector
+    const float* b;       // optional second vector (added)
+    float* dst;
+    int kind;             // 0: A-operand pack, 1: transposed pack (data gradient), 2: padded vector
+    int N, Ktot, w0, w1, T;   // T = number of 32-wide output tiles (kind 0/1) ; npad (kind 2)
+    long long total;      // elements of dst
+    long long blk_begin;  // first block of this descriptor
+};
+
+__device__ __forceinline__ float pack_elem(const PackDesc& d, long long idx) {
+    if (d.kind == 2) {
+        const int g0 = (d.w0 + 7) / 8;
+        const int g = (int)(idx >> 3), e = (int)(idx & 7);
+        int k, ok;
+        if (g < g0) { k = 8 * g + e; ok = k < d.w0; }
+        else { const int kk = 8 * (g - g0) + e; ok = kk < d.w1; k = d.w0 + kk; }
+        float v = 0.f;
+        if (ok) { v = d.a[k]; if (d.b) v += d.b[k]; }
+        return v;
+    }
+    const int p = idx & 3, lane = (idx >> 2) & 63;
+    const long long tg = idx >> 8;
+    const int g0 = (d.w0 + 7) / 8;
+    if (d.kind == 0) {
+        const int KG = g0 + (d.w1 + 7) / 8;
         const int g = tg % KG, nt = tg / KG;
         const int n = 32 * nt + (lane & 31);
         int k, ok;
-        if (g < g0) { k = 8 * g + 4 * (lane >> 5) + p; ok = k < w0; }
-        else { const int kk = 8 * (g - g0) + 4 * (lane >> 5) + p; ok = kk < w1; k = w0 + kk; }
-        out[idx] = (ok && n < N && k < Ktot) ? W[(size_t)n * Ktot + k] : 0.f;
+        if (g < g0) { k = 8 * g + 4 * (lane >> 5) + p; ok = k < d.w0; }
+        else { const int kk = 8 * (g - g0) + 4 * (lane >> 5) + p; ok = kk < d.w1; k = d.w0 + kk; }
+        return (ok && n < d.N && k < d.Ktot) ? d.a[(size_t)n * d.Ktot + k] : 0.f;
     }
+    const int NGin = (d.N + 7) / 8;
+    const int g = tg % NGin, ot = tg / NGin;
+    const int n = 8 * g + 4 * (lane >> 5) + p;
+    const int o = 32 * ot + (lane & 31);
+    const int og = o >> 3, e = o & 7;
+    int col, ok;
+    if (og < g0) { col = 8 * og + e; ok = col < d.w0; }
+    else { const int c = 8 * (og - g0) + e; ok = c < d.w1; col = d.w0 + c; }
+    return (ok && n < d.N && col < d.Ktot) ? d.a[(size_t)n * d.Ktot + col] : 0.f;
 }
 
-// dst[i] (group-padded over two segments) = a[k] (+ b[k]) ; zero in the padding.  Used for biases and LN params.
-__global__ void k_pad_vec(const float* __restrict__ a, const float* __restrict__ b, int w0, int w1, float* __restrict__ dst, int npad) {
-    const int g0 = (w0 + 7) / 8;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x) {
-        const int g = i >> 3, e = i & 7;
-        int k, ok;
-        if (g < g0) { k = 8 * g + e; ok = k < w0; }
-        else { const int kk = 8 * (g - g0) + e; ok = kk < w1; k = w0 + kk; }
-        float v = 0.f;
-        if (ok) { v = a[k]; if (b) v += b[k]; }
-        dst[i] = v;
+constexpr int kPackPerBlock = 256 * 8;
+
+__global__ __launch_bounds__(256) void k_pack_grouped(const PackDesc* __restrict__ descs, int ndesc) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].blk_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = descs[lo];
+    const long long base = ((long long)blockIdx.x - d.blk_begin) * kPackPerBlock;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const long long idx = base + it * 256 + threadIdx.x;
+        if (idx < d.total) d.dst[idx] = pack_elem(d, idx);
     }
 }
 
@@ -467,7 +503,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void k_time_embed(const float* __restrict__ tvals, const float* __restrict__ freq, int half,
                                                     const float* __restrict__ W1, const float* __restrict__ b1,
                                                     const float* __restrict__ W2, const float* __restrict__ b2, int td,
-                                                    float* __restrict__ st) {
+                                                    float* __restrict__ st, float* __restrict__ save_emb, float* __restrict__ save_h1pre,
+                                                    float* __restrict__ save_h1s, float* __restrict__ save_tpre) {
     extern __shared__ float sm[];
     float* e = sm;            // [2*half]
     float* h1 = sm + 2 * half;  // [td]
@@ -477,6 +514,7 @@ __global__ __launch_bounds__(256) void k_time_embed(const float* __restrict__ tv
         const float ang = t * freq[i];
         e[i] = sinf(ang);
         e[half + i] = cosf(ang);
+        if (save_emb) { save_emb[(size_t)ent * 2 * half + i] = e[i]; save_emb[(size_t)ent * 2 * half + half + i] = e[half + i]; }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -485,14 +523,20 @@ __global__ __launch_bounds__(256) void k_time_embed(const float* __restrict__ tv
         float s = 0.f;
         for (int k = lane; k < K1; k += 64) s = fmaf(W1[(size_t)n * K1 + k], e[k], s);
         s = wave_sum(s) + b1[n];
-        if (lane == 0) h1[n] = silu(s);
+        if (lane == 0) {
+            h1[n] = silu(s);
+            if (save_h1pre) { save_h1pre[(size_t)ent * td + n] = s; save_h1s[(size_t)ent * td + n] = h1[n]; }
+        }
     }
     __syncthreads();
     for (int n = wave; n < td; n += nw) {
         float s = 0.f;
         for (int k = lane; k < td; k += 64) s = fmaf(W2[(size_t)n * td + k], h1[k], s);
         s = wave_sum(s) + b2[n];
-        if (lane == 0) st[(size_t)ent * td + n] = silu(s);
+        if (lane == 0) {
+            st[(size_t)ent * td + n] = silu(s);
+            if (save_tpre) save_tpre[(size_t)ent * td + n] = s;
+        }
     }
 }
 

@@ -1,0 +1,680 @@
+// Training step kernels (gfx950): q_sample, eps-MSE loss, the backward of the fused ResidualBlock / Linear kernels
+// of dsg_kernels.hpp, the grouped weight-gradient GEMM and the column-sum (bias / LayerNorm) gradients.
+//
+// Reference: DDPM.forward (classifier_free_MSR.py:100-112) + torch autograd through UNet1D (UNetCF.py:318-356).
+//
+// Data flow of one step (single pass, per-row ts):
+//   k_qsample -> forward kernels (k_resblock with save_h1/save_h2) -> k_loss_grad
+//   -> k_linear_bwd (final) -> k_resblock_bwd / k_linear_bwd in reverse op order   (activation gradients, registers)
+//   -> k_wgrad (ONE grouped launch: dW = G^T A for every Linear, contraction over batch rows, LDS transposition)
+//   -> k_colsum (ONE grouped launch: bias and LayerNorm gamma/beta gradients)
+//   -> k_reduce_slabs (deterministic sum of the per-row-chunk partial slabs into the flat gradient bucket)
+//   -> time-path backward on the [T x .] tables (k_small_gemm, tiny).
+// All gradients land in ONE flat float32 buffer in state-dict order: the DP all-reduce bucket.
+#pragma once
+#include "dsg_kernels.hpp"
+
+namespace dsg {
+
+// ---------------------------------------------------------------------------------------------
+// q_sample (MSR.py:103): y_t = sqrt_acp[ts]*y + sqrt_1m_acp[ts]*noise, written row-major (for feature_proj) and in
+// fragment layout (A operand of feature_proj's weight gradient).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_qsample(const float* __restrict__ y, const float* __restrict__ noise, const int* __restrict__ ts,
+                          const float* __restrict__ sa, const float* __restrict__ sb, int nrows, int D, float* __restrict__ yt_rm,
+                          float* __restrict__ yt_frag, int ntiles) {
+    const int DG = (D + 7) / 8;
+    const size_t total = (size_t)ntiles * DG * 256;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int p = idx & 3, lane = (idx >> 2) & 63;
+        const size_t tg = idx >> 8;
+        const int g = tg % DG, tile = tg / DG;
+        const int row = tile * 32 + (lane & 31), f = 8 * g + 4 * (lane >> 5) + p;
+        float v = 0.f;
+        if (row < nrows && f < D) {
+            const int t = ts[row];
+            v = __fadd_rn(__fmul_rn(sa[t], y[(size_t)row * D + f]), __fmul_rn(sb[t], noise[(size_t)row * D + f]));
+            yt_rm[(size_t)row * D + f] = v;
+        }
+        yt_frag[idx] = v;
+    }
+}
+
+// loss = mean((noise - eps_hat)^2) (F.mse_loss, MSR.py:112); d_eps = 2 (eps_hat - noise) / (B*D) in fragment layout.
+// Per-block float64 partial sums; k_loss_final reduces them in a fixed order.
+__global__ __launch_bounds__(256) void k_loss_grad(const float* __restrict__ eps, const float* __restrict__ noise, int nrows, int D,
+                                                   float* __restrict__ deps_frag, int ntiles, double* __restrict__ part) {
+    __shared__ double sm[4];
+    const int DG = (D + 7) / 8;
+    const size_t total = (size_t)ntiles * DG * 256;
+    const float scale = 2.0f / ((float)nrows * (float)D);
+    double s = 0.0;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int p = idx & 3, lane = (idx >> 2) & 63;
+        const size_t tg = idx >> 8;
+        const int g = tg % DG, tile = tg / DG;
+        const int row = tile * 32 + (lane & 31), f = 8 * g + 4 * (lane >> 5) + p;
+        float v = 0.f;
+        if (row < nrows && f < D) {
+            const float d = eps[(size_t)row * D + f] - noise[(size_t)row * D + f];
+            s += (double)d * (double)d;
+            v = d * scale;
+        }
+        deps_frag[idx] = v;
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void k_loss_final(const double* __restrict__ part, int nparts, double denom, float* __restrict__ loss) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < nparts; ++i) t += part[i];
+        *loss = (float)(t / denom);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm + SiLU backward on an accumulator-resident gradient (in place):
+//   in : da[f] = dL/d silu(u[f]),  x[f] = LN input,  u = xhat*gamma + beta
+//   out: da[f] <- dL/dx[f] ;  du_out[f] = dL/du[f] (stored for the gamma/beta column sums)
+// Row reductions run over the true width n_true; padded features are forced to zero.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_grad(float u) {
+    const float sg = __builtin_amdgcn_rcpf(1.0f + expf(-u));
+    return sg * fmaf(u, 1.0f - sg, 1.0f);
+}
+
+// NG groups held in acc arrays da[], x[] (accumulator order).  W = true width.
+template <int NG, int NT>
+__device__ __forceinline__ void ln_silu_bwd_acc(f32x16 (&da)[NT], const f32x16 (&x)[NT], const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float mean, float rstd, int W, int h,
+                                                float* __restrict__ du_out /* + lane*4, group stride 256 */) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int G = 0; G < NG; ++G) {
+        const float4 gm = ld4(gamma + 8 * G + 4 * h), bt = ld4(beta + 8 * G + 4 * h);
+        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+        float duv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool ok = 8 * G + 4 * h + p < W;
+            const float xh = (x[G >> 2][4 * (G & 3) + p] - mean) * rstd;
+            const float u = fmaf(xh, gmv[p], btv[p]);
+            const float du = ok ? da[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
+            duv[p] = du;
+            const float t = du * gmv[p];
+            da[G >> 2][4 * (G & 3) + p] = t;
+            s1 += t;
+            s2 = fmaf(t, xh, s2);
+        }
+        st4(du_out + (size_t)G * 256, make_float4(duv[0], duv[1], duv[2], duv[3]));
+    }
+    s1 = xhalf_sum(s1) * (1.0f / W);
+    s2 = xhalf_sum(s2) * (1.0f / W);
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool ok = 8 * G + 4 * h + p < W;
+            const float xh = (x[G >> 2][4 * (G & 3) + p] - mean) * rstd;
+            const float t = da[G >> 2][4 * (G & 3) + p];
+            da[G >> 2][4 * (G & 3) + p] = ok ? rstd * (t - s1 - xh * s2) : 0.f;
+        }
+}
+
+template <int NG, int NT>
+__device__ __forceinline__ void acc_load(f32x16 (&a)[NT], const float* __restrict__ p /* tile base + lane*4 */) {
+#pragma unroll
+    for (int G = 0; G < NT * 4; ++G) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (G < NG) v = ld4(p + (size_t)G * 256);
+        a[G >> 2][4 * (G & 3) + 0] = v.x; a[G >> 2][4 * (G & 3) + 1] = v.y;
+        a[G >> 2][4 * (G & 3) + 2] = v.z; a[G >> 2][4 * (G & 3) + 3] = v.w;
+    }
+}
+template <int NG, int NT>
+__device__ __forceinline__ void acc_load_add(f32x16 (&a)[NT], const float* __restrict__ p) {
+#pragma unroll
+    for (int G = 0; G < NG; ++G) {
+        const float4 v = ld4(p + (size_t)G * 256);
+        a[G >> 2][4 * (G & 3) + 0] += v.x; a[G >> 2][4 * (G & 3) + 1] += v.y;
+        a[G >> 2][4 * (G & 3) + 2] += v.z; a[G >> 2][4 * (G & 3) + 3] += v.w;
+    }
+}
+template <int NG, int NT>
+__device__ __forceinline__ void acc_store(const f32x16 (&a)[NT], float* __restrict__ p) {
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+        st4(p + (size_t)G * 256, make_float4(a[G >> 2][4 * (G & 3)], a[G >> 2][4 * (G & 3) + 1], a[G >> 2][4 * (G & 3) + 2],
+                                             a[G >> 2][4 * (G & 3) + 3]));
+}
+template <int NT>
+__device__ __forceinline__ void acc_zero(f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[nt][r] = 0.f;
+}
+
+// out += Wt * in  where `in` is an accumulator-resident gradient of NGin groups (raw, no activation).
+template <int NGin, int NTin, int NTout>
+__device__ __forceinline__ void chain_raw_from_acc(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], const float* __restrict__ wp,
+                                                   int lane) {
+    const size_t nt_stride = (size_t)NGin * 256;
+#pragma unroll
+    for (int G = 0; G < NGin; ++G)
+        mfma_group<NTout>(out, wp + (size_t)G * 256 + lane * 4, nt_stride, in[G >> 2][4 * (G & 3) + 0], in[G >> 2][4 * (G & 3) + 1],
+                          in[G >> 2][4 * (G & 3) + 2], in[G >> 2][4 * (G & 3) + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ResidualBlock backward, one wave per 32-row tile (mirror of k_resblock).
+// ---------------------------------------------------------------------------------------------
+struct BlockBwdArgs {
+    Seg in0, in1;            // forward inputs (+ their (mean, M2) statistics)
+    const float* h1;         // saved pre-LN2 tensor [tiles][NG][256]
+    const float* h2;         // saved pre-LN3 tensor
+    const float* gout_a;     // dL/d(out) from the chain consumer
+    const float* gout_b;     // dL/d(out) from the skip consumer, or null
+    const float* W3T;        // packed transposed weights
+    const float* W2T;
+    const float* W1T;        // [OT1][NG][256], OT1 = ceil(8*KG/32)
+    const float* WscT;       // or null (identity shortcut)
+    const float* gamma1; const float* beta1;
+    const float* gamma2; const float* beta2;
+    const float* gamma3; const float* beta3;
+    float* gin0;             // dL/d(in0) [tiles][g0][256]
+    float* gin1;             // dL/d(in1) [tiles][g1][256] or null
+    float* du1; float* du2; float* du3;   // dL/du of the three LayerNorm+SiLU stages (fragment layout)
+    float* dh1; float* dh2;               // dL/dh1, dL/dh2 (G operands of the weight gradients)
+    float* rs1; float* rs2; float* rs3;   // per-row (mean, rstd) of LN1/2/3 for the weight-gradient A operands
+    int ntiles;
+};
+
+// SCLIN <=> the block has a concat input (up blocks): the stage-1 data gradient then spans 2*NG groups.
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256) void k_resblock_bwd(const BlockBwdArgs a) {
+    constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
+    constexpr int KGT = SCLIN ? (2 * NG + 3) / 4 : NT;  // 32-feature output tiles of dL/dx
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int h = lane >> 5, j = lane & 31;
+    const int KG = a.in0.groups + a.in1.groups;
+    const size_t tN = (size_t)tile * NG * 256 + lane * 4;
+
+    // ---- dL/d(out)
+    f32x16 g[NT];
+    acc_load<NG, NT>(g, a.gout_a + tN);
+    if (a.gout_b) acc_load_add<NG, NT>(g, a.gout_b + tN);
+
+    // ---- stage 3: d a3 = W3^T g ; LN3/SiLU backward with h2
+    f32x16 d[NT], x[NT];
+    acc_zero<NT>(d);
+    chain_raw_from_acc<NG, NT, NT>(d, g, a.W3T, lane);
+    acc_load<NG, NT>(x, a.h2 + tN);
+    {
+        float mean, m2;
+        acc_stats<N, NT>(x, h, mean, m2);
+        const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+        if (h == 0) reinterpret_cast<float2*>(a.rs3)[(size_t)tile * 32 + j] = make_float2(mean, rstd);
+        ln_silu_bwd_acc<NG, NT>(d, x, a.gamma3, a.beta3, mean, rstd, N, h, a.du3 + tN);
+    }
+    acc_store<NG, NT>(d, a.dh2 + tN);
+
+    // ---- stage 2: d a2 = W2^T dh2 ; LN2/SiLU backward with h1
+    f32x16 (&d1)[NT] = g;  // reuse: g is re-read from memory for the shortcut
+    acc_zero<NT>(d1);
+    chain_raw_from_acc<NG, NT, NT>(d1, d, a.W2T, lane);
+    acc_load<NG, NT>(x, a.h1 + tN);
+    {
+        float mean, m2;
+        acc_stats<N, NT>(x, h, mean, m2);
+        const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+        if (h == 0) reinterpret_cast<float2*>(a.rs2)[(size_t)tile * 32 + j] = make_float2(mean, rstd);
+        ln_silu_bwd_acc<NG, NT>(d1, x, a.gamma2, a.beta2, mean, rstd, N, h, a.du2 + tN);
+    }
+    acc_store<NG, NT>(d1, a.dh1 + tN);
+
+    // ---- stage 1: d a1 = W1^T dh1 over the concat width; LN1/SiLU backward with x = cat(in0, in1)
+    float mean1, rstd1, wtot;
+    {
+        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
+        float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
+        if (a.in1.groups) {
+            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
+            const float n1 = (float)a.in1.width, nt_ = n + n1;
+            const float dd = s1.x - mean;
+            m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
+            mean = mean + dd * (n1 / nt_);
+            n = nt_;
+        }
+        mean1 = mean; wtot = n;
+        rstd1 = rsqrtf(m2 / n + kLnEps);
+        if (h == 0) reinterpret_cast<float2*>(a.rs1)[(size_t)tile * 32 + j] = make_float2(mean1, rstd1);
+    }
+    f32x16 dx[KGT];
+    acc_zero<KGT>(dx);
+    chain_raw_from_acc<NG, NT, KGT>(dx, d1, a.W1T, lane);
+    {
+        // pass 1: du, t = du*gamma, row sums (x streamed from memory, group by group)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int G = 0; G < KGT * 4; ++G) {
+            if (G < KG) {
+                const bool first = G < a.in0.groups;
+                const Seg& sg = first ? a.in0 : a.in1;
+                const int gl = first ? G : G - a.in0.groups;
+                const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                const float4 gm = ld4(a.gamma1 + 8 * G + 4 * h), bt = ld4(a.beta1 + 8 * G + 4 * h);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+                float duv[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool ok = 8 * gl + 4 * h + p < sg.width;
+                    const float xh = (xs[p] - mean1) * rstd1;
+                    const float u = fmaf(xh, gmv[p], btv[p]);
+                    const float du = ok ? dx[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
+                    duv[p] = du;
+                    const float t = du * gmv[p];
+                    dx[G >> 2][4 * (G & 3) + p] = t;
+                    s1 += t;
+                    s2 = fmaf(t, xh, s2);
+                }
+                st4(a.du1 + ((size_t)tile * KG + G) * 256 + lane * 4, make_float4(duv[0], duv[1], duv[2], duv[3]));
+            }
+        }
+        s1 = xhalf_sum(s1) / wtot;
+        s2 = xhalf_sum(s2) / wtot;
+        // pass 2: dL/dx
+#pragma unroll
+        for (int G = 0; G < KGT * 4; ++G) {
+            if (G < KG) {
+                const bool first = G < a.in0.groups;
+                const Seg& sg = first ? a.in0 : a.in1;
+                const int gl = first ? G : G - a.in0.groups;
+                const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool ok = 8 * gl + 4 * h + p < sg.width;
+                    const float xh = (xs[p] - mean1) * rstd1;
+                    const float t = dx[G >> 2][4 * (G & 3) + p];
+                    dx[G >> 2][4 * (G & 3) + p] = ok ? rstd1 * (t - s1 - xh * s2) : 0.f;
+                }
+            }
+        }
+    }
+    // ---- shortcut: + Wsc^T g  (Linear) or + g (identity); g re-read from memory
+    {
+        f32x16 (&gg)[NT] = x;
+        acc_load<NG, NT>(gg, a.gout_a + tN);
+        if (a.gout_b) acc_load_add<NG, NT>(gg, a.gout_b + tN);
+        if (SCLIN) {
+            chain_raw_from_acc<NG, NT, KGT>(dx, gg, a.WscT, lane);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) dx[nt] += gg[nt];
+        }
+    }
+    // ---- scatter dL/dx to the two input gradients
+#pragma unroll
+    for (int G = 0; G < KGT * 4; ++G) {
+        if (G < KG) {
+            const float4 v = make_float4(dx[G >> 2][4 * (G & 3)], dx[G >> 2][4 * (G & 3) + 1], dx[G >> 2][4 * (G & 3) + 2],
+                                         dx[G >> 2][4 * (G & 3) + 3]);
+            if (G < a.in0.groups) st4(a.gin0 + ((size_t)tile * a.in0.groups + G) * 256 + lane * 4, v);
+            else st4(a.gin1 + ((size_t)tile * a.in1.groups + (G - a.in0.groups)) * 256 + lane * 4, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plain Linear backward (data): gin = W^T gout ; with LNBWD (final layer) followed by LayerNorm+SiLU backward.
+// ---------------------------------------------------------------------------------------------
+struct LinBwdArgs {
+    const float* gout_a;     // [tiles][NGout][256]
+    const float* gout_b;     // or null
+    int out_groups;          // groups of gout (N of the Linear)
+    const float* WT;         // packed [OT][NGout][256]
+    Seg in;                  // forward input (for LNBWD)
+    const float* gamma; const float* beta;
+    float* gin;              // [tiles][in.groups][256]
+    float* du;               // LNBWD only
+    float* rs;               // LNBWD only: (mean, rstd)
+    int ntiles;
+};
+
+template <int OT, bool LNBWD>
+__global__ __launch_bounds__(256) void k_linear_bwd(const LinBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int h = lane >> 5, j = lane & 31;
+    const int NGo = a.out_groups, KG = a.in.groups;
+    f32x16 dx[OT];
+    acc_zero<OT>(dx);
+    const size_t nt_stride = (size_t)NGo * 256;
+    for (int g = 0; g < NGo; ++g) {
+        float4 gv = ld4(a.gout_a + ((size_t)tile * NGo + g) * 256 + lane * 4);
+        if (a.gout_b) {
+            const float4 gb = ld4(a.gout_b + ((size_t)tile * NGo + g) * 256 + lane * 4);
+            gv.x += gb.x; gv.y += gb.y; gv.z += gb.z; gv.w += gb.w;
+        }
+        mfma_group<OT>(dx, a.WT + (size_t)g * 256 + lane * 4, nt_stride, gv.x, gv.y, gv.z, gv.w);
+    }
+    if (LNBWD) {
+        const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)tile * 32 + j];
+        const float mean = s.x, rstd = rsqrtf(s.y / (float)a.in.width + kLnEps), invw = 1.0f / (float)a.in.width;
+        if (h == 0) reinterpret_cast<float2*>(a.rs)[(size_t)tile * 32 + j] = make_float2(mean, rstd);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int G = 0; G < OT * 4; ++G) {
+            if (G < KG) {
+                const float4 xv = ld4(a.in.data + ((size_t)tile * KG + G) * 256 + lane * 4);
+                const float4 gm = ld4(a.gamma + 8 * G + 4 * h), bt = ld4(a.beta + 8 * G + 4 * h);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+                float duv[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool ok = 8 * G + 4 * h + p < a.in.width;
+                    const float xh = (xs[p] - mean) * rstd;
+                    const float u = fmaf(xh, gmv[p], btv[p]);
+                    const float du = ok ? dx[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
+                    duv[p] = du;
+                    const float t = du * gmv[p];
+                    dx[G >> 2][4 * (G & 3) + p] = t;
+                    s1 += t;
+                    s2 = fmaf(t, xh, s2);
+                }
+                st4(a.du + ((size_t)tile * KG + G) * 256 + lane * 4, make_float4(duv[0], duv[1], duv[2], duv[3]));
+            }
+        }
+        s1 = xhalf_sum(s1) * invw;
+        s2 = xhalf_sum(s2) * invw;
+#pragma unroll
+        for (int G = 0; G < OT * 4; ++G) {
+            if (G < KG) {
+                const float4 xv = ld4(a.in.data + ((size_t)tile * KG + G) * 256 + lane * 4);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool ok = 8 * G + 4 * h + p < a.in.width;
+                    const float xh = (xs[p] - mean) * rstd;
+                    const float t = dx[G >> 2][4 * (G & 3) + p];
+                    dx[G >> 2][4 * (G & 3) + p] = ok ? rstd * (t - s1 - xh * s2) : 0.f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int G = 0; G < OT * 4; ++G)
+        if (G < KG)
+            st4(a.gin + ((size_t)tile * KG + G) * 256 + lane * 4,
+                make_float4(dx[G >> 2][4 * (G & 3)], dx[G >> 2][4 * (G & 3) + 1], dx[G >> 2][4 * (G & 3) + 2], dx[G >> 2][4 * (G & 3) + 3]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight gradient: for every Linear,  dW[n][k] = sum_rows G[row][n] * A[row][k].
+// The contraction runs over batch rows, which sit on the LANE axis of the fragment layout, so each 32-row tile of G
+// and A is transposed through LDS ([row][feature] images, rows padded by 4 floats: conflict-free b128 writes and
+// b32 reads) and fed to v_mfma_f32_32x32x2_f32 with i = out feature, j = in feature, k = row.
+// One workgroup = (descriptor, block of <=128 input features, row chunk); partial results go to slab[chunk].
+// ---------------------------------------------------------------------------------------------
+enum { A_RAW = 0, A_LNSILU = 1, A_ONEHOT = 2 };
+
+struct WgradDesc {
+    const float* G0; const float* G1;   // gradient wrt the Linear's output (sum of two tensors if G1)
+    int N, NG;                          // out features and groups of the G tensors
+    int amode;
+    Seg a0, a1;                         // A sources (fragment layout); a1.groups = 0 if absent
+    const float* rs;                    // A_LNSILU: per-row (mean, rstd)
+    const float* gamma; const float* beta;  // A_LNSILU: group-order padded
+    const int* ts;                      // A_ONEHOT: per-row entry
+    int onehot_n;                       // A_ONEHOT: number of entries (T)
+    long long out_off;                  // offset inside a slab of dW[0][0]
+    int ld;                             // row stride of dW (= Ktot)
+    int KG;                             // total A groups
+    int nrows;
+};
+struct WgradUnit { int desc; int kblk; int chunk; int pad; };
+
+constexpr int kWgLd = 132;  // padded row length of the LDS images (128 features + 4)
+
+__global__ __launch_bounds__(256) void k_wgrad(const WgradDesc* __restrict__ descs, const WgradUnit* __restrict__ units,
+                                               float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks) {
+    __shared__ __attribute__((aligned(16))) float img[2 * 32 * kWgLd];
+    float* Gimg = img;
+    float* Aimg = img + 32 * kWgLd;
+    const WgradUnit un = units[blockIdx.x];
+    const WgradDesc d = descs[un.desc];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int NT = (d.N + 31) / 32;
+    const int NTp = NT <= 1 ? 1 : (NT == 2 ? 2 : 4);      // n-tiles padded to a divisor of 4
+    const int rsplit = 4 / NTp;                           // waves sharing one n-tile split the 16 row-pair steps
+    const int my_nt = wave % NTp, my_part = wave / NTp;
+    const int g_lo = un.kblk * 16;
+    const int g_hi = (g_lo + 16 < d.KG) ? g_lo + 16 : d.KG;
+    const int ngr = g_hi - g_lo;                          // A groups handled here (<= 16)
+    const int KT = (ngr + 3) / 4;
+    const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+    const int t_lo = un.chunk * tiles_per_chunk;
+    const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
+
+    f32x16 acc[4];
+    acc_zero<4>(acc);
+
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        // ---- stage G: NG groups spread over the 4 waves
+        for (int g = wave; g < NTp * 4; g += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < d.NG) {
+                v = ld4(d.G0 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
+                if (d.G1) {
+                    const float4 w = ld4(d.G1 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
+                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                }
+            }
+            st4(&Gimg[j * kWgLd + 8 * g + 4 * h], v);
+        }
+        // ---- stage A
+        for (int gi = wave; gi < KT * 4; gi += 4) {
+            const int G = g_lo + gi;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gi < ngr) {
+                if (d.amode == A_ONEHOT) {
+                    int row = tile * 32 + j;
+                    const int e = row < d.nrows ? d.ts[row] : -1;
+                    const int f = 8 * G + 4 * h;
+                    v = make_float4(e == f ? 1.f : 0.f, e == f + 1 ? 1.f : 0.f, e == f + 2 ? 1.f : 0.f, e == f + 3 ? 1.f : 0.f);
+                } else {
+                    const bool first = G < d.a0.groups;
+                    const Seg& sg = first ? d.a0 : d.a1;
+                    const int gl = first ? G : G - d.a0.groups;
+                    v = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                    if (d.amode == A_LNSILU) {
+                        const float2 ms = reinterpret_cast<const float2*>(d.rs)[(size_t)tile * 32 + j];
+                        const float4 gm = ld4(d.gamma + 8 * G + 4 * h), bt = ld4(d.beta + 8 * G + 4 * h);
+                        v.x = silu(fmaf((v.x - ms.x) * ms.y, gm.x, bt.x)); v.y = silu(fmaf((v.y - ms.x) * ms.y, gm.y, bt.y));
+                        v.z = silu(fmaf((v.z - ms.x) * ms.y, gm.z, bt.z)); v.w = silu(fmaf((v.w - ms.x) * ms.y, gm.w, bt.w));
+                    }
+                    // rows beyond the batch must not contribute: forward tensors of padded rows are not zero
+                    if (tile * 32 + j >= d.nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            st4(&Aimg[j * kWgLd + 8 * gi + 4 * h], v);
+        }
+        __syncthreads();
+        // ---- MFMA: i = out feature (n-tile my_nt), j = in feature (k-tile kt), k = row pair
+        const int s_lo = my_part * (16 / rsplit), s_hi = s_lo + 16 / rsplit;
+        for (int s = s_lo; s < s_hi; ++s) {
+            const float av = Gimg[(2 * s + h) * kWgLd + 32 * my_nt + j];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+                if (kt < KT) {
+                    const float bv = Aimg[(2 * s + h) * kWgLd + 32 * kt + j];
+                    DSG_MFMA(acc[kt], av, bv);
+                }
+        }
+        __syncthreads();
+    }
+    // ---- waves that split the rows of one n-tile add their partial tiles through LDS, then the first writes the slab
+    if (rsplit > 1) {
+        float* red = img;  // <= 2 n-tiles x 4 k-tiles x 16 regs x 64 lanes = 32 KiB <= sizeof(img)
+        for (int part = 1; part < rsplit; ++part) {
+            if (my_part == part) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((my_nt * 4 + kt) * 16 + r) * 64 + lane] = acc[kt][r];
+            }
+            __syncthreads();
+            if (my_part == 0) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[kt][r] += red[((my_nt * 4 + kt) * 16 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+    }
+    if (my_part == 0 && my_nt < NT) {
+        float* out = slabs + (size_t)un.chunk * slab_stride + d.out_off;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < KT) {
+                // input feature of lane j in k-tile kt -> column of dW (the two A segments are padded separately)
+                const int G = g_lo + 4 * kt + (j >> 3), e = j & 7;
+                int col = -1;
+                if (G < g_hi) {
+                    if (d.amode == A_ONEHOT) { col = 8 * G + e; if (col >= d.onehot_n) col = -1; }
+                    else if (G < d.a0.groups) { col = 8 * G + e; if (col >= d.a0.width) col = -1; }
+                    else { const int c = 8 * (G - d.a0.groups) + e; col = c < d.a1.width ? d.a0.width + c : -1; }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 32 * my_nt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (col >= 0 && n < d.N) out[(size_t)n * d.ld + col] = acc[kt][r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped column sums over batch rows of fragment-layout tensors:
+//   out[f]  = sum_rows (P0 + P1)[row][f]                          (bias gradients)
+//   out2[f] = sum_rows P0[row][f] * xhat[row][f]                  (LayerNorm gamma gradient; xhat from X and rs)
+// One wave per (descriptor, group, chunk); lanes accumulate their own (row, half) slice, one cross-lane reduction at
+// the end.
+// ---------------------------------------------------------------------------------------------
+struct ColsumDesc {
+    const float* P0; const float* P1;
+    int groups;                 // groups of P
+    Seg x0, x1;                 // xhat sources (null data when unused)
+    const float* rs;
+    int w0, w1;                 // true widths of the (up to two) feature segments: column mapping
+    long long out_off;          // sum P      -> slab[out_off + col]   (or -1)
+    long long out_off_b;        // second destination of the same sum (or -1)
+    long long out2_off;         // sum P*xhat -> slab[out2_off + col]  (or -1)
+};
+struct ColsumUnit { int desc; int group; int chunk; int pad; };
+
+__global__ __launch_bounds__(256) void k_colsum(const ColsumDesc* __restrict__ descs, const ColsumUnit* __restrict__ units, int nunits,
+                                                float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks, int nrows) {
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= nunits) return;
+    const ColsumUnit un = units[u];
+    const ColsumDesc d = descs[un.desc];
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int G = un.group;
+    const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+    const int t_lo = un.chunk * tiles_per_chunk;
+    const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
+    const bool want2 = d.out2_off >= 0;
+    const int g0x = d.x0.groups;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        if (tile * 32 + j >= nrows) continue;
+        float4 p = ld4(d.P0 + ((size_t)tile * d.groups + G) * 256 + lane * 4);
+        if (want2) {
+            const Seg& sg = G < g0x ? d.x0 : d.x1;
+            const int gl = G < g0x ? G : G - g0x;
+            const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+            const float2 ms = reinterpret_cast<const float2*>(d.rs)[(size_t)tile * 32 + j];
+            q[0] = fmaf(p.x, (xv.x - ms.x) * ms.y, q[0]); q[1] = fmaf(p.y, (xv.y - ms.x) * ms.y, q[1]);
+            q[2] = fmaf(p.z, (xv.z - ms.x) * ms.y, q[2]); q[3] = fmaf(p.w, (xv.w - ms.x) * ms.y, q[3]);
+        }
+        if (d.P1) {
+            const float4 w = ld4(d.P1 + ((size_t)tile * d.groups + G) * 256 + lane * 4);
+            p.x += w.x; p.y += w.y; p.z += w.z; p.w += w.w;
+        }
+        s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            s[p] += __shfl_xor(s[p], o);
+            q[p] += __shfl_xor(q[p], o);
+        }
+    if (j == 0) {
+        const int gseg0 = (d.w0 + 7) / 8;
+        float* out = slabs + (size_t)un.chunk * slab_stride;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int col;
+            if (G < gseg0) { col = 8 * G + 4 * h + p; if (col >= d.w0) col = -1; }
+            else { const int c = 8 * (G - gseg0) + 4 * h + p; col = c < d.w1 ? d.w0 + c : -1; }
+            if (col >= 0) {
+                if (d.out_off >= 0) out[d.out_off + col] = s[p];
+                if (d.out_off_b >= 0) out[d.out_off_b + col] = s[p];
+                if (want2) out[d.out2_off + col] = q[p];
+            }
+        }
+    }
+}
+
+// grads[i] = sum_c slab[c][i]  (fixed order: deterministic)
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, size_t slab_stride, int nchunks, float* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float t = 0.f;
+        for (int c = 0; c < nchunks; ++c) t += slabs[(size_t)c * slab_stride + i];
+        out[i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time-path backward on the [entries x .] tables: tiny dense products, one thread per output.
+//   C[i][j] (+)= sum_l A[i*ai + l*al] * B[l*bl + j*bj]      (optional elementwise factor on A: swish'(Apre))
+// ---------------------------------------------------------------------------------------------
+__global__ void k_small_gemm(const float* __restrict__ A, long long ai, long long al, const float* __restrict__ B, long long bl,
+                             long long bj, float* __restrict__ C, long long ci, long long cj, int M, int N, int L, int accumulate) {
+    const long long total = (long long)M * N;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int jn = idx % N, im = idx / N;
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s = fmaf(A[im * ai + l * al], B[l * bl + jn * bj], s);
+        float* c = C + im * ci + jn * cj;
+        *c = accumulate ? *c + s : s;
+    }
+}
+
+// x[i] *= swish'(pre[i])
+__global__ void k_mul_silu_grad(float* __restrict__ x, const float* __restrict__ pre, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] *= silu_grad(pre[i]);
+}
+
+// out[j] = sum_i X[i][j]  (i < M rows, row stride ld)
+__global__ void k_col_sum_small(const float* __restrict__ X, int M, int N, long long ld, float* __restrict__ out) {
+    for (int jn = blockIdx.x * blockDim.x + threadIdx.x; jn < N; jn += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < M; ++i) s += X[i * ld + jn];
+        out[jn] = s;
+    }
+}
+
+}  // namespace dsg

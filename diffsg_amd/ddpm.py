@@ -122,5 +122,84 @@ class DDPMCore(nn.Module):
             out.append((name.value.decode(), fl.value, by.value, ms.value, calls.value))
         return out
 
-    def forward(self, y, cond):
-        raise NotImplementedError("DDPM.forward (training step) is wired in by diffsg_amd.train")
+    # ------------------------------------------------------------------ training
+    def forward(self, y, cond, *, ts=None, noise=None, cond_mask=None):
+        """loss = mean((noise - eps_theta(q_sample(y, ts, noise), ts/T, cond * mask))^2)   (MSR.py:100-112).
+
+        The three random draws are made here with torch's generator in the reference's order (randint, randn_like,
+        bernoulli) unless injected.  Forward and backward run fused in dsg_train_step; `loss.backward()` then only
+        publishes the gradients as `.grad` views of one flat bucket (see `grad_bucket`)."""
+        if not y.is_cuda:
+            raise RuntimeError("DDPM.forward: inputs are not on a HIP device; libdiffsg_hip has no CPU path")
+        hd = self.model.native_handle()
+        B, dev = y.shape[0], y.device
+        if ts is None:
+            ts = torch.randint(low=0, high=self.T, size=(1, B), device=dev)
+        if noise is None:
+            noise = torch.randn_like(y)
+        if cond_mask is None:
+            cond_mask = torch.bernoulli(torch.fill(torch.zeros(cond.shape[0], device=dev), 1 - self.uncond_prob))[:, None]
+        y32 = y.detach().to(torch.float32).contiguous()
+        c32 = cond.detach().to(dev, torch.float32).contiguous()
+        ts32 = ts.to(dev).reshape(-1).to(torch.int32).contiguous()
+        nz = noise.detach().to(dev, torch.float32).reshape(B, -1).contiguous()
+        mk = cond_mask.detach().to(dev, torch.float32).reshape(-1).contiguous()
+        if ts32.numel() != B or mk.numel() != B or nz.shape != y32.shape:
+            raise ValueError("ts / noise / cond_mask do not match the batch")
+        L = _lib.lib()
+        total = L.dsg_param_total(hd)
+        if getattr(self, "_grad_work", None) is None or self._grad_work.device != dev or self._grad_work.numel() != total:
+            self._grad_work = torch.zeros(total, device=dev, dtype=torch.float32)
+            self._grad_bucket = torch.zeros(total, device=dev, dtype=torch.float32)
+            self._loss_anchor = torch.zeros((), device=dev, requires_grad=True)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(L.dsg_train_step(hd, _lib.ptr(y32), _lib.ptr(c32), _lib.ptr(ts32), _lib.ptr(nz), _lib.ptr(mk),
+                                        _lib.ptr(self.sqrt_alphas_cumprod), _lib.ptr(self.sqrt_one_minus_alphas_cumprod),
+                                        self.T, _lib.ptr(self._grad_work), _lib.ptr(loss), B, _lib.stream_ptr()))
+        self._keepalive = (y32, c32, ts32, nz, mk)
+        if not torch.is_grad_enabled():
+            return loss
+        return _PublishGrads.apply(self._loss_anchor, loss, self)
+
+    @property
+    def grad_bucket(self):
+        """Flat float32 buffer (state-dict order of `model.*`) that backs every `model` parameter's `.grad`: the single
+        message of the data-parallel all-reduce."""
+        return getattr(self, "_grad_bucket", None)
+
+    def _publish(self, grad_out):
+        work, bucket = self._grad_work, self._grad_bucket
+        work.mul_(grad_out.to(work.dtype))
+        params = list(self.model.parameters())
+        installed = all(p.grad is not None for p in params) and params[0].grad.data_ptr() == bucket.data_ptr()
+        if installed:
+            bucket.add_(work)          # gradient accumulation across calls, as autograd would
+        else:
+            bucket.copy_(work)
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.grad = bucket[off:off + n].view_as(p)
+                off += n
+
+    def allreduce_grads(self):
+        """Data parallel: ONE all-reduce of the flat bucket, mean over ranks (mse_loss is a mean over local rows)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self.grad_bucket is not None:
+            dist.all_reduce(self._grad_bucket, op=dist.ReduceOp.SUM)
+            self._grad_bucket.div_(dist.get_world_size())
+
+
+class _PublishGrads(torch.autograd.Function):
+    """Connects the already-computed loss to autograd: backward() publishes the fused kernel's gradients."""
+
+    @staticmethod
+    def forward(ctx, anchor, loss, owner):
+        ctx.owner = owner
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.owner._publish(grad_out)
+        return None, None, None

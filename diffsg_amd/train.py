@@ -8,30 +8,6 @@ not communicated.
 """
 from __future__ import annotations
 
-import torch
-import torch.distributed as dist
-
-
-class GradBucket:
-    """Flat float32 view over the gradients of the denoiser's parameters: one collective per step."""
-
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-
-    def zero(self):
-        self.flat.zero_()
-
-    def all_reduce_mean(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
 
 
 def run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log=print):
@@ -43,6 +19,7 @@ def run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, w
             y_true = y_true.to(device)
             loss = diffusion_model(y_true, x)
             loss.backward()
+            diffusion_model.allreduce_grads()   # no-op unless torch.distributed is initialised with world_size > 1
             optimizer.step()
             optimizer.zero_grad()
             if (use_ema and epoch > warmup_epoch and ema_step_cnt > diffusion_model.ema_start

@@ -41,6 +41,7 @@ const char* dsg_last_error(void);
 int dsg_param_count(const dsg_handle* h);
 const char* dsg_param_name(const dsg_handle* h, int i);
 long long dsg_param_numel(const dsg_handle* h, int i);
+long long dsg_param_total(const dsg_handle* h);   /* sum of numel = length of the flat gradient bucket */
 int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* stream);
 
 /* Pre-size the workspace for up to `max_rows` batch rows and `max_entries` time-table rows. */
@@ -64,6 +65,18 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
 #define DSG_SAMPLE_PROFILE 2
 int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed,
                float omega, const float* coef, int T, float* out, int B, int flags, void* stream);
+
+/* One training step's forward + backward: loss = DDPM.forward(y, cond) (classifier_free_MSR.py:100-112) and
+ * d(loss)/d(theta) for every denoiser tensor, as `loss.backward()` produces them (classifier_free_MSR.py:223-224).
+ *   y [B][D], cond [B][C] row-major;  ts [B] int32 in [0,T);  noise [B][D];  cond_mask [B] (0/1) -- the three random
+ *   draws of the reference (MSR.py:101,102,107) are made by the caller so that it keeps their order and generator;
+ *   sqrt_acp / sqrt_1m_acp [T] = the registered buffers sqrt_alphas_cumprod / sqrt_one_minus_alphas_cumprod;
+ *   grads_flat [dsg_param_total] receives the gradients concatenated in state-dict order (the DP all-reduce bucket);
+ *   loss_out  one float on the device.
+ * The weights bound by the last dsg_bind_weights are used; rebind after the optimizer step. */
+int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* ts, const float* noise,
+                   const float* cond_mask, const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat,
+                   float* loss_out, int B, void* stream);
 
 /* avg = decay*avg + one_minus_decay*p over n floats   (ddpm_opt/ema.py:11-12). */
 int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_decay, long long n, void* stream);

@@ -337,6 +337,15 @@ def g7():
         out[f"step{step}_feature_proj.weight"] = ema.module.feature_proj.weight.detach().numpy().copy()
         out[f"step{step}_norm.bias"] = ema.module.norm.bias.detach().numpy().copy()
     save("g7_ema.npz", **out)
+    # seeded construction + init_weights: per-tensor float64 sums pin the construction order / RNG consumption
+    out = {}
+    for name in ("tiny", "nu3"):
+        torch.manual_seed(5)
+        m = ref_unet(CONFIGS[name])
+        m.apply(init_weights)
+        out[name + "_sums"] = np.array([float(v.double().sum()) for v in m.state_dict().values()])
+        out[name + "_abs"] = np.array([float(v.double().abs().sum()) for v in m.state_dict().values()])
+    save("g7_seeded_init.npz", **out)
 
 
 if __name__ == "__main__":

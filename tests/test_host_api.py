@@ -1,0 +1,133 @@
+"""CPU tests of the host side: the C-ABI library loads and exports what include/diffsg.h declares, the module tree has
+the reference's state-dict layout and seeded init, loaders / decoders / schedule match the reference-generated goldens,
+and the compute entry points fail loudly without a GPU (no fallback).  No compute call is made here."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from _util import GOLD, ROOT
+from weights import CONFIGS
+
+
+def test_library_exports_every_declared_symbol():
+    from diffsg_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "diffsg.h")).read()
+    declared = sorted(set(re.findall(r"\b(dsg_[a-z_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in diffsg.h but not exported"
+    assert sorted(_lib.exported_symbols()) == declared
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_state_dict_layout(name):
+    from diffsg_amd import UNet1D, generate_cosine_schedule
+    from diffsg_amd.classifier_free_MSR import DDPM
+    with open(os.path.join(GOLD, "g7_state_layout.json")) as f:
+        ref = json.load(f)[name]
+    cfg = CONFIGS[name]
+    D = cfg["input_dim"]
+    m = UNet1D(**cfg, is_attn=(False,) * len(cfg["dims"]))
+    d = DDPM(20, m, D, 10.0, 1.0 - generate_cosine_schedule(20), torch.device("cpu"), (1, D), None)
+    got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in d.state_dict().items()]
+    assert got == ref
+
+
+@pytest.mark.parametrize("name", ["tiny", "nu3"])
+def test_seeded_construction_matches_reference(gold, name):
+    from diffsg_amd import UNet1D, init_weights
+    g = gold("g7_seeded_init.npz")
+    cfg = CONFIGS[name]
+    torch.manual_seed(5)
+    m = UNet1D(**cfg, is_attn=(False,) * len(cfg["dims"]))
+    m.apply(init_weights)
+    sums = np.array([float(v.double().sum()) for v in m.state_dict().values()])
+    absum = np.array([float(v.double().abs().sum()) for v in m.state_dict().values()])
+    assert np.array_equal(sums, g[name + "_sums"]) and np.array_equal(absum, g[name + "_abs"])
+
+
+def test_nu_checkpoint_weights_load_strict(gold):
+    from diffsg_amd import UNet1D
+    g = gold("g4_sample_nu_ckpt.npz")
+    cfg = CONFIGS["nu3"]
+    m = UNet1D(**cfg, is_attn=(False,) * 3)
+    m.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}, strict=True)
+
+
+@pytest.mark.parametrize("T", [4, 20, 400, 500, 1000])
+def test_schedule_and_buffers(gold, T):
+    from diffsg_amd import generate_cosine_schedule
+    from diffsg_amd.classifier_free_MSR import DDPM
+    g = gold("g1_schedule.npz")
+    betas = generate_cosine_schedule(T)
+    assert np.array_equal(betas, g[f"T{T}_betas_f64"])
+    d = DDPM(T, torch.nn.Identity(), 3, 10.0, 1.0 - betas, "cpu", (1, 3))
+    names = [k for k in d.state_dict() if not k.startswith("ema.")]
+    assert names == ["betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                     "reciprocal_sqrt_alphas", "remove_noise_coeff", "sqrt_betas"]
+    for k in names:
+        assert np.array_equal(d.state_dict()[k].numpy(), g[f"T{T}_{k}"]), k
+    # per-step coefficient table against the reference's scalar expressions (MSR.py:133-134)
+    coef = d._coef_table()
+    for i in (0, 1, 2, T - 1):
+        c1 = d.betas[i] / d.sqrt_one_minus_alphas_cumprod[i]
+        c3 = (1.0 - d.alphas_cumprod[i - 1 if i - 1 >= 0 else 0]) / (1.0 - d.alphas_cumprod[i])
+        assert coef[i, 0] == c1 and coef[i, 1] == d.reciprocal_sqrt_alphas[i] and coef[i, 2] == c3
+        assert float(coef[i, 3]) == (1.0 if i > 1 else 0.0)
+
+
+def test_loaders_match_reference(gold):
+    from diffsg_amd.classifier_free_CO import co_data_load
+    from diffsg_amd.classifier_free_MSR import msr_data_load
+    from diffsg_amd.classifier_free_NU import nu_data_load
+    g = gold("g6_loaders.npz")
+    dd = os.path.join(GOLD, "data")
+    Xtr, Ytr, Xte, Yte, cfg = msr_data_load(os.path.join(dd, "3c_10w_200samples.csv"))
+    for a, k in ((Xtr, "msr_Xtr"), (Ytr, "msr_Ytr"), (Xte, "msr_Xte"), (Yte, "msr_Yte")):
+        assert np.array_equal(a, g[k]), k
+    assert [cfg["M"], cfg["W"], cfg["scaler_min"], cfg["scaler_max"]] == list(g["msr_cfg"])
+    assert (cfg["sfn"], cfg["cfn"], cfg["cdim"]) == (1, 0, 1)
+    Xtr, Ytr, Xte, Yte, Rte, cfg = nu_data_load(os.path.join(dd, "3u_18mW_200samples.csv"), 400, 400)
+    for a, k in ((Xtr, "nu_Xtr"), (Ytr, "nu_Ytr"), (Xte, "nu_Xte"), (Yte, "nu_Yte"), (Rte, "nu_Rte")):
+        assert np.array_equal(a, g[k]), k
+    assert [cfg["K"], cfg["P_sum"]] == list(g["nu_cfg"]) and (cfg["width"], cfg["height"]) == (400, 400)
+    Xtr, Ytr, Xte, Yte, cfg = co_data_load(os.path.join(dd, "3nodes_200samples_ood.csv"))
+    for a, k in ((Xtr, "co_Xtr"), (Ytr, "co_Ytr"), (Xte, "co_Xte"), (Yte, "co_Yte")):
+        assert a.shape == g[k].shape and np.allclose(a, g[k], rtol=1e-13, atol=0), k
+    assert np.allclose([cfg["scaler_min"], cfg["scaler_max"]], g["co_cfg"], rtol=1e-13)
+
+
+def test_decoders_match_reference(gold):
+    from diffsg_amd import decode as Dc
+    g = gold("g5_decoders.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    close = lambda a, b, tol=2e-6: np.abs(a.numpy() - b).max() <= tol * max(np.abs(b).max(), 1e-30)
+    dec = Dc.msr_decode(t("msr_y"))
+    assert close(dec, g["msr_dec"]) and close(Dc.msr_rate(10.0 * dec, t("msr_gain")), g["msr_rate"])
+    dec = Dc.co_decode(t("co_y"))
+    assert close(dec, g["co_dec"]) and close(Dc.co_cost(t("co_X"), dec), g["co_cost"])
+    dec = Dc.nu_decode(t("nu_y"), 400, 400, 18.0)
+    assert close(dec, g["nu_dec"]) and close(Dc.nu_rate(dec, t("nu_X")), g["nu_rate"], 1e-5)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_compute_entry_points_fail_loudly_without_gpu():
+    from diffsg_amd import UNet1D, generate_cosine_schedule
+    from diffsg_amd.classifier_free_MSR import DDPM, train_ddpm_msr
+    cfg = CONFIGS["tiny"]
+    m = UNet1D(**cfg, is_attn=(False,) * 3)
+    x, c = torch.zeros(4, 3), torch.zeros(4, 3)
+    with pytest.raises(RuntimeError):
+        m(x, torch.zeros(1, 4), c, torch.ones(4, 1))
+    d = DDPM(20, m, 3, 10.0, 1.0 - generate_cosine_schedule(20), torch.device("cpu"), (1, 3), None)
+    with pytest.raises(RuntimeError):
+        d.sample(c, 1.0)
+    with pytest.raises(RuntimeError):
+        d(x, c)
+    with pytest.raises(RuntimeError):
+        train_ddpm_msr(os.path.join(GOLD, "data", "3c_10w_200samples.csv"), epochs=1)
