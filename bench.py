@@ -87,6 +87,44 @@ def _cpu_baseline_run(nthreads, sample_rows, steps, B_ref):
             "row_steps_per_s": row_steps}
 
 
+def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=3):
+    """MSR-80c training throughput (BASELINE config 5 shape): per GPU `B` rows, T=20, Adam(lr 5e-3); one step =
+    DDPM.forward (q_sample + denoiser forward + backward in libdiffsg_hip) + ONE all-reduce of the flat 6.6 MB gradient
+    bucket (RCCL, world > 1) + Adam.step + re-pack of the updated weights."""
+    ddpm = build_model(dev, 20)
+    opt = torch.optim.Adam(ddpm.parameters(), lr=0.005)
+    g = torch.Generator().manual_seed(100 + rank)
+    cond = torch.rand(B, 80, generator=g).to(dev)
+    y = (torch.rand(B, 80, generator=g) * (20.0 / 80)).to(dev)
+
+    def one():
+        loss = ddpm(y, cond)
+        loss.backward()
+        ddpm.allreduce_grads()
+        opt.step()
+        opt.zero_grad()
+        return loss
+    for _ in range(warmup):
+        one()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # algorithmic FLOP per sample: 3 x 2 x (trunk + cond) MACs with the time path tabulated over T rows (SURVEY 8(d))
+    f_train = 3 * 2 * (566_400 + 100_480)
+    sps = world * B * steps / dt
+    return {"samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": B, "global_batch": world * B,
+            "steps": steps, "T": 20, "final_loss": float(loss), "achieved_tflops": sps / world * f_train / 1e12,
+            "frac_f32_mfma": sps / world * f_train / 1e12 / PEAK_F32_TFLOPS, "grad_bucket_bytes": int(ddpm.grad_bucket.numel()) * 4,
+            "collective": "one all_reduce(SUM)/world per step over the flat bucket" if world > 1 else "none (1 GPU)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +133,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="rows per GPU")
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=32768, help="training rows per GPU (global 262144 on 8 GPUs)")
+    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--no-train", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +176,10 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(y0).all()
 
+    train = None
+    if not a.no_train:
+        train = train_leg(dev, dist, rank, world, a.train_batch, a.train_steps, barrier)
+
     if rank == 0:
         # roofline of the dominant kernel: eager re-run of the same K steps with HIP events around every launch
         ddpm_k.sample(cond, a.omega, seed=2, profile=True)
@@ -169,6 +214,8 @@ def main():
                               "frac_hbm": BYT_ALG * B / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             "op_ms_per_step": {r[0]: r[3] / K for r in prof},
         }
+        if train is not None:
+            out["train"] = train
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

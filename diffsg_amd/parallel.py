@@ -1,0 +1,50 @@
+"""One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+Reverse sampling is row-parallel with NO collective: every rank runs `DDPM.sample` on its own row shard, exactly as
+the reference treats its 512-row chunks as independent calls (classifier_free_MSR.py:273-279; the early-step global
+renorm is per call).  Training is data parallel with ONE all-reduce per step over the flat gradient bucket
+(`DDPMCore.allreduce_grads`); `ema.module.*` and the schedule buffers are never communicated.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_rows(n_rows: int, rank: int, world_size: int):
+    """Contiguous, balanced [start, stop) of rank's rows (the first n_rows % world ranks get one extra row)."""
+    base, extra = divmod(n_rows, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def sample_sharded(ddpm, cond_all, omega=1.0, gather=False, **kw):
+    """Each rank samples its shard of `cond_all` (no collective).  With gather=True the shards are all-gathered
+    afterwards (a convenience for evaluation, outside the sampling path)."""
+    rank, ws = world()
+    lo, hi = shard_rows(cond_all.shape[0], rank, ws)
+    y = ddpm.sample(cond_all[lo:hi], omega, **kw)
+    if not gather or ws == 1:
+        return y
+    sizes = [shard_rows(cond_all.shape[0], r, ws) for r in range(ws)]
+    width = max(b - a for a, b in sizes)
+    pad = torch.zeros(width, y.shape[1], device=y.device, dtype=y.dtype)
+    pad[: y.shape[0]] = y
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[: b - a] for p, (a, b) in zip(parts, sizes)])
+
+
+def broadcast_parameters(module, src=0):
+    """Replicas start from rank `src`'s weights (one flat broadcast per dtype group is not needed at 6 MB)."""
+    rank, ws = world()
+    if ws == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)

@@ -252,3 +252,34 @@ def test_training_reduces_loss_and_matches_cpu_adam():
         assert abs(float(loss) - float(ref)) <= 2e-4 * abs(float(ref)), step
     for k, v in ddpm.model.state_dict().items():
         assert rel(v, cpu[k].detach()) <= 1e-3, k
+
+
+def test_entry_points_train_save_load_eval(tmp_path):
+    """train_ddpm_msr -> torch.save(state_dict) -> load_test_msr on the committed 200-row CSV slice (the reference's
+    call sequence, classifier_free_MSR.py:347-355), plus the NU and CO loaders through their train entry points."""
+    import os
+    from _util import GOLD
+    from diffsg_amd import classifier_free_CO as CO, classifier_free_MSR as MSR, classifier_free_NU as NU
+    dd = os.path.join(GOLD, "data")
+    logs = []
+    torch.manual_seed(0)
+    model = MSR.train_ddpm_msr(os.path.join(dd, "3c_10w_200samples.csv"), epochs=3, batch_size=64, log=logs.append)
+    losses = [float(l.split("Loss:")[1]) for l in logs]
+    assert len(losses) == 3 and all(np.isfinite(losses)) and losses[-1] < losses[0]
+    ck = str(tmp_path / "ddpm_msr_3c.pt")
+    torch.save(model.state_dict(), ck)
+    sd = torch.load(ck, map_location="cpu")
+    assert list(sd)[:8] == ["betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                            "reciprocal_sqrt_alphas", "remove_noise_coeff", "sqrt_betas"] and len(sd) == 985
+    out = MSR.load_test_msr(ck, os.path.join(dd, "3c_10w_200samples.csv"), omega=1.0, log=logs.append)
+    assert np.isfinite(out["less_ratio"]) and 0.0 < out["less_ratio"] < 1.5
+    m = NU.train_ddpm_nu(os.path.join(dd, "3u_18mW_200samples.csv"), epochs=1, batch_size=70, log=logs.append)
+    assert np.isfinite(float(logs[-1].split("Loss:")[1]))
+    ck = str(tmp_path / "ddpm_nu.pt")
+    torch.save(m.state_dict(), ck)
+    assert np.isfinite(NU.load_test_nu(ck, os.path.join(dd, "3u_18mW_200samples.csv"), omega=1.0, log=logs.append)["less_ratio"])
+    m = CO.train_ddpm_co(os.path.join(dd, "3nodes_200samples_ood.csv"), epochs=1, batch_size=70, use_ema=True, warmup_epoch=-1,
+                         log=logs.append)
+    ck = str(tmp_path / "ddpm_co.pt")
+    torch.save(m.state_dict(), ck)
+    assert np.isfinite(CO.load_test_co(ck, os.path.join(dd, "3nodes_200samples_ood.csv"), omega=1.0, log=logs.append)["exceeded_ratio"])
