@@ -35,8 +35,10 @@ import torch  # noqa: E402
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (fp32 vector = fp32 MFMA)
 PEAK_HBM_GBS = 8000.0     # spec; 6290 measured
 MSR80 = dict(input_dim=80, proj_dim=128, cond_dim=80, dims=(64, 32, 16, 8), n_blocks=2)
-# algorithmic work per sample-step with the time path hoisted and the uncond cond-GEMMs elided
-F_ALG = 2 * (2 * 566_400 + 100_480)   # FLOP / row / step
+# Algorithmic work per sample-step: 2 passes x trunk MACs.  The time path (depends only on the step) and the condition
+# embeddings (depend only on the row, not on the step) are computed once per sample() call, outside the step; SURVEY
+# 8(d) still counted the conditional pass's cond GEMMs (+100 480 MAC) because it hoisted only the time path.
+F_ALG = 2 * (2 * 566_400)             # FLOP / row / step
 BYT_ALG = 4 * (3 * 80 + 80)           # B / row / step
 
 
@@ -185,7 +187,8 @@ def main():
         ddpm_k.sample(cond, a.omega, seed=2, profile=True)
         torch.cuda.synchronize()
         prof = ddpm_k.op_profile()
-        name, fl, by, ms, calls = max(prof, key=lambda r: r[3])
+        # dominant kernel = the operator shape with the largest algorithmic FLOP count (the proj_dim-wide up blocks)
+        name, fl, by, ms, calls = max(prof, key=lambda r: (r[1], r[3]))
         dom = [r for r in prof if r[1] == fl and r[0].split(".")[0] == name.split(".")[0]]
         ms_sum, n_calls = sum(r[3] for r in dom), sum(r[4] for r in dom)
         avg_ms = ms_sum / n_calls

@@ -60,6 +60,7 @@ _SIGS = {
                                   ctypes.c_void_p]),
     "dsg_ema_update": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_longlong,
                                       ctypes.c_void_p]),
+    "dsg_fused_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "dsg_op_count": (ctypes.c_int, [ctypes.c_void_p]),
     "dsg_op_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_double)]),

@@ -58,6 +58,7 @@ struct ResP {              // ResidualBlock (UNetCF.py:49-95)
     NormP n1, n2, n3;
     LinearP l1, l2, l3, sc, te, ce;
     int tb_off = 0;        // slice of the time table row
+    size_t ce_off = 0;     // per-tile float offset of this block's precomputed condition embedding
     // packed (arena offsets, floats)
     size_t W1p, g1p, b1p, W2p, g2p, b2p, c2p, Wcp, W3p, g3p, b3p, c3p, Wscp;
     size_t W1T, W2T, W3T, WscT;  // transposed packs (data gradients)
@@ -119,6 +120,10 @@ struct dsg_handle {
     int cap_rows = 0, cap_entries = 0;
     float* ws = nullptr;        // activations
     float* condfrag = nullptr;
+    float* cembed = nullptr;    // [tiles_per_pass cap][ce_per_tile]: Wc silu(cond) of every block (sampling)
+    float* ce_stats = nullptr;  // scratch statistics sink of the precompute launches
+    size_t ce_per_tile = 0;
+    size_t zero_off = 0;        // 128 zero floats in the arena
     float* tb = nullptr;        // [entries][tb_stride]
     float* st = nullptr;        // [entries][td]
     float* tvals = nullptr;     // [entries]
@@ -132,6 +137,11 @@ struct dsg_handle {
     hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream)
     std::vector<double> op_ms;   // DSG_SAMPLE_PROFILE: summed HIP-event time per op
     std::vector<int> op_calls;
+
+    // fused narrow run [fuse_lo, fuse_hi) of `ops` (inference only)
+    int fuse_lo = 0, fuse_hi = 0;
+    FusedOp* fused_dev = nullptr;
+    std::vector<FusedOp> fused_host;
 
     // cached step graphs
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
@@ -240,7 +250,9 @@ void carve(dsg_handle* h) {
         l.betap = l.lnact ? c.take((size_t)KG * 8 + 32) : 0;
         l.WT = c.take((size_t)cdiv(KG, 4) * groups_of(l.l.N) * 256);
     }
+    h->zero_off = c.take(128);
     h->arena_floats = c.off;
+    for (auto& r : h->res) { r.ce_off = h->ce_per_tile; h->ce_per_tile += (size_t)groups_of(r.N) * 256; }
     // training workspace layout (per-tile float offsets)
     size_t o = 0;
     auto take = [&](size_t f) { size_t r = o; o += f; return r; };
@@ -281,9 +293,10 @@ void free_train_workspace(dsg_handle* h) {
 void free_workspace(dsg_handle* h) {
     free_graphs(h);
     free_train_workspace(h);  // its descriptors point into the forward workspace
-    void* ptrs[] = {h->ws, h->condfrag, h->tb, h->st, h->tvals, h->ts_ident, h->eps, h->ywork};
+    void* ptrs[] = {h->ws, h->condfrag, h->tb, h->st, h->tvals, h->ts_ident, h->eps, h->ywork, h->cembed, h->ce_stats};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    h->cembed = h->ce_stats = nullptr;
     h->ws = h->condfrag = h->tb = h->st = h->tvals = h->eps = h->ywork = nullptr;
     h->ts_ident = nullptr;
     h->cap_rows = h->cap_entries = 0;
@@ -307,6 +320,8 @@ int ensure_workspace(dsg_handle* h, int rows, int entries) {
     HIPCK(hipMalloc(&h->ws, tiles * h->per_tile_floats * sizeof(float)));
     HIPCK(hipMemset(h->ws, 0, tiles * h->per_tile_floats * sizeof(float)));
     HIPCK(hipMalloc(&h->condfrag, (tiles / 2) * CG * 256 * sizeof(float)));
+    HIPCK(hipMalloc(&h->cembed, (tiles / 2) * h->ce_per_tile * sizeof(float)));
+    HIPCK(hipMalloc(&h->ce_stats, (tiles / 2) * 64 * sizeof(float)));
     HIPCK(hipMalloc(&h->tb, (size_t)nent * h->tb_stride * sizeof(float)));
     HIPCK(hipMalloc(&h->st, (size_t)nent * h->td * sizeof(float)));
     HIPCK(hipMalloc(&h->tvals, (size_t)nent * sizeof(float)));
@@ -394,6 +409,7 @@ struct RunCtx {
     const int* step_ptr; // or null
     const int* ts;       // or null
     bool train;          // save h1/h2 for the backward pass
+    bool cond_pre;       // condition embeddings precomputed for this call (dsg_sample)
 };
 
 size_t cap_tiles_of(const dsg_handle* h) { return (size_t)cdiv(h->cap_rows, 32) * 2; }
@@ -427,6 +443,7 @@ void fill_block_args(const dsg_handle* h, const Op& op, const RunCtx& c, BlockAr
     const Seg o = seg_of(h, op.out);
     a.out = const_cast<float*>(o.data); a.out_stats = const_cast<float*>(o.stats);
     if (c.train) { a.save_h1 = trp(h, r.h1); a.save_h2 = trp(h, r.h2); }
+    if (c.cond_pre) a.cond_pre = h->cembed + r.ce_off * (cap_tiles_of(h) / 2);
     a.ntiles = tpp * c.npass; a.tiles_per_pass = tpp; a.uncond_tiles = c.uncond_tiles; a.nrows = c.nrows;
 }
 
@@ -463,8 +480,49 @@ void launch_op(const dsg_handle* h, const Op& op, const RunCtx& c, hipStream_t s
     }
 }
 
+bool fusable(const dsg_handle* h, const Op& op) {
+    if (op.kind == OP_RES) return h->res[op.p].N <= 32;
+    if (op.kind == OP_LIN) return h->lin[op.p].l.N <= 64;
+    return false;
+}
+
+// Upload the operator descriptors of the fused narrow run for this context (stream ordered; replayed graphs read them).
+int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
+    const int n = h->fuse_hi - h->fuse_lo;
+    if (n < 2 || c.train) return 0;
+    HIPCK(hipStreamSynchronize(s));  // fused_host may still be the source of an earlier async copy
+    h->fused_host.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const Op& op = h->ops[h->fuse_lo + i];
+        FusedOp& f = h->fused_host[i];
+        memset(&f, 0, sizeof f);
+        if (op.kind == OP_RES) {
+            f.kind = 0; f.N = h->res[op.p].N; f.sclin = h->res[op.p].sclin;
+            fill_block_args(h, op, c, f.b);
+        } else {
+            f.kind = 1; f.N = h->lin[op.p].l.N;
+            fill_lin_args(h, op, c, f.l);
+        }
+    }
+    HIPCK(hipMemcpyAsync(h->fused_dev, h->fused_host.data(), n * sizeof(FusedOp), hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+void launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
+    const int ntiles = cdiv(c.nrows, 32) * c.npass;
+    hipLaunchKernelGGL(k_fused_narrow, dim3(cdiv(ntiles, kWavesPerBlock)), dim3(256), 0, s, h->fused_dev, h->fuse_hi - h->fuse_lo, ntiles);
+}
+
 void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
-    for (const Op& op : h->ops) launch_op(h, op, c, s);
+    const bool fuse = !c.train && h->fuse_hi - h->fuse_lo >= 2;
+    for (int i = 0; i < (int)h->ops.size(); ++i) {
+        if (fuse && i == h->fuse_lo) {
+            launch_fused(h, c, s);
+            i = h->fuse_hi - 1;
+            continue;
+        }
+        launch_op(h, h->ops[i], c, s);
+    }
 }
 
 // time path for `entries` t values already in h->tvals (saves for the backward when `train`)
@@ -720,7 +778,17 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
     for (const ResP& r : h->res)
         if ((r.in1 && r.in1 != r.in0) || (r.sclin != (r.in1 != 0))) { fail("internal: unexpected block shape"); delete h; return nullptr; }
     carve(h);
-    bool ok = hipMalloc(&h->arena, h->arena_floats * sizeof(float)) == hipSuccess &&
+    {   // longest consecutive run of narrow operators
+        int best_lo = 0, best_hi = 0, lo = -1;
+        for (int i = 0; i <= (int)h->ops.size(); ++i) {
+            const bool f = i < (int)h->ops.size() && fusable(h, h->ops[i]);
+            if (f && lo < 0) lo = i;
+            if (!f && lo >= 0) { if (i - lo > best_hi - best_lo) { best_lo = lo; best_hi = i; } lo = -1; }
+        }
+        h->fuse_lo = best_lo; h->fuse_hi = best_hi;
+    }
+    bool ok = hipMalloc(&h->fused_dev, (h->ops.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
+              hipMalloc(&h->arena, h->arena_floats * sizeof(float)) == hipSuccess &&
               hipMemset(h->arena, 0, h->arena_floats * sizeof(float)) == hipSuccess &&
               hipMalloc(&h->tdesc_dev, h->res.size() * sizeof(TimeBlockDesc)) == hipSuccess &&
               hipMalloc(&h->freq, (d.proj_dim / 2) * sizeof(float)) == hipSuccess &&
@@ -744,7 +812,7 @@ void dsg_destroy(dsg_handle* h) {
     if (!h) return;
     (void)hipDeviceSynchronize();
     free_workspace(h);
-    void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev};
+    void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -852,7 +920,8 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
     const int tpp = cdiv(B, 32), CG = groups_of(h->d.cond_dim);
     hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tpp * CG * 256, 256)), dim3(256), 0, s, cond, cond_mask, B, h->d.cond_dim, CG,
                        h->condfrag, tpp);
-    RunCtx c{B, 1, 0, x, out, nullptr, h->ts_ident, false};
+    RunCtx c{B, 1, 0, x, out, nullptr, h->ts_ident, false, false};
+    if (prepare_fused(h, c, s)) return 1;
     run_unet(h, c, s);
     HIPCK(hipGetLastError());
     return 0;
@@ -861,9 +930,12 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
 static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, bool renorm, hipStream_t s,
                         hipEvent_t* ev = nullptr) {
     if (ev) {  // DSG_SAMPLE_PROFILE: one event pair per operator launch
+        const bool fuse = h->fuse_hi - h->fuse_lo >= 2;
         for (size_t i = 0; i < h->ops.size(); ++i) {
             HIPCK(hipEventRecord(ev[2 * i], s));
-            launch_op(h, h->ops[i], c, s);
+            // the fused narrow run is one launch: its time is booked on its first operator, the others read ~0
+            if (fuse && (int)i == h->fuse_lo) launch_fused(h, c, s);
+            else if (!(fuse && (int)i > h->fuse_lo && (int)i < h->fuse_hi)) launch_op(h, h->ops[i], c, s);
             HIPCK(hipEventRecord(ev[2 * i + 1], s));
         }
     } else {
@@ -905,6 +977,17 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
     run_time_path(h, T, s);
     hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tpp * CG * 256, 256)), dim3(256), 0, s, cond, (const float*)nullptr, B,
                        h->d.cond_dim, CG, h->condfrag, tpp);
+    // condition embeddings of every block, once per call: cond is the same in all T steps (MSR.py:126-127)
+    for (const ResP& r : h->res) {
+        LinArgs a;
+        memset(&a, 0, sizeof a);
+        a.in.data = h->condfrag; a.in.groups = CG; a.in.width = h->d.cond_dim;
+        a.in_width = h->d.cond_dim; a.in_groups = CG;
+        a.W = h->arena + r.Wcp; a.bias = h->arena + h->zero_off;
+        a.out = h->cembed + r.ce_off * (cap_tiles_of(h) / 2); a.out_stats = h->ce_stats; a.out_width = r.N;
+        a.ntiles = tpp; a.tiles_per_pass = tpp; a.nrows = B;
+        launch_lin(r.N, IN_FRAG, OUT_FRAG, false, a, s);
+    }
     if (y_T) HIPCK(hipMemcpyAsync(h->ywork, y_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     else hipLaunchKernelGGL(k_randn, dim3(2048), dim3(256), 0, s, h->ywork, n, seed, 0xFFFFFFFFu);
     const int start = T - 1;
@@ -913,7 +996,8 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
     HIPCK(hipMemcpyAsync(h->call_dev, &cp, sizeof cp, hipMemcpyHostToDevice, s));
     HIPCK(hipStreamSynchronize(s));  // `start` and `cp` are host temporaries
 
-    RunCtx c{B, 2, tpp, h->ywork, h->eps, h->step_dev, nullptr, false};
+    RunCtx c{B, 2, tpp, h->ywork, h->eps, h->step_dev, nullptr, false, true};
+    if (prepare_fused(h, c, s)) return 1;
     UpdateArgs u;
     u.eps = h->eps; u.y = h->ywork; u.cp = h->call_dev; u.step_ptr = h->step_dev; u.n = n;
 
@@ -978,7 +1062,7 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tiles * CG * 256, 256)), dim3(256), 0, s, cond, cond_mask, B, C, CG, h->condfrag, tiles);
     hipLaunchKernelGGL(k_qsample, dim3(cdiv(tiles * DG * 256, 256)), dim3(256), 0, s, y, noise, h->tr_ts, sqrt_acp, sqrt_1m_acp, B, D,
                        h->tr_yt_rm, trp(h, h->tr_yt_frag), tiles);
-    RunCtx c{B, 1, 0, h->tr_yt_rm, h->eps, nullptr, h->tr_ts, true};
+    RunCtx c{B, 1, 0, h->tr_yt_rm, h->eps, nullptr, h->tr_ts, true, false};
     run_unet(h, c, s);
     hipLaunchKernelGGL(k_loss_grad, dim3(kRedBlocks), dim3(256), 0, s, h->eps, noise, B, D, trp(h, h->tr_deps), tiles, h->red);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, s, h->red, kRedBlocks, (double)B * (double)D, loss_out);
@@ -1074,6 +1158,14 @@ int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_deca
 
 int dsg_op_count(const dsg_handle* h) { return h ? (int)h->ops.size() : 0; }
 
+int dsg_fused_range(const dsg_handle* h, int* lo, int* hi) {
+    if (!h) return fail("null handle");
+    const bool on = h->fuse_hi - h->fuse_lo >= 2;
+    if (lo) *lo = on ? h->fuse_lo : 0;
+    if (hi) *hi = on ? h->fuse_hi : 0;
+    return 0;
+}
+
 int dsg_op_profile(const dsg_handle* h, int op, double* ms_total, int* calls) {
     if (!h || op < 0 || op >= (int)h->op_ms.size()) return fail("dsg_op_profile: no profile for op %d (run dsg_sample with DSG_SAMPLE_PROFILE)", op);
     if (ms_total) *ms_total = h->op_ms[op];
@@ -1097,7 +1189,8 @@ int dsg_op_info(const dsg_handle* h, int op, char* name, double* flops_per_row, 
         bytes = 2.0 * 4.0 * (l.l.K + l.l.N);
     }
     if (name) { strncpy(name, o.name.c_str(), 63); name[63] = 0; }
-    if (flops_per_row) *flops_per_row = 2.0 * (2.0 * macs2 + macs_cond);
+    (void)macs_cond;  // hoisted out of the step: the condition embeddings are computed once per dsg_sample call
+    if (flops_per_row) *flops_per_row = 2.0 * (2.0 * macs2);
     if (bytes_per_row) *bytes_per_row = bytes;
     return 0;
 }
@@ -1109,7 +1202,7 @@ int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* st
     hipStream_t s = (hipStream_t)stream;
     const int zero = 0;
     HIPCK(hipMemcpyAsync(h->step_dev, &zero, sizeof(int), hipMemcpyHostToDevice, s));
-    RunCtx c{B, 2, cdiv(B, 32), h->ywork, h->eps, h->step_dev, nullptr, false};
+    RunCtx c{B, 2, cdiv(B, 32), h->ywork, h->eps, h->step_dev, nullptr, false, true};
     hipEvent_t e0, e1;
     HIPCK(hipEventCreate(&e0));
     HIPCK(hipEventCreate(&e1));

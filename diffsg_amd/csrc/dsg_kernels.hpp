@@ -34,24 +34,75 @@ constexpr float kLnEps = 1e-5f;    // nn.LayerNorm default (UNetCF.py:60)
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// Swish, UNetCF.py:14: x * sigmoid(x)
-__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+// Swish, UNetCF.py:14: x * sigmoid(x).  exp(-v) = 2^(-v log2 e) on v_exp_f32 (1 ulp) with the rounding error of the
+// product and the low part of log2 e folded back in (2^(t+e) ~ 2^t (1 + e ln 2)), so the result stays within ~2 ulp of
+// expf() at a third of its VALU cost; a bare v_exp_f32(-v*log2e) is |v|*6e-8 off, which at omega = 500 tripled the
+// end-to-end deviation from the float64 trajectory.
+__device__ __forceinline__ float fast_exp_neg(float v) {
+    constexpr float c_hi = -1.44269504088896341f, c_lo = -1.925963033500671e-08f;  // -log2(e) split
+    const float t = v * c_hi;
+    const float e = fmaf(v, c_lo, fmaf(v, c_hi, -t));
+    const float p = __builtin_amdgcn_exp2f(t);
+    return fmaf(p * e, 0.693147180559945f, p);
+}
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + fast_exp_neg(v)); }
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
 
 #define DSG_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
 
-// One k-group (4 k-steps) into NT output tiles.  wbase points at packed[(nt*KG + g)*256 + lane*4].
+// Weight fragments of one k-group for NT output tiles: wp points at packed[(0*KG + g)*256 + lane*4].
+// Loads are issued one k-group AHEAD of the MFMAs that consume them (software prefetch): hipcc otherwise emits
+// load -> s_waitcnt vmcnt(0) -> 4 MFMAs per tile, exposing a full L2 round trip every 256 MFMA cycles.
 template <int NT>
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[NT], const float* __restrict__ wp, size_t nt_stride,
-                                           float b0, float b1, float b2, float b3) {
+__device__ __forceinline__ void load_wfrag(float4 (&w)[NT], const float* __restrict__ wp, size_t nt_stride) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) w[nt] = ld4(wp + nt * nt_stride);
+}
+
+// One k-group (4 k-steps) into NT output tiles from preloaded fragments.
+template <int NT>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[NT], const float4 (&w)[NT], float b0, float b1, float b2, float b3) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const float4 w = ld4(wp + nt * nt_stride);
-        DSG_MFMA(acc[nt], w.x, b0);
-        DSG_MFMA(acc[nt], w.y, b1);
-        DSG_MFMA(acc[nt], w.z, b2);
-        DSG_MFMA(acc[nt], w.w, b3);
+        DSG_MFMA(acc[nt], w[nt].x, b0);
+        DSG_MFMA(acc[nt], w[nt].y, b1);
+        DSG_MFMA(acc[nt], w[nt].z, b2);
+        DSG_MFMA(acc[nt], w[nt].w, b3);
+    }
+}
+
+__device__ __forceinline__ float4 ln_silu4(float4 x, float mean, float rstd, float4 gm, float4 bt) {
+    return make_float4(silu(fmaf((x.x - mean) * rstd, gm.x, bt.x)), silu(fmaf((x.y - mean) * rstd, gm.y, bt.y)),
+                       silu(fmaf((x.z - mean) * rstd, gm.z, bt.z)), silu(fmaf((x.w - mean) * rstd, gm.w, bt.w)));
+}
+
+// Stream `groups` k-groups of a fragment tensor from memory into the chain (runtime loop, prefetch distance 1).
+//   xp     tile base of the tensor + lane*4 (group stride 256)
+//   wp     packed weights of the first of these groups + lane*4 (group stride 256, tile stride nt_stride)
+//   gamma  LayerNorm parameters of the first group + 4h (LNACT), group stride 8
+template <int NT, bool LNACT>
+__device__ __forceinline__ void chain_from_mem(f32x16 (&acc)[NT], const float* __restrict__ xp, int groups, const float* __restrict__ wp,
+                                               size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               float mean, float rstd) {
+    if (groups <= 0) return;
+    float4 wn[NT], xn, gmn = make_float4(0.f, 0.f, 0.f, 0.f), btn = gmn;
+    load_wfrag<NT>(wn, wp, nt_stride);
+    xn = ld4(xp);
+    if (LNACT) { gmn = ld4(gamma); btn = ld4(beta); }
+    for (int g = 0; g < groups; ++g) {
+        float4 wc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
+        float4 xv = xn;
+        const float4 gm = gmn, bt = btn;
+        if (g + 1 < groups) {
+            load_wfrag<NT>(wn, wp + (size_t)(g + 1) * 256, nt_stride);
+            xn = ld4(xp + (size_t)(g + 1) * 256);
+            if (LNACT) { gmn = ld4(gamma + 8 * (g + 1)); btn = ld4(beta + 8 * (g + 1)); }
+        }
+        if (LNACT) xv = ln_silu4(xv, mean, rstd, gm, bt);
+        mfma_group<NT>(acc, wc, xv.x, xv.y, xv.z, xv.w);
     }
 }
 
@@ -109,15 +160,24 @@ __device__ __forceinline__ void chain_from_acc(f32x16 (&out)[NT], const f32x16 (
                                                float mean, float rstd, int lane, int h) {
     constexpr int NG = (N + 7) / 8;
     const size_t nt_stride = (size_t)NG * 256;
+    float4 wn[NT], gmn, btn;
+    load_wfrag<NT>(wn, wp + lane * 4, nt_stride);
+    gmn = ld4(gamma + 4 * h);
+    btn = ld4(beta + 4 * h);
 #pragma unroll
     for (int G = 0; G < NG; ++G) {
-        const float4 gm = ld4(gamma + 8 * G + 4 * h);
-        const float4 bt = ld4(beta + 8 * G + 4 * h);
-        const float b0 = silu(fmaf((in[G >> 2][4 * (G & 3) + 0] - mean) * rstd, gm.x, bt.x));
-        const float b1 = silu(fmaf((in[G >> 2][4 * (G & 3) + 1] - mean) * rstd, gm.y, bt.y));
-        const float b2 = silu(fmaf((in[G >> 2][4 * (G & 3) + 2] - mean) * rstd, gm.z, bt.z));
-        const float b3 = silu(fmaf((in[G >> 2][4 * (G & 3) + 3] - mean) * rstd, gm.w, bt.w));
-        mfma_group<NT>(out, wp + (size_t)G * 256 + lane * 4, nt_stride, b0, b1, b2, b3);
+        float4 wc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
+        const float4 gm = gmn, bt = btn;
+        if (G + 1 < NG) {
+            load_wfrag<NT>(wn, wp + (size_t)(G + 1) * 256 + lane * 4, nt_stride);
+            gmn = ld4(gamma + 8 * (G + 1) + 4 * h);
+            btn = ld4(beta + 8 * (G + 1) + 4 * h);
+        }
+        const float4 b = ln_silu4(make_float4(in[G >> 2][4 * (G & 3) + 0], in[G >> 2][4 * (G & 3) + 1], in[G >> 2][4 * (G & 3) + 2],
+                                              in[G >> 2][4 * (G & 3) + 3]), mean, rstd, gm, bt);
+        mfma_group<NT>(out, wc, b.x, b.y, b.z, b.w);
     }
 }
 
@@ -152,6 +212,8 @@ struct BlockArgs {
     const float* Wc;      // packed [NT][CG][256]
     const float* condfrag;  // [tiles_per_pass][CG][64][4] = silu(cond * mask)
     int cond_groups;
+    const float* cond_pre;  // sampling: Wc silu(cond) of THIS block, precomputed once per call [tiles_per_pass][NG][64][4]
+                            // (cond does not change over the T steps), or null -> run the GEMM here
     const float* W3;
     const float* gamma3;
     const float* beta3;
@@ -168,11 +230,8 @@ struct BlockArgs {
 };
 
 template <int N, bool SCLIN>
-__global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {
+__device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile, const int lane) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (tile >= a.ntiles) return;
     const int h = lane >> 5, j = lane & 31;
     const int ptile = tile % a.tiles_per_pass;
     const int KG = a.in0.groups + a.in1.groups;
@@ -209,25 +268,12 @@ __global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {
     }
     {
         const size_t nt_stride = (size_t)KG * 256;
-        const float* xp = a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4;
-        for (int g = 0; g < a.in0.groups; ++g) {
-            const float4 xv = ld4(xp + (size_t)g * 256);
-            const float4 gm = ld4(a.gamma1 + 8 * g + 4 * h), bt = ld4(a.beta1 + 8 * g + 4 * h);
-            mfma_group<NT>(acc1, a.W1 + (size_t)g * 256 + lane * 4, nt_stride,
-                           silu(fmaf((xv.x - mean1) * rstd1, gm.x, bt.x)), silu(fmaf((xv.y - mean1) * rstd1, gm.y, bt.y)),
-                           silu(fmaf((xv.z - mean1) * rstd1, gm.z, bt.z)), silu(fmaf((xv.w - mean1) * rstd1, gm.w, bt.w)));
-        }
-        if (a.in1.groups) {
-            const float* sp = a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4;
-            for (int g = 0; g < a.in1.groups; ++g) {
-                const int gg = a.in0.groups + g;
-                const float4 xv = ld4(sp + (size_t)g * 256);
-                const float4 gm = ld4(a.gamma1 + 8 * gg + 4 * h), bt = ld4(a.beta1 + 8 * gg + 4 * h);
-                mfma_group<NT>(acc1, a.W1 + (size_t)gg * 256 + lane * 4, nt_stride,
-                               silu(fmaf((xv.x - mean1) * rstd1, gm.x, bt.x)), silu(fmaf((xv.y - mean1) * rstd1, gm.y, bt.y)),
-                               silu(fmaf((xv.z - mean1) * rstd1, gm.z, bt.z)), silu(fmaf((xv.w - mean1) * rstd1, gm.w, bt.w)));
-            }
-        }
+        chain_from_mem<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, a.W1 + lane * 4, nt_stride,
+                                 a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
+        if (a.in1.groups)
+            chain_from_mem<NT, true>(acc1, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
+                                     a.W1 + (size_t)a.in0.groups * 256 + lane * 4, nt_stride, a.gamma1 + 8 * a.in0.groups + 4 * h,
+                                     a.beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1);
     }
     if (a.save_h1) {
 #pragma unroll
@@ -247,11 +293,17 @@ __global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {
         chain_from_acc<N, NT>(acc2, acc1, a.W2, a.gamma2, a.beta2, mean, rstd, lane, h);
     }
     if (tile >= a.uncond_tiles) {
-        const size_t nt_stride = (size_t)a.cond_groups * 256;
-        const float* cp = a.condfrag + (size_t)ptile * a.cond_groups * 256 + lane * 4;
-        for (int g = 0; g < a.cond_groups; ++g) {
-            const float4 cv = ld4(cp + (size_t)g * 256);
-            mfma_group<NT>(acc2, a.Wc + (size_t)g * 256 + lane * 4, nt_stride, cv.x, cv.y, cv.z, cv.w);
+        if (a.cond_pre) {
+            const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
+#pragma unroll
+            for (int G = 0; G < NG; ++G) {
+                const float4 cv = ld4(cp + (size_t)G * 256);
+                acc2[G >> 2][4 * (G & 3) + 0] += cv.x; acc2[G >> 2][4 * (G & 3) + 1] += cv.y;
+                acc2[G >> 2][4 * (G & 3) + 2] += cv.z; acc2[G >> 2][4 * (G & 3) + 3] += cv.w;
+            }
+        } else {
+            chain_from_mem<NT, false>(acc2, a.condfrag + (size_t)ptile * a.cond_groups * 256 + lane * 4, a.cond_groups, a.Wc + lane * 4,
+                                      (size_t)a.cond_groups * 256, nullptr, nullptr, 0.f, 1.f);
         }
     }
     if (a.save_h2) {
@@ -273,18 +325,11 @@ __global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {
     }
     if (SCLIN) {
         const size_t nt_stride = (size_t)KG * 256;
-        const float* xp = a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4;
-        for (int g = 0; g < a.in0.groups; ++g) {
-            const float4 xv = ld4(xp + (size_t)g * 256);
-            mfma_group<NT>(acc3, a.Wsc + (size_t)g * 256 + lane * 4, nt_stride, xv.x, xv.y, xv.z, xv.w);
-        }
-        if (a.in1.groups) {
-            const float* sp = a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4;
-            for (int g = 0; g < a.in1.groups; ++g) {
-                const float4 xv = ld4(sp + (size_t)g * 256);
-                mfma_group<NT>(acc3, a.Wsc + (size_t)(a.in0.groups + g) * 256 + lane * 4, nt_stride, xv.x, xv.y, xv.z, xv.w);
-            }
-        }
+        chain_from_mem<NT, false>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, a.Wsc + lane * 4, nt_stride,
+                                  nullptr, nullptr, 0.f, 1.f);
+        if (a.in1.groups)
+            chain_from_mem<NT, false>(acc3, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
+                                      a.Wsc + (size_t)a.in0.groups * 256 + lane * 4, nt_stride, nullptr, nullptr, 0.f, 1.f);
     } else {
         const float* xp = a.in0.data + (size_t)tile * NG * 256 + lane * 4;
 #pragma unroll
@@ -306,6 +351,14 @@ __global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {
                 make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2],
                             acc3[G >> 2][4 * (G & 3) + 3]));
     }
+}
+
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    resblock_body<N, SCLIN>(a, tile, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,10 +387,7 @@ enum { IN_FRAG = 0, IN_ROWMAJOR = 1 };
 enum { OUT_FRAG = 0, OUT_ROWMAJOR = 1 };
 
 template <int NT, int INMODE, int OUTMODE, bool LNACT>
-__global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (tile >= a.ntiles) return;
+__device__ __forceinline__ void linear_body(const LinArgs& a, const int tile, const int lane) {
     const int h = lane >> 5, j = lane & 31;
     const int ptile = tile % a.tiles_per_pass;
     const int pass = tile / a.tiles_per_pass;
@@ -354,25 +404,21 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
         mean = s.x;
         rstd = rsqrtf(s.y / (float)a.in.width + kLnEps);
     }
-    for (int g = 0; g < KG; ++g) {
-        float4 xv;
-        if (INMODE == IN_FRAG) {
-            xv = ld4(a.in.data + ((size_t)tile * KG + g) * 256 + lane * 4);
-        } else {
+    if (INMODE == IN_FRAG) {
+        chain_from_mem<NT, LNACT>(acc, a.in.data + (size_t)tile * KG * 256 + lane * 4, KG, a.W + lane * 4, nt_stride,
+                                  LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
+    } else {
+        for (int g = 0; g < KG; ++g) {
+            float4 wc[NT];
+            load_wfrag<NT>(wc, a.W + (size_t)g * 256 + lane * 4, nt_stride);
             float v[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int f = 8 * g + 4 * h + p;
                 v[p] = (row < a.nrows && f < a.in_width) ? a.in_rm[(size_t)row * a.in_width + f] : 0.f;
             }
-            xv = make_float4(v[0], v[1], v[2], v[3]);
+            mfma_group<NT>(acc, wc, v[0], v[1], v[2], v[3]);
         }
-        if (LNACT) {
-            const float4 gm = ld4(a.gamma + 8 * g + 4 * h), bt = ld4(a.beta + 8 * g + 4 * h);
-            xv.x = silu(fmaf((xv.x - mean) * rstd, gm.x, bt.x)); xv.y = silu(fmaf((xv.y - mean) * rstd, gm.y, bt.y));
-            xv.z = silu(fmaf((xv.z - mean) * rstd, gm.z, bt.z)); xv.w = silu(fmaf((xv.w - mean) * rstd, gm.w, bt.w));
-        }
-        mfma_group<NT>(acc, a.W + (size_t)g * 256 + lane * 4, nt_stride, xv.x, xv.y, xv.z, xv.w);
     }
 
     if (OUTMODE == OUT_FRAG) {
@@ -413,6 +459,61 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
                     if (f < a.out_width) o[f] = acc[G >> 2][4 * (G & 3) + p];
                 }
         }
+    }
+}
+
+template <int NT, int INMODE, int OUTMODE, bool LNACT>
+__global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    linear_body<NT, INMODE, OUTMODE, LNACT>(a, tile, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The narrow middle of the U-Net (every module whose output is <= 64 wide and whose blocks are <= 32 wide) as ONE
+// launch: a wave walks its tile through the whole run of operators.  Tensors still round-trip through their
+// fragment buffers (the wave re-reads what it wrote itself: tile-local, L2-hot), so this removes ~25 dependent
+// kernel boundaries and their fill/drain per reverse step, not the arithmetic.  Inference only.
+// ---------------------------------------------------------------------------------------------
+struct FusedOp {
+    int kind;     // 0: ResidualBlock, 1: Linear
+    int N;        // block width / Linear out width
+    int sclin;
+    int pad;
+    BlockArgs b;
+    LinArgs l;
+};
+
+__global__ __launch_bounds__(256) void k_fused_narrow(const FusedOp* __restrict__ ops, int nops, int ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    for (int i = 0; i < nops; ++i) {
+        const FusedOp& op = ops[i];
+        if (op.kind == 0) {
+            if (op.sclin) {
+                switch (op.N) {
+                    case 4: resblock_body<4, true>(op.b, tile, lane); break;
+                    case 8: resblock_body<8, true>(op.b, tile, lane); break;
+                    case 16: resblock_body<16, true>(op.b, tile, lane); break;
+                    default: resblock_body<32, true>(op.b, tile, lane); break;
+                }
+            } else {
+                switch (op.N) {
+                    case 4: resblock_body<4, false>(op.b, tile, lane); break;
+                    case 8: resblock_body<8, false>(op.b, tile, lane); break;
+                    case 16: resblock_body<16, false>(op.b, tile, lane); break;
+                    default: resblock_body<32, false>(op.b, tile, lane); break;
+                }
+            }
+        } else if (op.N <= 32) {
+            linear_body<1, IN_FRAG, OUT_FRAG, false>(op.l, tile, lane);
+        } else {
+            linear_body<2, IN_FRAG, OUT_FRAG, false>(op.l, tile, lane);
+        }
+        // the next operator of THIS wave reads what it just stored (same tile): drain the stores first
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 

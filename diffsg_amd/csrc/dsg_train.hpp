@@ -81,7 +81,7 @@ __global__ void k_loss_final(const double* __restrict__ part, int nparts, double
 // Row reductions run over the true width n_true; padded features are forced to zero.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float silu_grad(float u) {
-    const float sg = __builtin_amdgcn_rcpf(1.0f + expf(-u));
+    const float sg = __builtin_amdgcn_rcpf(1.0f + fast_exp_neg(u));
     return sg * fmaf(u, 1.0f - sg, 1.0f);
 }
 
@@ -162,10 +162,17 @@ template <int NGin, int NTin, int NTout>
 __device__ __forceinline__ void chain_raw_from_acc(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], const float* __restrict__ wp,
                                                    int lane) {
     const size_t nt_stride = (size_t)NGin * 256;
+    float4 wn[NTout];
+    load_wfrag<NTout>(wn, wp + lane * 4, nt_stride);
 #pragma unroll
-    for (int G = 0; G < NGin; ++G)
-        mfma_group<NTout>(out, wp + (size_t)G * 256 + lane * 4, nt_stride, in[G >> 2][4 * (G & 3) + 0], in[G >> 2][4 * (G & 3) + 1],
-                          in[G >> 2][4 * (G & 3) + 2], in[G >> 2][4 * (G & 3) + 3]);
+    for (int G = 0; G < NGin; ++G) {
+        float4 wc[NTout];
+#pragma unroll
+        for (int nt = 0; nt < NTout; ++nt) wc[nt] = wn[nt];
+        if (G + 1 < NGin) load_wfrag<NTout>(wn, wp + (size_t)(G + 1) * 256 + lane * 4, nt_stride);
+        mfma_group<NTout>(out, wc, in[G >> 2][4 * (G & 3) + 0], in[G >> 2][4 * (G & 3) + 1], in[G >> 2][4 * (G & 3) + 2],
+                          in[G >> 2][4 * (G & 3) + 3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -356,13 +363,29 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const LinBwdArgs a) {
     f32x16 dx[OT];
     acc_zero<OT>(dx);
     const size_t nt_stride = (size_t)NGo * 256;
-    for (int g = 0; g < NGo; ++g) {
-        float4 gv = ld4(a.gout_a + ((size_t)tile * NGo + g) * 256 + lane * 4);
-        if (a.gout_b) {
-            const float4 gb = ld4(a.gout_b + ((size_t)tile * NGo + g) * 256 + lane * 4);
-            gv.x += gb.x; gv.y += gb.y; gv.z += gb.z; gv.w += gb.w;
+    {
+        float4 wn[OT], gn;
+        auto load_g = [&](int g) {
+            float4 gv = ld4(a.gout_a + ((size_t)tile * NGo + g) * 256 + lane * 4);
+            if (a.gout_b) {
+                const float4 gb = ld4(a.gout_b + ((size_t)tile * NGo + g) * 256 + lane * 4);
+                gv.x += gb.x; gv.y += gb.y; gv.z += gb.z; gv.w += gb.w;
+            }
+            return gv;
+        };
+        load_wfrag<OT>(wn, a.WT + lane * 4, nt_stride);
+        gn = load_g(0);
+        for (int g = 0; g < NGo; ++g) {
+            float4 wc[OT];
+#pragma unroll
+            for (int nt = 0; nt < OT; ++nt) wc[nt] = wn[nt];
+            const float4 gv = gn;
+            if (g + 1 < NGo) {
+                load_wfrag<OT>(wn, a.WT + (size_t)(g + 1) * 256 + lane * 4, nt_stride);
+                gn = load_g(g + 1);
+            }
+            mfma_group<OT>(dx, wc, gv.x, gv.y, gv.z, gv.w);
         }
-        mfma_group<OT>(dx, a.WT + (size_t)g * 256 + lane * 4, nt_stride, gv.x, gv.y, gv.z, gv.w);
     }
     if (LNBWD) {
         const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)tile * 32 + j];

@@ -84,7 +84,10 @@ int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_deca
 /* Measurement hooks for bench.py: the per-step operator list and a timed replay of one operator's kernel with HIP
  * events on `stream` (rows = B rows, both passes, as inside dsg_sample). */
 int dsg_op_count(const dsg_handle* h);
-/* name: >= 64 bytes.  flops/bytes are ALGORITHMIC per batch row per reverse step (both passes). */
+/* Operators [lo, hi) run as ONE fused launch at inference (the narrow middle of the U-Net); lo == hi if none. */
+int dsg_fused_range(const dsg_handle* h, int* lo, int* hi);
+/* name: >= 64 bytes.  flops/bytes are ALGORITHMIC per batch row per reverse step (both passes; the step-invariant
+ * time path and condition embeddings are computed once per call and are not counted). */
 int dsg_op_info(const dsg_handle* h, int op, char* name, double* flops_per_row, double* bytes_per_row);
 int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* stream);
 /* Summed HIP-event time (ms) and launch count of operator `op` over the last DSG_SAMPLE_PROFILE call. */
