@@ -482,7 +482,7 @@ void launch_op(const dsg_handle* h, const Op& op, const RunCtx& c, hipStream_t s
 
 bool fusable(const dsg_handle* h, const Op& op) {
     if (op.kind == OP_RES) return h->res[op.p].N <= 32;
-    if (op.kind == OP_LIN) return h->lin[op.p].l.N <= 64;
+    if (op.kind == OP_LIN) return h->lin[op.p].l.N <= 32;
     return false;
 }
 

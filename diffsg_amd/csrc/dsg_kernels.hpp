@@ -154,16 +154,36 @@ __device__ __forceinline__ void acc_stats(const f32x16 (&acc)[NT], int h, float&
 
 // B operands for a chain whose input is an accumulator: act = silu(LN(acc)), then MFMA into `out`.
 // ResidualBlock stages 2 and 3 (UNetCF.py:92,94).
+// First-group operands of a register-fed chain, issued by the caller well before the chain starts (narrow blocks are
+// latency-bound: this takes one L2 round trip per stage off the critical path).
+template <int NT>
+struct ChainHead { float4 w[NT]; float4 gm, bt; };
+
+template <int N, int NT>
+__device__ __forceinline__ void chain_head_load(ChainHead<NT>& hd, const float* __restrict__ wp, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, int lane, int h) {
+    constexpr int NG = (N + 7) / 8;
+    load_wfrag<NT>(hd.w, wp + lane * 4, (size_t)NG * 256);
+    hd.gm = ld4(gamma + 4 * h);
+    hd.bt = ld4(beta + 4 * h);
+}
+
 template <int N, int NT>
 __device__ __forceinline__ void chain_from_acc(f32x16 (&out)[NT], const f32x16 (&in)[NT], const float* __restrict__ wp,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                               float mean, float rstd, int lane, int h) {
+                                               float mean, float rstd, int lane, int h, const ChainHead<NT>* head = nullptr) {
     constexpr int NG = (N + 7) / 8;
     const size_t nt_stride = (size_t)NG * 256;
     float4 wn[NT], gmn, btn;
-    load_wfrag<NT>(wn, wp + lane * 4, nt_stride);
-    gmn = ld4(gamma + 4 * h);
-    btn = ld4(beta + 4 * h);
+    if (head) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wn[nt] = head->w[nt];
+        gmn = head->gm; btn = head->bt;
+    } else {
+        load_wfrag<NT>(wn, wp + lane * 4, nt_stride);
+        gmn = ld4(gamma + 4 * h);
+        btn = ld4(beta + 4 * h);
+    }
 #pragma unroll
     for (int G = 0; G < NG; ++G) {
         float4 wc[NT];
@@ -253,6 +273,14 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
         rstd1 = rsqrtf(m2 / n + kLnEps);
     }
 
+    // narrow blocks: issue the first operands of stages 2 and 3 now
+    constexpr bool EARLY = NT == 1;
+    ChainHead<NT> head2, head3;
+    if (EARLY) {
+        chain_head_load<N, NT>(head2, a.W2, a.gamma2, a.beta2, lane, h);
+        chain_head_load<N, NT>(head3, a.W3, a.gamma3, a.beta3, lane, h);
+    }
+
     // ---- stage 1
     f32x16 acc1[NT];
     {
@@ -290,7 +318,7 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
         acc_stats<N, NT>(acc1, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
         acc_init<NT>(acc2, a.c2, h);
-        chain_from_acc<N, NT>(acc2, acc1, a.W2, a.gamma2, a.beta2, mean, rstd, lane, h);
+        chain_from_acc<N, NT>(acc2, acc1, a.W2, a.gamma2, a.beta2, mean, rstd, lane, h, EARLY ? &head2 : nullptr);
     }
     if (tile >= a.uncond_tiles) {
         if (a.cond_pre) {
@@ -321,7 +349,7 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
         acc_stats<N, NT>(acc2, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
         acc_init<NT>(acc3, a.c3, h);
-        chain_from_acc<N, NT>(acc3, acc2, a.W3, a.gamma3, a.beta3, mean, rstd, lane, h);
+        chain_from_acc<N, NT>(acc3, acc2, a.W3, a.gamma3, a.beta3, mean, rstd, lane, h, EARLY ? &head3 : nullptr);
     }
     if (SCLIN) {
         const size_t nt_stride = (size_t)KG * 256;
@@ -471,7 +499,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The narrow middle of the U-Net (every module whose output is <= 64 wide and whose blocks are <= 32 wide) as ONE
+// The narrow middle of the U-Net (the longest run of modules whose outputs are <= 32 wide) as ONE
 // launch: a wave walks its tile through the whole run of operators.  Tensors still round-trip through their
 // fragment buffers (the wave re-reads what it wrote itself: tile-local, L2-hot), so this removes ~25 dependent
 // kernel boundaries and their fill/drain per reverse step, not the arithmetic.  Inference only.
@@ -485,7 +513,7 @@ struct FusedOp {
     LinArgs l;
 };
 
-__global__ __launch_bounds__(256) void k_fused_narrow(const FusedOp* __restrict__ ops, int nops, int ntiles) {
+__global__ __launch_bounds__(256, 4) void k_fused_narrow(const FusedOp* __restrict__ ops, int nops, int ntiles) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
@@ -507,10 +535,8 @@ __global__ __launch_bounds__(256) void k_fused_narrow(const FusedOp* __restrict_
                     default: resblock_body<32, false>(op.b, tile, lane); break;
                 }
             }
-        } else if (op.N <= 32) {
-            linear_body<1, IN_FRAG, OUT_FRAG, false>(op.l, tile, lane);
         } else {
-            linear_body<2, IN_FRAG, OUT_FRAG, false>(op.l, tile, lane);
+            linear_body<1, IN_FRAG, OUT_FRAG, false>(op.l, tile, lane);
         }
         // the next operator of THIS wave reads what it just stored (same tile): drain the stores first
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
