@@ -101,6 +101,7 @@ __device__ __forceinline__ void chain_from_mem(f32x16 (&acc)[NT], const float* _
             xn = ld4(xp + (size_t)(g + 1) * 256);
             if (LNACT) { gmn = ld4(gamma + 8 * (g + 1)); btn = ld4(beta + 8 * (g + 1)); }
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs (hipcc otherwise sinks it)
         if (LNACT) xv = ln_silu4(xv, mean, rstd, gm, bt);
         mfma_group<NT>(acc, wc, xv.x, xv.y, xv.z, xv.w);
     }
@@ -195,6 +196,7 @@ __device__ __forceinline__ void chain_from_acc(f32x16 (&out)[NT], const f32x16 (
             gmn = ld4(gamma + 8 * (G + 1) + 4 * h);
             btn = ld4(beta + 8 * (G + 1) + 4 * h);
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs
         const float4 b = ln_silu4(make_float4(in[G >> 2][4 * (G & 3) + 0], in[G >> 2][4 * (G & 3) + 1], in[G >> 2][4 * (G & 3) + 2],
                                               in[G >> 2][4 * (G & 3) + 3]), mean, rstd, gm, bt);
         mfma_group<NT>(out, wc, b.x, b.y, b.z, b.w);

@@ -170,6 +170,7 @@ __device__ __forceinline__ void chain_raw_from_acc(f32x16 (&out)[NTout], const f
 #pragma unroll
         for (int nt = 0; nt < NTout; ++nt) wc[nt] = wn[nt];
         if (G + 1 < NGin) load_wfrag<NTout>(wn, wp + (size_t)(G + 1) * 256 + lane * 4, nt_stride);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_group<NTout>(out, wc, in[G >> 2][4 * (G & 3) + 0], in[G >> 2][4 * (G & 3) + 1], in[G >> 2][4 * (G & 3) + 2],
                           in[G >> 2][4 * (G & 3) + 3]);
     }
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const LinBwdArgs a) {
                 load_wfrag<OT>(wn, a.WT + (size_t)(g + 1) * 256 + lane * 4, nt_stride);
                 gn = load_g(g + 1);
             }
+            __builtin_amdgcn_sched_barrier(0);
             mfma_group<OT>(dx, wc, gv.x, gv.y, gv.z, gv.w);
         }
     }
