@@ -193,6 +193,12 @@ class UNet1D(nn.Module):
             nat.bound_key = key
         return nat.handle
 
+    def set_precision(self, mode):
+        """Arithmetic of the >= 64-wide blocks inside DDPM.sample: "split_f16" (default; float32-accurate hi/lo fp16
+        split on the f16 matrix cores, f32 accumulate) or "f32" (exact v_mfma_f32_32x32x2_f32)."""
+        code = {"split_f16": 0, "f32": 1}[mode]
+        _lib.check(_lib.lib().dsg_set_precision(self.native_handle(), code))
+
     def forward(self, x, t, cond, cond_mask):
         """
         :param x: (batch_size, input_dim)

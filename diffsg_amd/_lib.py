@@ -13,7 +13,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiffsg_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "dsg_api.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "dsg_kernels.hpp"), os.path.join(_HERE, "csrc", "dsg_train.hpp"),
+HEADERS = [os.path.join(_HERE, "csrc", "dsg_kernels.hpp"), os.path.join(_HERE, "csrc", "dsg_train.hpp"), os.path.join(_HERE, "csrc", "dsg_split.hpp"),
            os.path.join(os.path.dirname(_HERE), "include", "diffsg.h")]
 
 MAX_RES = 8
@@ -53,6 +53,7 @@ _SIGS = {
     "dsg_train_step": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_void_p]),
     "dsg_bind_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
+    "dsg_set_precision": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "dsg_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "dsg_unet_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
     "dsg_sample": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong,

@@ -3,6 +3,7 @@
 // C ABI: include/diffsg.h.
 #include "dsg_kernels.hpp"
 #include "dsg_train.hpp"
+#include "dsg_split.hpp"
 #include "../../include/diffsg.h"
 
 #include <math.h>
@@ -62,6 +63,8 @@ struct ResP {              // ResidualBlock (UNetCF.py:49-95)
     // packed (arena offsets, floats)
     size_t W1p, g1p, b1p, W2p, g2p, b2p, c2p, Wcp, W3p, g3p, b3p, c3p, Wscp;
     size_t W1T, W2T, W3T, WscT;  // transposed packs (data gradients)
+    size_t W1h = 0, W2h = 0, W3h = 0, Wsch = 0;  // fp16-split planes (blocks >= 64 wide, sampling)
+    bool split = false;
     // training workspace (per-tile float offsets)
     size_t h1, h2, du1, du2, du3, dh1, dh2, rs1, rs2, rs3;
     long long dtb_off;     // slab scratch: dTB_b [N][T]
@@ -115,6 +118,13 @@ struct dsg_handle {
     long long pack_blocks = 0;
     std::vector<const float*> bound_ptrs;
     bool bound = false;
+
+    // fp16-split path (dsg_split.hpp): wide blocks of the sampling loop
+    bool use_split = true;
+    float* maxabs = nullptr;           // [params]: max|W| per tensor, refreshed at every bind
+    const float** mx_ptrs_dev = nullptr; long long* mx_numel_dev = nullptr; int* mx_idx_dev = nullptr; int mx_n = 0;
+    std::vector<int> mx_param;         // param index of each k_maxabs block
+    PackHDesc* packh_dev = nullptr; int packh_n = 0; long long packh_blocks = 0;
 
     // forward workspace
     int cap_rows = 0, cap_entries = 0;
@@ -241,6 +251,14 @@ void carve(dsg_handle* h) {
         r.W2T = c.take((size_t)NT * NG * 256);
         r.W3T = c.take((size_t)NT * NG * 256);
         r.WscT = r.sclin ? c.take((size_t)OT1 * NG * 256) : 0;
+        r.split = r.N >= 64 && r.N % 32 == 0;
+        if (r.split) {
+            const size_t KS1 = (size_t)(groups_of(r.in0) + 1) / 2 + (size_t)(groups_of(r.in1) + 1) / 2;
+            r.W1h = c.take((size_t)NT * KS1 * 128 * 4);
+            r.W2h = c.take((size_t)NT * (r.N / 16) * 128 * 4);
+            r.W3h = c.take((size_t)NT * (r.N / 16) * 128 * 4);
+            r.Wsch = r.sclin ? c.take((size_t)NT * KS1 * 128 * 4) : 0;
+        }
     }
     for (auto& l : h->lin) {
         const int NT = cdiv(l.l.N, 32), KG = groups_of(l.l.K);
@@ -466,11 +484,30 @@ void fill_lin_args(const dsg_handle* h, const Op& op, const RunCtx& c, LinArgs& 
     }
 }
 
+void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStream_t s) {
+    BlockArgsH a;
+    a.b = b;
+    const float* A = h->arena;
+    a.W1h = reinterpret_cast<const uint4*>(A + r.W1h); a.W2h = reinterpret_cast<const uint4*>(A + r.W2h);
+    a.W3h = reinterpret_cast<const uint4*>(A + r.W3h); a.Wsch = r.sclin ? reinterpret_cast<const uint4*>(A + r.Wsch) : nullptr;
+    a.m1 = h->maxabs + r.l1.w; a.m2 = h->maxabs + r.l2.w; a.m3 = h->maxabs + r.l3.w; a.msc = r.sclin ? h->maxabs + r.sc.w : nullptr;
+    const dim3 grid(cdiv(b.ntiles, kWavesPerBlock)), block(256);
+    if (r.N == 128) {
+        if (r.sclin) hipLaunchKernelGGL((k_resblock_h<128, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_resblock_h<128, false>), grid, block, 0, s, a);
+    } else {
+        if (r.sclin) hipLaunchKernelGGL((k_resblock_h<64, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_resblock_h<64, false>), grid, block, 0, s, a);
+    }
+}
+
 void launch_op(const dsg_handle* h, const Op& op, const RunCtx& c, hipStream_t s) {
     if (op.kind == OP_RES) {
         BlockArgs a;
         fill_block_args(h, op, c, a);
-        launch_res(h->res[op.p].N, h->res[op.p].sclin, a, s);
+        const ResP& r = h->res[op.p];
+        if (h->use_split && r.split && c.cond_pre && !c.train) launch_res_h(h, r, a, s);
+        else launch_res(r.N, r.sclin, a, s);
     } else {
         LinArgs a;
         fill_lin_args(h, op, c, a);
@@ -787,7 +824,9 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         }
         h->fuse_lo = best_lo; h->fuse_hi = best_hi;
     }
-    bool ok = hipMalloc(&h->fused_dev, (h->ops.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
+    if (const char* e = getenv("DSG_PRECISION")) h->use_split = strcmp(e, "f32") != 0;
+    bool ok = hipMalloc(&h->maxabs, (h->params.size() + 1) * sizeof(float)) == hipSuccess &&
+              hipMalloc(&h->fused_dev, (h->ops.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
               hipMalloc(&h->arena, h->arena_floats * sizeof(float)) == hipSuccess &&
               hipMemset(h->arena, 0, h->arena_floats * sizeof(float)) == hipSuccess &&
               hipMalloc(&h->tdesc_dev, h->res.size() * sizeof(TimeBlockDesc)) == hipSuccess &&
@@ -812,7 +851,8 @@ void dsg_destroy(dsg_handle* h) {
     if (!h) return;
     (void)hipDeviceSynchronize();
     free_workspace(h);
-    void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev};
+    void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev, h->maxabs,
+                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -891,6 +931,45 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
                 padv(P[l.ln.b].ptr, nullptr, l.l.K, 0, l.betap, KG * 8 + 32);
             }
         }
+        {   // fp16-split planes of the wide blocks
+            std::vector<const float*> mp; std::vector<long long> mn; std::vector<PackHDesc> hd;
+            h->mx_param.clear();
+            long long hb = 0;
+            auto want = [&](const LinearP& l) {
+                for (size_t i = 0; i < h->mx_param.size(); ++i) if (h->mx_param[i] == l.w) return;
+                h->mx_param.push_back(l.w); mp.push_back(P[l.w].ptr); mn.push_back(P[l.w].numel);
+            };
+            auto pushh = [&](const LinearP& l, const LinearP* pair, int role, int w0, int w1, size_t off) {
+                PackHDesc d;
+                const int NT = cdiv(l.N, 32), KS = (groups_of(w0) + 1) / 2 + (groups_of(w1) + 1) / 2;
+                d.W = P[l.w].ptr; d.dst = reinterpret_cast<uint4*>(A + off); d.m_self = h->maxabs + l.w; d.m_pair = pair ? h->maxabs + pair->w : nullptr;
+                d.role = role; d.N = l.N; d.Ktot = l.K; d.w0 = w0; d.w1 = w1; d.NT = NT; d.total = (long long)NT * KS * 128; d.blk_begin = hb;
+                hb += (d.total + 255) / 256;
+                hd.push_back(d);
+            };
+            for (const ResP& r : h->res) {
+                if (!r.split) continue;
+                want(r.l1); want(r.l2); want(r.l3);
+                if (r.sclin) want(r.sc);
+                pushh(r.l1, nullptr, 0, r.in0, r.in1, r.W1h);
+                pushh(r.l2, nullptr, 0, r.N, 0, r.W2h);
+                if (r.sclin) { pushh(r.l3, &r.sc, 1, r.N, 0, r.W3h); pushh(r.sc, &r.l3, 2, r.in0, r.in1, r.Wsch); }
+                else pushh(r.l3, nullptr, 0, r.N, 0, r.W3h);
+            }
+            h->mx_n = (int)mp.size(); h->packh_n = (int)hd.size(); h->packh_blocks = hb;
+            if (h->mx_n) {
+                if (!h->mx_ptrs_dev) {
+                    HIPCK(hipMalloc(&h->mx_ptrs_dev, mp.size() * sizeof(float*)));
+                    HIPCK(hipMalloc(&h->mx_numel_dev, mn.size() * sizeof(long long)));
+                    HIPCK(hipMalloc(&h->packh_dev, hd.size() * sizeof(PackHDesc)));
+                    HIPCK(hipMalloc(&h->mx_idx_dev, mp.size() * sizeof(int)));
+                }
+                HIPCK(hipMemcpy(h->mx_idx_dev, h->mx_param.data(), mp.size() * sizeof(int), hipMemcpyHostToDevice));
+                HIPCK(hipMemcpy(h->mx_ptrs_dev, mp.data(), mp.size() * sizeof(float*), hipMemcpyHostToDevice));
+                HIPCK(hipMemcpy(h->mx_numel_dev, mn.data(), mn.size() * sizeof(long long), hipMemcpyHostToDevice));
+                HIPCK(hipMemcpy(h->packh_dev, hd.data(), hd.size() * sizeof(PackHDesc), hipMemcpyHostToDevice));
+            }
+        }
         if (!h->pack_dev) HIPCK(hipMalloc(&h->pack_dev, pd.size() * sizeof(PackDesc)));
         h->pack_n = (int)pd.size();
         h->pack_blocks = blk;
@@ -899,8 +978,22 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
         HIPCK(hipStreamSynchronize(s));  // pd / td are host temporaries
     }
     hipLaunchKernelGGL(k_pack_grouped, dim3((unsigned)h->pack_blocks), dim3(256), 0, s, h->pack_dev, h->pack_n);
+    if (h->mx_n) {
+        // max|W| of every split-packed weight -> maxabs[param index]; the pack and the block kernels derive the same
+        // power-of-two scale from it on the device (no host round trip)
+        hipLaunchKernelGGL(k_maxabs, dim3(h->mx_n), dim3(256), 0, s, h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->maxabs);
+        hipLaunchKernelGGL(k_pack_h, dim3((unsigned)h->packh_blocks), dim3(256), 0, s, h->packh_dev, h->packh_n);
+    }
     HIPCK(hipGetLastError());
     h->bound = true;
+    return 0;
+}
+
+int dsg_set_precision(dsg_handle* h, int mode) {
+    if (!h) return fail("null handle");
+    if (mode != DSG_PRECISION_SPLIT_F16 && mode != DSG_PRECISION_F32_MFMA) return fail("unknown precision mode %d", mode);
+    const bool split = mode == DSG_PRECISION_SPLIT_F16;
+    if (split != h->use_split) { (void)hipDeviceSynchronize(); free_graphs(h); h->use_split = split; }
     return 0;
 }
 

@@ -1,0 +1,377 @@
+// Wide ResidualBlocks on the real matrix cores: float32-accurate GEMMs as a 2-way fp16 split on
+// v_mfma_f32_32x32x16_f16 with float32 accumulation.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at the float32 VECTOR rate (157 TFLOP/s) and, measured here
+// (tools/ubench/chain_rate.hip), does not overlap with VALU / VMEM issue from the same SIMD: the activation VALU of
+// a block simply adds to its MFMA time (91 cycles per MFMA instead of 64).  The f16 MFMA is 16x faster per MAC and
+// does overlap, so three of them -- hi*hi + hi*lo + lo*hi of operands split as x = hi + lo, hi = fp16(x),
+// lo = fp16(x - hi) -- cost 96 cycles per 32x32x16 block instead of 512, at 22 significant bits per operand
+// (2^-22 = 2.4e-7 relative; float32 itself is 6e-8) and exact float32 accumulation.  Operands are pre-scaled by
+// powers of two so that the lo parts stay in fp16's normal range (weights by 2^e per layer from max|W|, activations
+// by 16); the accumulator is un-scaled with one fma (which also adds the bias).  tools/ubench/split_rate.hip:
+// 367 float32-equivalent TFLOP/s for the stage pattern of a 128-wide block, against 110 on the f32 MFMA.
+//
+// Layouts are those of dsg_kernels.hpp (same fragment tensors in HBM, same accumulator order): the C/D map of the
+// 32x32x16 MFMA equals the 32x32x2 one, and its B operand of k16-step S is exactly fragment groups 2S and 2S+1 of the
+// lane (8 halfs), so the accumulator-is-the-next-operand chaining carries over unchanged.  Packed weights: per
+// (out tile, k16-step) two planes (hi, lo) of 64 lanes x 8 halfs.
+#pragma once
+#include "dsg_kernels.hpp"
+
+namespace dsg {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+
+constexpr float kActScale = 16.0f;       // B operands that are LayerNorm+SiLU outputs (bounded by ~sqrt(width))
+constexpr float kRawScale = 1.0f;        // B operands that are raw residual-stream values
+
+// Weight scale exponent of one Linear from max|W|: max|W| * 2^e in [4096, 8192).
+__device__ __forceinline__ int scale_exp(float maxabs) {
+    int e = (int)floorf(log2f(8192.0f / fmaxf(maxabs, 1e-30f)));
+    return e < -8 ? -8 : (e > 24 ? 24 : e);
+}
+// lin3 and the Linear shortcut accumulate into one chain: (2^e3 * kActScale) must equal (2^esc * kRawScale).
+__device__ __forceinline__ int scale_exp_lin3(float m3, float msc) {
+    const int e3 = scale_exp(m3), esc = scale_exp(msc) - 4;
+    return e3 < esc ? e3 : esc;
+}
+
+#define DSG_MFMA_H(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (acc), 0, 0, 0)
+
+template <int NT>
+struct HFrag { uint4 hi[NT], lo[NT]; };
+
+// wp: packed planes of this k16-step for out tile 0, + lane; tile stride in uint4
+template <int NT>
+__device__ __forceinline__ void load_hfrag(HFrag<NT>& w, const uint4* __restrict__ wp, size_t nt_stride) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { w.hi[nt] = wp[nt * nt_stride]; w.lo[nt] = wp[nt * nt_stride + 64]; }
+}
+
+// 8 float32 values (already multiplied by the activation scale) -> hi / lo half vectors (round toward zero: the
+// residual is then exactly representable and hi + lo carries 22 bits)
+__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+    for (int p = 0; p < 8; p += 2) {
+        const hp2 a = __builtin_amdgcn_cvt_pkrtz(v[p], v[p + 1]);
+        const hp2 b = __builtin_amdgcn_cvt_pkrtz(v[p] - (float)a[0], v[p + 1] - (float)a[1]);
+        hi[p] = (_Float16)a[0]; hi[p + 1] = (_Float16)a[1];
+        lo[p] = (_Float16)b[0]; lo[p + 1] = (_Float16)b[1];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[NT], const HFrag<NT>& w, const h8 bhi, const h8 blo) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const h8 whi = __builtin_bit_cast(h8, w.hi[nt]), wlo = __builtin_bit_cast(h8, w.lo[nt]);
+        DSG_MFMA_H(acc[nt], whi, bhi);
+        DSG_MFMA_H(acc[nt], whi, blo);
+        DSG_MFMA_H(acc[nt], wlo, bhi);
+    }
+}
+
+__device__ __forceinline__ void act8(float (&v)[8], const float4 x0, const float4 x1, float c, float d, const float4 g0, const float4 b0,
+                                     const float4 g1, const float4 b1) {
+    // LayerNorm as x*c + d (c = rstd, d = -mean*rstd), affine, SiLU, activation scale
+    v[0] = kActScale * silu(fmaf(fmaf(x0.x, c, d), g0.x, b0.x)); v[1] = kActScale * silu(fmaf(fmaf(x0.y, c, d), g0.y, b0.y));
+    v[2] = kActScale * silu(fmaf(fmaf(x0.z, c, d), g0.z, b0.z)); v[3] = kActScale * silu(fmaf(fmaf(x0.w, c, d), g0.w, b0.w));
+    v[4] = kActScale * silu(fmaf(fmaf(x1.x, c, d), g1.x, b1.x)); v[5] = kActScale * silu(fmaf(fmaf(x1.y, c, d), g1.y, b1.y));
+    v[6] = kActScale * silu(fmaf(fmaf(x1.z, c, d), g1.z, b1.z)); v[7] = kActScale * silu(fmaf(fmaf(x1.w, c, d), g1.w, b1.w));
+}
+
+// Register-fed stage (stages 2 and 3): B = split(16 * silu(LN(in))).  N is a multiple of 16 here (N in {64, 128}).
+template <int N, int NT>
+__device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16 (&in)[NT], const uint4* __restrict__ wp,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float mean, float rstd,
+                                                 int lane, int h) {
+    constexpr int KS = N / 16;
+    const size_t nt_stride = (size_t)KS * 128;
+    const float c = rstd, d = -mean * rstd;
+    HFrag<NT> wn;
+    float4 gn0, bn0, gn1, bn1;
+    load_hfrag<NT>(wn, wp + lane, nt_stride);
+    gn0 = ld4(gamma + 4 * h); bn0 = ld4(beta + 4 * h); gn1 = ld4(gamma + 8 + 4 * h); bn1 = ld4(beta + 8 + 4 * h);
+#pragma unroll
+    for (int S = 0; S < KS; ++S) {
+        const HFrag<NT> wc = wn;
+        const float4 g0 = gn0, b0 = bn0, g1 = gn1, b1 = bn1;
+        if (S + 1 < KS) {
+            load_hfrag<NT>(wn, wp + (size_t)(S + 1) * 128 + lane, nt_stride);
+            gn0 = ld4(gamma + 16 * (S + 1) + 4 * h); bn0 = ld4(beta + 16 * (S + 1) + 4 * h);
+            gn1 = ld4(gamma + 16 * (S + 1) + 8 + 4 * h); bn1 = ld4(beta + 16 * (S + 1) + 8 + 4 * h);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int t = S >> 1, r0 = 8 * (S & 1);
+        float v[8];
+        act8(v, make_float4(in[t][r0], in[t][r0 + 1], in[t][r0 + 2], in[t][r0 + 3]),
+             make_float4(in[t][r0 + 4], in[t][r0 + 5], in[t][r0 + 6], in[t][r0 + 7]), c, d, g0, b0, g1, b1);
+        h8 bhi, blo;
+        split8(v, bhi, blo);
+        mfma_step_h<NT>(out, wc, bhi, blo);
+    }
+}
+
+// Memory-fed stage over one fragment tensor (runtime k16-step loop, prefetch distance 1).  `groups` may be odd: the
+// missing group of the last step reads as zero (its packed weights are zero too).
+template <int NT, bool LNACT>
+__device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float* __restrict__ xp, int groups, const uint4* __restrict__ wp,
+                                                 size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float mean, float rstd) {
+    const int steps = (groups + 1) >> 1;
+    if (steps <= 0) return;
+    const float c = rstd, d = -mean * rstd;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    HFrag<NT> wn;
+    float4 xn0, xn1, gn0 = z4, bn0 = z4, gn1 = z4, bn1 = z4;
+    load_hfrag<NT>(wn, wp, nt_stride);
+    xn0 = ld4(xp);
+    xn1 = groups > 1 ? ld4(xp + 256) : z4;
+    if (LNACT) { gn0 = ld4(gamma); bn0 = ld4(beta); gn1 = ld4(gamma + 8); bn1 = ld4(beta + 8); }
+    for (int S = 0; S < steps; ++S) {
+        const HFrag<NT> wc = wn;
+        const float4 x0 = xn0, x1 = xn1, g0 = gn0, b0 = bn0, g1 = gn1, b1 = bn1;
+        if (S + 1 < steps) {
+            load_hfrag<NT>(wn, wp + (size_t)(S + 1) * 128, nt_stride);
+            xn0 = ld4(xp + (size_t)(2 * S + 2) * 256);
+            xn1 = (2 * S + 3 < groups) ? ld4(xp + (size_t)(2 * S + 3) * 256) : z4;
+            if (LNACT) {
+                gn0 = ld4(gamma + 16 * (S + 1)); bn0 = ld4(beta + 16 * (S + 1));
+                gn1 = ld4(gamma + 16 * (S + 1) + 8); bn1 = ld4(beta + 16 * (S + 1) + 8);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float v[8];
+        if (LNACT) {
+            act8(v, x0, x1, c, d, g0, b0, g1, b1);
+        } else {
+            v[0] = kRawScale * x0.x; v[1] = kRawScale * x0.y; v[2] = kRawScale * x0.z; v[3] = kRawScale * x0.w;
+            v[4] = kRawScale * x1.x; v[5] = kRawScale * x1.y; v[6] = kRawScale * x1.z; v[7] = kRawScale * x1.w;
+        }
+        h8 bhi, blo;
+        split8(v, bhi, blo);
+        mfma_step_h<NT>(acc, wc, bhi, blo);
+    }
+}
+
+// acc <- acc * inv + vec  (un-scale and add the per-feature vector, padded to NT*32)
+template <int NT>
+__device__ __forceinline__ void acc_unscale_add(f32x16 (&acc)[NT], float inv, const float* __restrict__ vec, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = ld4(vec + 32 * nt + 8 * q + 4 * h);
+            acc[nt][4 * q + 0] = fmaf(acc[nt][4 * q + 0], inv, b.x); acc[nt][4 * q + 1] = fmaf(acc[nt][4 * q + 1], inv, b.y);
+            acc[nt][4 * q + 2] = fmaf(acc[nt][4 * q + 2], inv, b.z); acc[nt][4 * q + 3] = fmaf(acc[nt][4 * q + 3], inv, b.w);
+        }
+}
+
+struct BlockArgsH {
+    BlockArgs b;             // tensors, biases, LayerNorm parameters, time table, cond_pre: as the f32 kernel
+    const uint4* W1h;        // packed planes [NT][KS1][2][64], KS1 = ceil(g0/2) + ceil(g1/2)
+    const uint4* W2h;        // [NT][N/16][2][64]
+    const uint4* W3h;
+    const uint4* Wsch;       // [NT][KS1][2][64] or null
+    const float* m1;         // device scalars: max|W| of lin1, lin2, lin3, shortcut (written by k_maxabs at bind time)
+    const float* m2;
+    const float* m3;
+    const float* msc;
+};
+
+// Inference only (sampling): needs cond_pre (the condition embedding is added, never multiplied here).
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256, 2) void k_resblock_h(const BlockArgsH ah) {
+    constexpr int NG = N / 8, NT = N / 32;
+    const BlockArgs& a = ah.b;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int h = lane >> 5, j = lane & 31;
+    const int ptile = tile % a.tiles_per_pass;
+    const int ks0 = (a.in0.groups + 1) >> 1, ks1 = (a.in1.groups + 1) >> 1, KS1 = ks0 + ks1;
+
+    // ---- LN1 statistics (Chan merge of the producers' (mean, M2))
+    float mean1, rstd1;
+    {
+        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
+        float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
+        if (a.in1.groups) {
+            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
+            const float n1 = (float)a.in1.width, nt_ = n + n1;
+            const float dd = s1.x - mean;
+            m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
+            mean = mean + dd * (n1 / nt_);
+            n = nt_;
+        }
+        mean1 = mean;
+        rstd1 = rsqrtf(m2 / n + kLnEps);
+    }
+    const int e1 = scale_exp(*ah.m1), e2 = scale_exp(*ah.m2);
+    const int e3 = SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3);
+    const float inv1 = ldexpf(1.0f / kActScale, -e1), inv2 = ldexpf(1.0f / kActScale, -e2), inv3 = ldexpf(1.0f / kActScale, -e3);
+
+    // ---- stage 1
+    f32x16 acc1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
+    {
+        const size_t nt_stride = (size_t)KS1 * 128;
+        chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
+                                   a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
+        if (a.in1.groups)
+            chain_from_mem_h<NT, true>(acc1, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
+                                       ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, a.gamma1 + 8 * a.in0.groups + 4 * h,
+                                       a.beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1);
+        int entry = 0;
+        if (a.ts) {
+            int row = ptile * 32 + j;
+            row = row < a.nrows ? row : a.nrows - 1;
+            entry = a.ts[row];
+        } else if (a.step_ptr) {
+            entry = *a.step_ptr;
+        }
+        acc_unscale_add<NT>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
+    }
+
+    // ---- stage 2
+    f32x16 acc2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.f;
+    {
+        float mean, m2;
+        acc_stats<N, NT>(acc1, h, mean, m2);
+        const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+        chain_from_acc_h<N, NT>(acc2, acc1, ah.W2h, a.gamma2, a.beta2, mean, rstd, lane, h);
+        acc_unscale_add<NT>(acc2, inv2, a.c2, h);
+    }
+    if (tile >= a.uncond_tiles) {
+        const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
+#pragma unroll
+        for (int G = 0; G < NG; ++G) {
+            const float4 cv = ld4(cp + (size_t)G * 256);
+            acc2[G >> 2][4 * (G & 3) + 0] += cv.x; acc2[G >> 2][4 * (G & 3) + 1] += cv.y;
+            acc2[G >> 2][4 * (G & 3) + 2] += cv.z; acc2[G >> 2][4 * (G & 3) + 3] += cv.w;
+        }
+    }
+
+    // ---- stage 3 (+ shortcut in the same scaled accumulator)
+    f32x16 (&acc3)[NT] = acc1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[nt][r] = 0.f;
+    {
+        float mean, m2;
+        acc_stats<N, NT>(acc2, h, mean, m2);
+        const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+        chain_from_acc_h<N, NT>(acc3, acc2, ah.W3h, a.gamma3, a.beta3, mean, rstd, lane, h);
+    }
+    if (SCLIN) {
+        const size_t nt_stride = (size_t)KS1 * 128;
+        chain_from_mem_h<NT, false>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
+                                    nullptr, nullptr, 0.f, 1.f);
+        if (a.in1.groups)
+            chain_from_mem_h<NT, false>(acc3, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
+                                        ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f);
+        acc_unscale_add<NT>(acc3, inv3, a.c3, h);
+    } else {
+        acc_unscale_add<NT>(acc3, inv3, a.c3, h);
+        const float* xp = a.in0.data + (size_t)tile * NG * 256 + lane * 4;
+#pragma unroll
+        for (int G = 0; G < NG; ++G) {
+            const float4 xv = ld4(xp + (size_t)G * 256);
+            acc3[G >> 2][4 * (G & 3) + 0] += xv.x; acc3[G >> 2][4 * (G & 3) + 1] += xv.y;
+            acc3[G >> 2][4 * (G & 3) + 2] += xv.z; acc3[G >> 2][4 * (G & 3) + 3] += xv.w;
+        }
+    }
+
+    // ---- store + statistics
+    {
+        float mean, m2;
+        acc_stats<N, NT>(acc3, h, mean, m2);
+        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+            st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2],
+                            acc3[G >> 2][4 * (G & 3) + 3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bind-time helpers: max|W| per weight tensor, and the fp16 plane packing
+//   dst[((nt*KS + S)*2 + plane)*64 + lane] = 8 halfs: plane(W[32nt + (lane&31)][col(2S + (jj>>2), 4(lane>>5) + (jj&3))] * 2^e)
+// with every K segment padded to an EVEN number of 8-feature groups.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_maxabs(const float* const* __restrict__ ptrs, const long long* __restrict__ numel,
+                                                const int* __restrict__ out_idx, float* __restrict__ out) {
+    __shared__ float sm[4];
+    const float* p = ptrs[blockIdx.x];
+    const long long n = numel[blockIdx.x];
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[out_idx[blockIdx.x]] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+struct PackHDesc {
+    const float* W;       // [N][Ktot]
+    uint4* dst;
+    const float* m_self;  // max|W| of this tensor
+    const float* m_pair;  // lin3 <-> shortcut partner or null
+    int role;             // 0: standalone, 1: lin3 with shortcut partner, 2: shortcut with lin3 partner
+    int N, Ktot, w0, w1, NT;
+    long long total;      // uint4 elements of dst
+    long long blk_begin;
+};
+
+__global__ __launch_bounds__(256) void k_pack_h(const PackHDesc* __restrict__ descs, int ndesc) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].blk_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackHDesc d = descs[lo];
+    const long long idx = ((long long)blockIdx.x - d.blk_begin) * 256 + threadIdx.x;
+    if (idx >= d.total) return;
+    int e;
+    if (d.role == 0) e = scale_exp(*d.m_self);
+    else if (d.role == 1) e = scale_exp_lin3(*d.m_self, *d.m_pair);
+    else e = scale_exp_lin3(*d.m_pair, *d.m_self) + 4;
+    const float sc = ldexpf(1.0f, e);
+    const int lane = idx & 63, plane = (idx >> 6) & 1;
+    const long long ts = idx >> 7;
+    const int g0 = (d.w0 + 7) / 8, g1 = (d.w1 + 7) / 8;
+    const int ks0 = (g0 + 1) >> 1, KS = ks0 + ((g1 + 1) >> 1);
+    const int S = ts % KS, nt = ts / KS;
+    const int n = 32 * nt + (lane & 31), h = lane >> 5;
+    h8 out;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int p = jj & 3;
+        int col = -1;
+        if (S < ks0) {
+            const int g = 2 * S + (jj >> 2), f = 8 * g + 4 * h + p;
+            if (g < g0 && f < d.w0) col = f;
+        } else {
+            const int g = 2 * (S - ks0) + (jj >> 2), f = 8 * g + 4 * h + p;
+            if (g < g1 && f < d.w1) col = d.w0 + f;
+        }
+        float v = 0.f;
+        if (col >= 0 && n < d.N) v = d.W[(size_t)n * d.Ktot + col] * sc;
+        const _Float16 vh = (_Float16)v;
+        out[jj] = plane == 0 ? vh : (_Float16)(v - (float)vh);
+    }
+    d.dst[idx] = __builtin_bit_cast(uint4, out);
+}
+
+}  // namespace dsg

@@ -87,6 +87,24 @@ def test_sample_vs_golden_synth(gold, name, T, graph):
         assert rel(y0, g[f"om{omega:g}_y0"]) <= 1e-4, omega
 
 
+@pytest.mark.parametrize("mode", ["split_f16", "f32"])
+def test_sample_precision_modes_wide_blocks(gold, mode):
+    """The >= 64-wide blocks run either on the fp16-split matrix-core path (default) or on the exact f32 MFMA; both must
+    meet the 1e-4 bar against the reference trajectory, and the exact one must be at float32 rounding level."""
+    T = 6
+    g = gold(f"g4_sample_msr80_T{T}.npz")
+    plan, p = synth_params("msr80", 31)
+    ddpm = make_ddpm("msr80", p, T)
+    ddpm.model.set_precision(mode)
+    cond = torch.from_numpy(g["cond"]).cuda()
+    worst = 0.0
+    for omega in (0.0, 1.0, 3.0):
+        y0 = ddpm.sample(cond, omega, y_T=torch.from_numpy(g["y_T"]), noise=_z(g, T))
+        worst = max(worst, rel(y0, g[f"om{omega:g}_y0"]))
+    print(f"{mode}: worst rel err {worst:.2e}")
+    assert worst <= (1e-4 if mode == "split_f16" else 2e-5)
+
+
 def test_sample_nu_checkpoint_known_answer(gold):
     """The shipped NU checkpoint on its first 512 test rows: trajectory parity at small omega, and the
     task metric at omega=500, where float32 itself is only good to 2.6e-3 against float64."""
