@@ -75,6 +75,7 @@ struct LinOpP {            // feature_proj / Down/Upsample / final
     NormP ln;              // final only
     bool lnact = false;
     size_t Wp, bp, gp, betap, WT;
+    size_t Wh = 0;         // fp16-split planes
     size_t du, rs;         // final only (training)
 };
 
@@ -152,6 +153,8 @@ struct dsg_handle {
     int fuse_lo = 0, fuse_hi = 0;
     FusedOp* fused_dev = nullptr;
     std::vector<FusedOp> fused_host;
+    FusedOpH* fusedh_dev = nullptr;
+    std::vector<FusedOpH> fusedh_host;
 
     // cached step graphs
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
@@ -251,12 +254,12 @@ void carve(dsg_handle* h) {
         r.W2T = c.take((size_t)NT * NG * 256);
         r.W3T = c.take((size_t)NT * NG * 256);
         r.WscT = r.sclin ? c.take((size_t)OT1 * NG * 256) : 0;
-        r.split = r.N >= 64 && r.N % 32 == 0;
+        r.split = true;
         if (r.split) {
             const size_t KS1 = (size_t)(groups_of(r.in0) + 1) / 2 + (size_t)(groups_of(r.in1) + 1) / 2;
             r.W1h = c.take((size_t)NT * KS1 * 128 * 4);
-            r.W2h = c.take((size_t)NT * (r.N / 16) * 128 * 4);
-            r.W3h = c.take((size_t)NT * (r.N / 16) * 128 * 4);
+            r.W2h = c.take((size_t)NT * ((NG + 1) / 2) * 128 * 4);
+            r.W3h = c.take((size_t)NT * ((NG + 1) / 2) * 128 * 4);
             r.Wsch = r.sclin ? c.take((size_t)NT * KS1 * 128 * 4) : 0;
         }
     }
@@ -267,6 +270,7 @@ void carve(dsg_handle* h) {
         l.gp = l.lnact ? c.take((size_t)KG * 8 + 32) : 0;
         l.betap = l.lnact ? c.take((size_t)KG * 8 + 32) : 0;
         l.WT = c.take((size_t)cdiv(KG, 4) * groups_of(l.l.N) * 256);
+        l.Wh = c.take((size_t)NT * ((KG + 1) / 2) * 128 * 4);
     }
     h->zero_off = c.take(128);
     h->arena_floats = c.off;
@@ -484,36 +488,74 @@ void fill_lin_args(const dsg_handle* h, const Op& op, const RunCtx& c, LinArgs& 
     }
 }
 
-void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStream_t s) {
-    BlockArgsH a;
+void fill_block_args_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, BlockArgsH& a) {
     a.b = b;
     const float* A = h->arena;
     a.W1h = reinterpret_cast<const uint4*>(A + r.W1h); a.W2h = reinterpret_cast<const uint4*>(A + r.W2h);
     a.W3h = reinterpret_cast<const uint4*>(A + r.W3h); a.Wsch = r.sclin ? reinterpret_cast<const uint4*>(A + r.Wsch) : nullptr;
     a.m1 = h->maxabs + r.l1.w; a.m2 = h->maxabs + r.l2.w; a.m3 = h->maxabs + r.l3.w; a.msc = r.sclin ? h->maxabs + r.sc.w : nullptr;
-    const dim3 grid(cdiv(b.ntiles, kWavesPerBlock)), block(256);
-    if (r.N == 128) {
-        if (r.sclin) hipLaunchKernelGGL((k_resblock_h<128, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_resblock_h<128, false>), grid, block, 0, s, a);
-    } else {
-        if (r.sclin) hipLaunchKernelGGL((k_resblock_h<64, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_resblock_h<64, false>), grid, block, 0, s, a);
+}
+void fill_lin_args_h(const dsg_handle* h, const LinOpP& l, const LinArgs& b, LinArgsH& a) {
+    a.l = b;
+    a.Wh = reinterpret_cast<const uint4*>(h->arena + l.Wh);
+    a.m = h->maxabs + l.l.w;
+}
+
+template <int N>
+void launch_res_h_n(bool sclin, const BlockArgsH& a, hipStream_t s) {
+    const dim3 grid(cdiv(a.b.ntiles, kWavesPerBlock)), block(256);
+    if (sclin) hipLaunchKernelGGL((k_resblock_h<N, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_resblock_h<N, false>), grid, block, 0, s, a);
+}
+void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStream_t s) {
+    BlockArgsH a;
+    fill_block_args_h(h, r, b, a);
+    switch (r.N) {
+        case 4: launch_res_h_n<4>(r.sclin, a, s); break;
+        case 8: launch_res_h_n<8>(r.sclin, a, s); break;
+        case 16: launch_res_h_n<16>(r.sclin, a, s); break;
+        case 32: launch_res_h_n<32>(r.sclin, a, s); break;
+        case 64: launch_res_h_n<64>(r.sclin, a, s); break;
+        case 128: launch_res_h_n<128>(r.sclin, a, s); break;
     }
 }
+template <int NT>
+void launch_lin_h_nt(int inmode, int outmode, bool lnact, const LinArgsH& a, hipStream_t s) {
+    const dim3 grid(cdiv(a.l.ntiles, kWavesPerBlock)), block(256);
+    if (inmode == IN_ROWMAJOR) hipLaunchKernelGGL((k_linear_h<NT, IN_ROWMAJOR, OUT_FRAG, false>), grid, block, 0, s, a);
+    else if (outmode == OUT_ROWMAJOR && lnact) hipLaunchKernelGGL((k_linear_h<NT, IN_FRAG, OUT_ROWMAJOR, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_linear_h<NT, IN_FRAG, OUT_FRAG, false>), grid, block, 0, s, a);
+}
+void launch_lin_h(int N, int inmode, int outmode, bool lnact, const LinArgsH& a, hipStream_t s) {
+    switch (cdiv(N, 32)) {
+        case 1: launch_lin_h_nt<1>(inmode, outmode, lnact, a, s); break;
+        case 2: launch_lin_h_nt<2>(inmode, outmode, lnact, a, s); break;
+        case 3: launch_lin_h_nt<3>(inmode, outmode, lnact, a, s); break;
+        case 4: launch_lin_h_nt<4>(inmode, outmode, lnact, a, s); break;
+    }
+}
+
+bool split_ctx(const dsg_handle* h, const RunCtx& c) { return h->use_split && c.cond_pre && !c.train; }
 
 void launch_op(const dsg_handle* h, const Op& op, const RunCtx& c, hipStream_t s) {
     if (op.kind == OP_RES) {
         BlockArgs a;
         fill_block_args(h, op, c, a);
         const ResP& r = h->res[op.p];
-        if (h->use_split && r.split && c.cond_pre && !c.train) launch_res_h(h, r, a, s);
+        if (split_ctx(h, c)) launch_res_h(h, r, a, s);
         else launch_res(r.N, r.sclin, a, s);
     } else {
         LinArgs a;
         fill_lin_args(h, op, c, a);
         const int inmode = op.kind == OP_PROJ ? IN_ROWMAJOR : IN_FRAG;
         const int outmode = op.kind == OP_FINAL ? OUT_ROWMAJOR : OUT_FRAG;
-        launch_lin(h->lin[op.p].l.N, inmode, outmode, op.kind == OP_FINAL, a, s);
+        if (split_ctx(h, c)) {
+            LinArgsH ah;
+            fill_lin_args_h(h, h->lin[op.p], a, ah);
+            launch_lin_h(h->lin[op.p].l.N, inmode, outmode, op.kind == OP_FINAL, ah, s);
+        } else {
+            launch_lin(h->lin[op.p].l.N, inmode, outmode, op.kind == OP_FINAL, a, s);
+        }
     }
 }
 
@@ -527,27 +569,38 @@ bool fusable(const dsg_handle* h, const Op& op) {
 int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
     const int n = h->fuse_hi - h->fuse_lo;
     if (n < 2 || c.train) return 0;
-    HIPCK(hipStreamSynchronize(s));  // fused_host may still be the source of an earlier async copy
-    h->fused_host.resize(n);
+    HIPCK(hipStreamSynchronize(s));  // the host tables may still be the source of an earlier async copy
+    const bool sp = split_ctx(h, c);
+    if (sp) h->fusedh_host.resize(n); else h->fused_host.resize(n);
     for (int i = 0; i < n; ++i) {
         const Op& op = h->ops[h->fuse_lo + i];
-        FusedOp& f = h->fused_host[i];
-        memset(&f, 0, sizeof f);
-        if (op.kind == OP_RES) {
-            f.kind = 0; f.N = h->res[op.p].N; f.sclin = h->res[op.p].sclin;
-            fill_block_args(h, op, c, f.b);
+        BlockArgs b; LinArgs l;
+        memset(&b, 0, sizeof b); memset(&l, 0, sizeof l);
+        const int kind = op.kind == OP_RES ? 0 : 1;
+        const int N = kind == 0 ? h->res[op.p].N : h->lin[op.p].l.N;
+        const int sclin = kind == 0 ? (int)h->res[op.p].sclin : 0;
+        if (kind == 0) fill_block_args(h, op, c, b); else fill_lin_args(h, op, c, l);
+        if (sp) {
+            FusedOpH& f = h->fusedh_host[i];
+            memset(&f, 0, sizeof f);
+            f.kind = kind; f.N = N; f.sclin = sclin;
+            if (kind == 0) fill_block_args_h(h, h->res[op.p], b, f.b); else fill_lin_args_h(h, h->lin[op.p], l, f.l);
         } else {
-            f.kind = 1; f.N = h->lin[op.p].l.N;
-            fill_lin_args(h, op, c, f.l);
+            FusedOp& f = h->fused_host[i];
+            memset(&f, 0, sizeof f);
+            f.kind = kind; f.N = N; f.sclin = sclin; f.b = b; f.l = l;
         }
     }
-    HIPCK(hipMemcpyAsync(h->fused_dev, h->fused_host.data(), n * sizeof(FusedOp), hipMemcpyHostToDevice, s));
+    if (sp) HIPCK(hipMemcpyAsync(h->fusedh_dev, h->fusedh_host.data(), n * sizeof(FusedOpH), hipMemcpyHostToDevice, s));
+    else HIPCK(hipMemcpyAsync(h->fused_dev, h->fused_host.data(), n * sizeof(FusedOp), hipMemcpyHostToDevice, s));
     return 0;
 }
 
 void launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     const int ntiles = cdiv(c.nrows, 32) * c.npass;
-    hipLaunchKernelGGL(k_fused_narrow, dim3(cdiv(ntiles, kWavesPerBlock)), dim3(256), 0, s, h->fused_dev, h->fuse_hi - h->fuse_lo, ntiles);
+    const dim3 grid(cdiv(ntiles, kWavesPerBlock)), block(256);
+    if (split_ctx(h, c)) hipLaunchKernelGGL(k_fused_narrow_h, grid, block, 0, s, h->fusedh_dev, h->fuse_hi - h->fuse_lo, ntiles);
+    else hipLaunchKernelGGL(k_fused_narrow, grid, block, 0, s, h->fused_dev, h->fuse_hi - h->fuse_lo, ntiles);
 }
 
 void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
@@ -825,7 +878,8 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         h->fuse_lo = best_lo; h->fuse_hi = best_hi;
     }
     if (const char* e = getenv("DSG_PRECISION")) h->use_split = strcmp(e, "f32") != 0;
-    bool ok = hipMalloc(&h->maxabs, (h->params.size() + 1) * sizeof(float)) == hipSuccess &&
+    bool ok = hipMalloc(&h->fusedh_dev, (h->ops.size() + 1) * sizeof(FusedOpH)) == hipSuccess &&
+              hipMalloc(&h->maxabs, (h->params.size() + 1) * sizeof(float)) == hipSuccess &&
               hipMalloc(&h->fused_dev, (h->ops.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
               hipMalloc(&h->arena, h->arena_floats * sizeof(float)) == hipSuccess &&
               hipMemset(h->arena, 0, h->arena_floats * sizeof(float)) == hipSuccess &&
@@ -852,7 +906,7 @@ void dsg_destroy(dsg_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev, h->maxabs,
-                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev};
+                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -956,6 +1010,7 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
                 if (r.sclin) { pushh(r.l3, &r.sc, 1, r.N, 0, r.W3h); pushh(r.sc, &r.l3, 2, r.in0, r.in1, r.Wsch); }
                 else pushh(r.l3, nullptr, 0, r.N, 0, r.W3h);
             }
+            for (const LinOpP& l : h->lin) { want(l.l); pushh(l.l, nullptr, 0, l.l.K, 0, l.Wh); }
             h->mx_n = (int)mp.size(); h->packh_n = (int)hd.size(); h->packh_blocks = hb;
             if (h->mx_n) {
                 if (!h->mx_ptrs_dev) {

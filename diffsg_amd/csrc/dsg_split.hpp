@@ -81,12 +81,13 @@ __device__ __forceinline__ void act8(float (&v)[8], const float4 x0, const float
     v[6] = kActScale * silu(fmaf(fmaf(x1.z, c, d), g1.z, b1.z)); v[7] = kActScale * silu(fmaf(fmaf(x1.w, c, d), g1.w, b1.w));
 }
 
-// Register-fed stage (stages 2 and 3): B = split(16 * silu(LN(in))).  N is a multiple of 16 here (N in {64, 128}).
+// Register-fed stage (stages 2 and 3): B = split(16 * silu(LN(in))).  An odd group count (N = 8, 4) pairs the last group
+// with the accumulator's zero padding (rows >= N of the producer's packed weights and biases are zero).
 template <int N, int NT>
 __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16 (&in)[NT], const uint4* __restrict__ wp,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float mean, float rstd,
                                                  int lane, int h) {
-    constexpr int KS = N / 16;
+    constexpr int KS = ((N + 7) / 8 + 1) / 2;
     const size_t nt_stride = (size_t)KS * 128;
     const float c = rstd, d = -mean * rstd;
     HFrag<NT> wn;
@@ -182,12 +183,9 @@ struct BlockArgsH {
 
 // Inference only (sampling): needs cond_pre (the condition embedding is added, never multiplied here).
 template <int N, bool SCLIN>
-__global__ __launch_bounds__(256, 2) void k_resblock_h(const BlockArgsH ah) {
-    constexpr int NG = N / 8, NT = N / 32;
+__device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane) {
+    constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
     const BlockArgs& a = ah.b;
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (tile >= a.ntiles) return;
     const int h = lane >> 5, j = lane & 31;
     const int ptile = tile % a.tiles_per_pass;
     const int ks0 = (a.in0.groups + 1) >> 1, ks1 = (a.in1.groups + 1) >> 1, KS1 = ks0 + ks1;
@@ -301,6 +299,146 @@ __global__ __launch_bounds__(256, 2) void k_resblock_h(const BlockArgsH ah) {
             st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
                 make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2],
                             acc3[G >> 2][4 * (G & 3) + 3]));
+    }
+}
+
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256, 2) void k_resblock_h(const BlockArgsH ah) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= ah.b.ntiles) return;
+    resblock_body_h<N, SCLIN>(ah, tile, lane);
+}
+
+// Plain Linear on the split path (feature_proj, Down/Upsample, final): same contract as linear_body.
+struct LinArgsH {
+    LinArgs l;
+    const uint4* Wh;   // [NT][ceil(KG/2)][2][64]
+    const float* m;    // max|W|
+};
+
+template <int NT, int INMODE, int OUTMODE, bool LNACT>
+__device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile, const int lane) {
+    const LinArgs& a = ah.l;
+    const int h = lane >> 5, j = lane & 31;
+    const int ptile = tile % a.tiles_per_pass;
+    const int pass = tile / a.tiles_per_pass;
+    const int row = ptile * 32 + j;
+    const int KG = a.in_groups, KS = (KG + 1) >> 1;
+    const size_t nt_stride = (size_t)KS * 128;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    float mean = 0.f, rstd = 1.f;
+    if (LNACT) {
+        const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)tile * 32 + j];
+        mean = s.x;
+        rstd = rsqrtf(s.y / (float)a.in.width + kLnEps);
+    }
+    if (INMODE == IN_FRAG) {
+        chain_from_mem_h<NT, LNACT>(acc, a.in.data + (size_t)tile * KG * 256 + lane * 4, KG, ah.Wh + lane, nt_stride,
+                                    LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
+    } else {
+        for (int S = 0; S < KS; ++S) {
+            HFrag<NT> wc;
+            load_hfrag<NT>(wc, ah.Wh + (size_t)S * 128 + lane, nt_stride);
+            float v[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int f = 8 * (2 * S + (jj >> 2)) + 4 * h + (jj & 3);
+                v[jj] = (row < a.nrows && f < a.in_width) ? kRawScale * a.in_rm[(size_t)row * a.in_width + f] : 0.f;
+            }
+            h8 bhi, blo;
+            split8(v, bhi, blo);
+            mfma_step_h<NT>(acc, wc, bhi, blo);
+        }
+    }
+    const float inv = ldexpf(1.0f / (LNACT ? kActScale : kRawScale), -scale_exp(*ah.m));
+    acc_unscale_add<NT>(acc, inv, a.bias, h);
+
+    if (OUTMODE == OUT_FRAG) {
+        const int NG = (a.out_width + 7) / 8;
+        float s = 0.f;
+#pragma unroll
+        for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (8 * G + 4 * h + p < a.out_width) s += acc[G >> 2][4 * (G & 3) + p];
+        const float m = xhalf_sum(s) / (float)a.out_width;
+        float q = 0.f;
+#pragma unroll
+        for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (8 * G + 4 * h + p < a.out_width) {
+                    const float d = acc[G >> 2][4 * (G & 3) + p] - m;
+                    q = fmaf(d, d, q);
+                }
+        q = xhalf_sum(q);
+        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
+#pragma unroll
+        for (int G = 0; G < NT * 4; ++G)
+            if (G < NG)
+                st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                    make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2],
+                                acc[G >> 2][4 * (G & 3) + 3]));
+    } else {
+        if (row < a.nrows) {
+            float* o = a.out_rm + ((size_t)pass * a.nrows + row) * a.out_width;
+#pragma unroll
+            for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int f = 8 * G + 4 * h + p;
+                    if (f < a.out_width) o[f] = acc[G >> 2][4 * (G & 3) + p];
+                }
+        }
+    }
+}
+
+template <int NT, int INMODE, int OUTMODE, bool LNACT>
+__global__ __launch_bounds__(256) void k_linear_h(const LinArgsH a) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= a.l.ntiles) return;
+    linear_body_h<NT, INMODE, OUTMODE, LNACT>(a, tile, lane);
+}
+
+// The narrow run on the split path (see k_fused_narrow).
+struct FusedOpH {
+    int kind, N, sclin, pad;
+    BlockArgsH b;
+    LinArgsH l;
+};
+
+__global__ __launch_bounds__(256, 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    for (int i = 0; i < nops; ++i) {
+        const FusedOpH& op = ops[i];
+        if (op.kind == 0) {
+            if (op.sclin) {
+                switch (op.N) {
+                    case 4: resblock_body_h<4, true>(op.b, tile, lane); break;
+                    case 8: resblock_body_h<8, true>(op.b, tile, lane); break;
+                    case 16: resblock_body_h<16, true>(op.b, tile, lane); break;
+                    default: resblock_body_h<32, true>(op.b, tile, lane); break;
+                }
+            } else {
+                switch (op.N) {
+                    case 4: resblock_body_h<4, false>(op.b, tile, lane); break;
+                    case 8: resblock_body_h<8, false>(op.b, tile, lane); break;
+                    case 16: resblock_body_h<16, false>(op.b, tile, lane); break;
+                    default: resblock_body_h<32, false>(op.b, tile, lane); break;
+                }
+            }
+        } else {
+            linear_body_h<1, IN_FRAG, OUT_FRAG, false>(op.l, tile, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
