@@ -72,13 +72,23 @@ __device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[NT], const HFrag<NT>& 
     }
 }
 
+// kActScale * silu(u): the scale rides in the denominator (u * rcp((1 + e)/16)); exp as fast_exp_neg without the c_lo
+// term (|u| * 1.3e-8, below float32 rounding here)
+__device__ __forceinline__ float silu_scaled(float u) {
+    const float t = u * -1.44269504088896341f;
+    const float e = fmaf(u, -1.44269504088896341f, -t);
+    const float p = __builtin_amdgcn_exp2f(t);
+    const float q = fmaf(p * e, 0.693147180559945f, p);
+    return u * __builtin_amdgcn_rcpf(fmaf(q, 1.0f / kActScale, 1.0f / kActScale));
+}
+
 __device__ __forceinline__ void act8(float (&v)[8], const float4 x0, const float4 x1, float c, float d, const float4 g0, const float4 b0,
                                      const float4 g1, const float4 b1) {
     // LayerNorm as x*c + d (c = rstd, d = -mean*rstd), affine, SiLU, activation scale
-    v[0] = kActScale * silu(fmaf(fmaf(x0.x, c, d), g0.x, b0.x)); v[1] = kActScale * silu(fmaf(fmaf(x0.y, c, d), g0.y, b0.y));
-    v[2] = kActScale * silu(fmaf(fmaf(x0.z, c, d), g0.z, b0.z)); v[3] = kActScale * silu(fmaf(fmaf(x0.w, c, d), g0.w, b0.w));
-    v[4] = kActScale * silu(fmaf(fmaf(x1.x, c, d), g1.x, b1.x)); v[5] = kActScale * silu(fmaf(fmaf(x1.y, c, d), g1.y, b1.y));
-    v[6] = kActScale * silu(fmaf(fmaf(x1.z, c, d), g1.z, b1.z)); v[7] = kActScale * silu(fmaf(fmaf(x1.w, c, d), g1.w, b1.w));
+    v[0] = silu_scaled(fmaf(fmaf(x0.x, c, d), g0.x, b0.x)); v[1] = silu_scaled(fmaf(fmaf(x0.y, c, d), g0.y, b0.y));
+    v[2] = silu_scaled(fmaf(fmaf(x0.z, c, d), g0.z, b0.z)); v[3] = silu_scaled(fmaf(fmaf(x0.w, c, d), g0.w, b0.w));
+    v[4] = silu_scaled(fmaf(fmaf(x1.x, c, d), g1.x, b1.x)); v[5] = silu_scaled(fmaf(fmaf(x1.y, c, d), g1.y, b1.y));
+    v[6] = silu_scaled(fmaf(fmaf(x1.z, c, d), g1.z, b1.z)); v[7] = silu_scaled(fmaf(fmaf(x1.w, c, d), g1.w, b1.w));
 }
 
 // Register-fed stage (stages 2 and 3): B = split(16 * silu(LN(in))).  An odd group count (N = 8, 4) pairs the last group
