@@ -12,11 +12,19 @@ device Philox stream; inputs are resident in HBM before the timed region.  Rever
 collective: every rank runs its own B-row batch (weak scaling) and `value` counts the B-row steps the
 whole job finished per second.
 
+Arithmetic: float32 in HBM and in every accumulator; the GEMMs run as hi/lo fp16 splits (22 significant bits per operand)
+on v_mfma_f32_32x32x16_f16 (`diffsg_amd/csrc/dsg_split.hpp`), which measures as accurate against the reference as the
+exact v_mfma_f32_32x32x2_f32 path (1.3e-6 vs 1.4e-6 worst relative error on the parity cases) and is what `dtype`
+"f32(2xf16-split MFMA, f32 accumulate)" names.  `--precision f32` times the exact-f32 MFMA path instead.
+
 Printed JSON (rank 0): the driver contract keys plus
-  roofline      dominant kernel (k_resblock of the proj_dim-wide up blocks): algorithmic FLOP per launch / mean launch
-                time from HIP events recorded around each launch on the launch stream in a second, eager run of the
-                same K steps; peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  `step` gives the same for a whole
-                step against both roofs (the fp32 FLOP roof binds, not HBM).
+  roofline      dominant kernel (k_resblock of the proj_dim-wide up blocks): ALGORITHMIC float32 FLOP per launch / mean
+                launch time from HIP events recorded around each launch on the launch stream in a second, eager run of
+                the same K steps.  `peak` is the 157.3 TFLOP/s float32 MFMA/VALU rate of MI355X_MICROARCH.md, the roof
+                SURVEY 8(d) names for this path; the split kernel issues 3 f16 MFMAs per float32 block and so can exceed
+                it (frac > 1).  Against the f16 matrix-core peak (2500 TFLOP/s dense, 3 MFMA FLOP per algorithmic FLOP)
+                the same kernel is at `frac_f16_mfma`; it is VALU-issue-bound (LayerNorm/SiLU/split), see DESIGN.md.
+                `step_roofline` gives the whole step against the float32 roof and the HBM roof.
   cpu_baseline  the CPU oracle (oracle/ddpm_oracle.py, the bit-checked restatement of the reference) timed on this
                 box's host cores on a bounded sample, converted to the same unit.
 """
@@ -54,10 +62,10 @@ def build_model(device, T, seed=0):
 
 def cpu_baseline(sample_rows=4096, steps=2, B_ref=65536):
     """Oracle timed on the host: `steps` reverse steps of a `sample_rows`-row batch.  The thread count is the best
-    of {all cores, 32, 16, 8} on a one-step probe (hundreds of small ATen ops oversubscribe a 128-core host)."""
+    of {32, 16, 8} on a one-step probe (hundreds of small ATen ops oversubscribe a 128-core host: all cores is slower)."""
     ncpu = os.cpu_count() or 1
     best = None
-    for nt in sorted({ncpu, min(ncpu, 32), min(ncpu, 16), min(ncpu, 8)}, reverse=True):
+    for nt in sorted({min(ncpu, 32), min(ncpu, 16), min(ncpu, 8)}, reverse=True):
         r = _cpu_baseline_run(nt, sample_rows, 1, B_ref)
         if best is None or r["row_steps_per_s"] > best["row_steps_per_s"]:
             best = r
@@ -135,6 +143,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="rows per GPU")
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["split_f16", "f32"], default="split_f16")
     ap.add_argument("--train-batch", type=int, default=32768, help="training rows per GPU (global 262144 on 8 GPUs)")
     ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--no-train", action="store_true")
@@ -158,6 +167,7 @@ def main():
     ddpm_k = build_model(dev, K)
     ddpm_w = build_model(dev, W)
     ddpm_w.model = ddpm_k.model          # one denoiser (one native handle, one captured graph) for both schedules
+    ddpm_k.model.set_precision(a.precision)
     g = torch.Generator().manual_seed(rank)
     cond = torch.rand(B, 80, generator=g).to(dev)
 
@@ -201,14 +211,16 @@ def main():
         out = {
             "metric": "ddpm_reverse_sample_steps_per_sec_msr80c", "value": world * K / dt, "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32(2xf16-split MFMA, f32 accumulate)" if a.precision == "split_f16" else "f32", "data": "synthetic",
             "config": {"workload": f"MSR-80c CFG reverse sampling, batch {B} x D=C=80 per GPU, UNet1D(proj 128, dims "
                                    f"(64,32,16,8), n_blocks 2), omega={a.omega:g}, device Philox noise; rows sharded, no collective",
                        "batch_per_gpu": B, "solution_dim": 80, "parallelism": f"rows x{world}"},
             "row_steps_per_s": world * K * B / dt,
-            "roofline": {"bound": "mfma", "kernel": f"k_resblock<128,linear-shortcut> ({len(dom)} launches/step: "
-                                                    f"{', '.join(r[0] for r in dom)})",
+            "roofline": {"bound": "mfma", "kernel": f"{'k_resblock_h' if a.precision == 'split_f16' else 'k_resblock'}<128,linear-shortcut> "
+                                                    f"({len(dom)} launches/step: {', '.join(r[0] for r in dom)})",
                          "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS,
+                         "frac_f16_mfma": (3 * ach / 2500.0) if a.precision == "split_f16" else None,
                          "traffic": traffic, "avg_launch_ms": avg_ms, "flop_per_launch": fl * B,
                          "share_of_step": ms_sum / sum(r[3] for r in prof)},
             "step_roofline": {"f_alg_per_row": F_ALG, "achieved_tflops": F_ALG * B / (step_ms * 1e-3) / 1e12,

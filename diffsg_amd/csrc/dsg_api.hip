@@ -137,6 +137,7 @@ struct dsg_handle {
     size_t zero_off = 0;        // 128 zero floats in the arena
     float* tb = nullptr;        // [entries][tb_stride]
     float* st = nullptr;        // [entries][td]
+    float* h1s = nullptr;       // [entries][td] Swish(lin1) of the time MLP
     float* tvals = nullptr;     // [entries]
     int* ts_ident = nullptr;    // [rows] identity index
     float* eps = nullptr;       // [2][rows][D]
@@ -171,6 +172,7 @@ struct dsg_handle {
     int* tr_ts = nullptr;        // [rows]
     float* tr_yt_rm = nullptr;   // [rows][D]
     float* tr_tsave = nullptr;   // emb | h1pre | h1s | tpre | d_st | d_h1s
+    long long* tw_dst_dev = nullptr; const float** tw_src_dev = nullptr; int tw_rows = 0;  // time_emb.weight rows of all blocks
     WgradDesc* wg_desc_dev = nullptr; WgradUnit* wg_unit_dev = nullptr; int wg_units = 0;
     ColsumDesc* cs_desc_dev = nullptr; ColsumUnit* cs_unit_dev = nullptr; int cs_units = 0;
 };
@@ -315,10 +317,10 @@ void free_train_workspace(dsg_handle* h) {
 void free_workspace(dsg_handle* h) {
     free_graphs(h);
     free_train_workspace(h);  // its descriptors point into the forward workspace
-    void* ptrs[] = {h->ws, h->condfrag, h->tb, h->st, h->tvals, h->ts_ident, h->eps, h->ywork, h->cembed, h->ce_stats};
+    void* ptrs[] = {h->ws, h->condfrag, h->tb, h->st, h->tvals, h->ts_ident, h->eps, h->ywork, h->cembed, h->ce_stats, h->h1s};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    h->cembed = h->ce_stats = nullptr;
+    h->cembed = h->ce_stats = h->h1s = nullptr;
     h->ws = h->condfrag = h->tb = h->st = h->tvals = h->eps = h->ywork = nullptr;
     h->ts_ident = nullptr;
     h->cap_rows = h->cap_entries = 0;
@@ -346,6 +348,7 @@ int ensure_workspace(dsg_handle* h, int rows, int entries) {
     HIPCK(hipMalloc(&h->ce_stats, (tiles / 2) * 64 * sizeof(float)));
     HIPCK(hipMalloc(&h->tb, (size_t)nent * h->tb_stride * sizeof(float)));
     HIPCK(hipMalloc(&h->st, (size_t)nent * h->td * sizeof(float)));
+    HIPCK(hipMalloc(&h->h1s, (size_t)nent * h->td * sizeof(float)));
     HIPCK(hipMalloc(&h->tvals, (size_t)nent * sizeof(float)));
     HIPCK(hipMalloc(&h->ts_ident, (size_t)nrows * sizeof(int)));
     HIPCK(hipMalloc(&h->eps, (size_t)2 * nrows * D * sizeof(float)));
@@ -619,16 +622,18 @@ void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
 void run_time_path(dsg_handle* h, int entries, hipStream_t s, bool train = false) {
     const int half = h->d.proj_dim / 2, td = h->td;
     const Param* P = h->params.data();
-    float *emb = nullptr, *h1pre = nullptr, *h1s = nullptr, *tpre = nullptr;
+    float *emb = nullptr, *h1pre = nullptr, *tpre = nullptr;
+    float* h1s = h->h1s;
     if (train) {
         emb = h->tr_tsave; h1pre = emb + (size_t)h->tr_T * 2 * half; h1s = h1pre + (size_t)h->tr_T * td;
         tpre = h1s + (size_t)h->tr_T * td;
     }
-    hipLaunchKernelGGL(k_time_embed, dim3(entries), dim3(256), (2 * half + td) * sizeof(float), s, h->tvals, h->freq, half,
-                       P[h->temb_l1w].ptr, P[h->temb_l1b].ptr, P[h->temb_l2w].ptr, P[h->temb_l2b].ptr, td, h->st, emb, h1pre, h1s, tpre);
+    const dim3 grid(entries, cdiv(td, 16));
+    hipLaunchKernelGGL(k_time_embed1, grid, dim3(256), 2 * half * sizeof(float), s, h->tvals, h->freq, half, P[h->temb_l1w].ptr,
+                       P[h->temb_l1b].ptr, td, h1s, emb, h1pre);
+    hipLaunchKernelGGL(k_time_embed2, grid, dim3(256), td * sizeof(float), s, h1s, P[h->temb_l2w].ptr, P[h->temb_l2b].ptr, td, h->st, tpre);
     const int nb = (int)h->res.size();
-    hipLaunchKernelGGL(k_time_table, dim3(entries, nb < 8 ? nb : 8), dim3(256), td * sizeof(float), s, h->st, td, h->tdesc_dev,
-                       nb, h->tb, h->tb_stride);
+    hipLaunchKernelGGL(k_time_table, dim3(entries, nb), dim3(256), td * sizeof(float), s, h->st, td, h->tdesc_dev, nb, h->tb, h->tb_stride);
 }
 
 int check_bound(const dsg_handle* h) {
@@ -906,7 +911,7 @@ void dsg_destroy(dsg_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev, h->maxabs,
-                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev};
+                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev, h->tw_dst_dev, (void*)h->tw_src_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1024,6 +1029,18 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
                 HIPCK(hipMemcpy(h->mx_numel_dev, mn.data(), mn.size() * sizeof(long long), hipMemcpyHostToDevice));
                 HIPCK(hipMemcpy(h->packh_dev, hd.data(), hd.size() * sizeof(PackHDesc), hipMemcpyHostToDevice));
             }
+        }
+        {   // time_emb.weight row tables (training time-path backward)
+            std::vector<long long> dst; std::vector<const float*> src;
+            for (const ResP& r : h->res)
+                for (int n = 0; n < r.N; ++n) { dst.push_back(P[r.te.w].off + (long long)n * h->td); src.push_back(P[r.te.w].ptr + (size_t)n * h->td); }
+            h->tw_rows = (int)dst.size();
+            if (!h->tw_dst_dev) {
+                HIPCK(hipMalloc(&h->tw_dst_dev, dst.size() * sizeof(long long)));
+                HIPCK(hipMalloc(&h->tw_src_dev, src.size() * sizeof(float*)));
+            }
+            HIPCK(hipMemcpy(h->tw_dst_dev, dst.data(), dst.size() * sizeof(long long), hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(h->tw_src_dev, src.data(), src.size() * sizeof(float*), hipMemcpyHostToDevice));
         }
         if (!h->pack_dev) HIPCK(hipMalloc(&h->pack_dev, pd.size() * sizeof(PackDesc)));
         h->pack_n = (int)pd.size();
@@ -1272,15 +1289,10 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
         float* tpre = h1s + (size_t)T * td;
         float* d_st = tpre + (size_t)T * td;
         float* d_h1s = d_st + (size_t)T * td;
-        bool first = true;
-        for (const ResP& r : h->res) {
-            const float* dtb = G + r.dtb_off;  // [N][T]
-            // d time_emb.weight[n][k] = sum_e dTB[n][e] * st[e][k]
-            small_gemm(dtb, T, 1, h->st, td, 1, G + P[r.te.w].off, td, 1, r.N, td, T, 0, s);
-            // d st[e][k] += sum_n dTB[n][e] * Wt[n][k]
-            small_gemm(dtb, 1, T, P[r.te.w].ptr, td, 1, d_st, td, 1, T, td, r.N, first ? 0 : 1, s);
-            first = false;
-        }
+        // all blocks at once: their dTB rows are contiguous from the first block's dtb_off
+        const float* dtb_all = G + h->res[0].dtb_off;
+        hipLaunchKernelGGL(k_time_wgrad, dim3(2048), dim3(256), 0, s, dtb_all, T, h->st, td, h->tw_dst_dev, G, h->tw_rows);
+        hipLaunchKernelGGL(k_time_dgrad, dim3(cdiv(T * td, 256)), dim3(256), 0, s, dtb_all, T, h->tw_src_dev, td, d_st, h->tw_rows);
         const unsigned eb = (unsigned)cdiv(T * td, 256);
         hipLaunchKernelGGL(k_mul_silu_grad, dim3(eb), dim3(256), 0, s, d_st, tpre, (size_t)T * td);          // d temb (pre-Swish)
         small_gemm(d_st, 1, td, h1s, td, 1, G + P[h->temb_l2w].off, td, 1, td, td, T, 0, s);                   // d lin2.weight

@@ -628,39 +628,44 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// one workgroup (256 threads) per entry e; tvals[e] is t (already divided by T)
-__global__ __launch_bounds__(256) void k_time_embed(const float* __restrict__ tvals, const float* __restrict__ freq, int half,
-                                                    const float* __restrict__ W1, const float* __restrict__ b1,
-                                                    const float* __restrict__ W2, const float* __restrict__ b2, int td,
-                                                    float* __restrict__ st, float* __restrict__ save_emb, float* __restrict__ save_h1pre,
-                                                    float* __restrict__ save_h1s, float* __restrict__ save_tpre) {
-    extern __shared__ float sm[];
-    float* e = sm;            // [2*half]
-    float* h1 = sm + 2 * half;  // [td]
+// Stage 1: emb = [sin, cos](t * freq), h1 = Swish(lin1 emb).  grid = (entries, ceil(td / 16)); one wave per output.
+__global__ __launch_bounds__(256) void k_time_embed1(const float* __restrict__ tvals, const float* __restrict__ freq, int half,
+                                                     const float* __restrict__ W1, const float* __restrict__ b1, int td,
+                                                     float* __restrict__ h1s, float* __restrict__ save_emb, float* __restrict__ save_h1pre) {
+    extern __shared__ float sm[];  // [2*half]
     const int ent = blockIdx.x;
     const float t = tvals[ent];
     for (int i = threadIdx.x; i < half; i += blockDim.x) {
         const float ang = t * freq[i];
-        e[i] = sinf(ang);
-        e[half + i] = cosf(ang);
-        if (save_emb) { save_emb[(size_t)ent * 2 * half + i] = e[i]; save_emb[(size_t)ent * 2 * half + half + i] = e[half + i]; }
+        sm[i] = sinf(ang);
+        sm[half + i] = cosf(ang);
+        if (save_emb && blockIdx.y == 0) { save_emb[(size_t)ent * 2 * half + i] = sm[i]; save_emb[(size_t)ent * 2 * half + half + i] = sm[half + i]; }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K1 = 2 * half;
-    for (int n = wave; n < td; n += nw) {
+    for (int n = blockIdx.y * 16 + wave; n < td && n < (int)(blockIdx.y + 1) * 16; n += 4) {
         float s = 0.f;
-        for (int k = lane; k < K1; k += 64) s = fmaf(W1[(size_t)n * K1 + k], e[k], s);
+        for (int k = lane; k < K1; k += 64) s = fmaf(W1[(size_t)n * K1 + k], sm[k], s);
         s = wave_sum(s) + b1[n];
         if (lane == 0) {
-            h1[n] = silu(s);
-            if (save_h1pre) { save_h1pre[(size_t)ent * td + n] = s; save_h1s[(size_t)ent * td + n] = h1[n]; }
+            h1s[(size_t)ent * td + n] = silu(s);
+            if (save_h1pre) save_h1pre[(size_t)ent * td + n] = s;
         }
     }
+}
+
+// Stage 2: st = Swish(lin2 h1).  Same grid.
+__global__ __launch_bounds__(256) void k_time_embed2(const float* __restrict__ h1s, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                     int td, float* __restrict__ st, float* __restrict__ save_tpre) {
+    extern __shared__ float sm[];  // [td]
+    const int ent = blockIdx.x;
+    for (int i = threadIdx.x; i < td; i += blockDim.x) sm[i] = h1s[(size_t)ent * td + i];
     __syncthreads();
-    for (int n = wave; n < td; n += nw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = blockIdx.y * 16 + wave; n < td && n < (int)(blockIdx.y + 1) * 16; n += 4) {
         float s = 0.f;
-        for (int k = lane; k < td; k += 64) s = fmaf(W2[(size_t)n * td + k], h1[k], s);
+        for (int k = lane; k < td; k += 64) s = fmaf(W2[(size_t)n * td + k], sm[k], s);
         s = wave_sum(s) + b2[n];
         if (lane == 0) {
             st[(size_t)ent * td + n] = silu(s);
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(256) void k_time_table(const float* __restrict__ st
     for (int i = threadIdx.x; i < td; i += blockDim.x) sm[i] = st[(size_t)ent * td + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int b = blockIdx.y; b < nblocks; b += gridDim.y) {
+    for (int b = blockIdx.y; b < nblocks; b += gridDim.y) {  // gridDim.y == nblocks: one block of the net per workgroup
         const TimeBlockDesc d = blocks[b];
         const int npad = (d.N + 31) / 32 * 32;
         for (int n = wave; n < npad; n += nw) {

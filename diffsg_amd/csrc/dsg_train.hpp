@@ -687,6 +687,31 @@ __global__ void k_small_gemm(const float* __restrict__ A, long long ai, long lon
     }
 }
 
+// Time-path gradients over ALL blocks in two launches.  dTB rows (one per block output feature, `nrows_all` in total,
+// each of length T) are contiguous; wt_row[r] / dst_row[r] give the matching time_emb.weight row and its gradient row.
+//   d time_emb.weight[r][k] = sum_e dTB[r][e] * st[e][k]
+__global__ void k_time_wgrad(const float* __restrict__ dtb, int T, const float* __restrict__ st, int td,
+                             const long long* __restrict__ dst_row, float* __restrict__ G, int nrows_all) {
+    const long long total = (long long)nrows_all * td;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int k = idx % td, r = idx / td;
+        float s = 0.f;
+        for (int e = 0; e < T; ++e) s = fmaf(dtb[(size_t)r * T + e], st[(size_t)e * td + k], s);
+        G[dst_row[r] + k] = s;
+    }
+}
+//   d st[e][k] = sum_r dTB[r][e] * Wt_row(r)[k]
+__global__ void k_time_dgrad(const float* __restrict__ dtb, int T, const float* const* __restrict__ wt_row, int td,
+                             float* __restrict__ d_st, int nrows_all) {
+    const long long total = (long long)T * td;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int k = idx % td, e = idx / td;
+        float s = 0.f;
+        for (int r = 0; r < nrows_all; ++r) s = fmaf(dtb[(size_t)r * T + e], wt_row[r][k], s);
+        d_st[idx] = s;
+    }
+}
+
 // x[i] *= swish'(pre[i])
 __global__ void k_mul_silu_grad(float* __restrict__ x, const float* __restrict__ pre, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
