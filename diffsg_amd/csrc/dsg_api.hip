@@ -538,7 +538,7 @@ void launch_lin_h(int N, int inmode, int outmode, bool lnact, const LinArgsH& a,
     }
 }
 
-bool split_ctx(const dsg_handle* h, const RunCtx& c) { return h->use_split && c.cond_pre && !c.train; }
+bool split_ctx(const dsg_handle* h, const RunCtx& c) { return h->use_split && c.cond_pre; }
 
 void launch_op(const dsg_handle* h, const Op& op, const RunCtx& c, hipStream_t s) {
     if (op.kind == OP_RES) {
@@ -634,6 +634,21 @@ void run_time_path(dsg_handle* h, int entries, hipStream_t s, bool train = false
     hipLaunchKernelGGL(k_time_embed2, grid, dim3(256), td * sizeof(float), s, h1s, P[h->temb_l2w].ptr, P[h->temb_l2b].ptr, td, h->st, tpre);
     const int nb = (int)h->res.size();
     hipLaunchKernelGGL(k_time_table, dim3(entries, nb), dim3(256), td * sizeof(float), s, h->st, td, h->tdesc_dev, nb, h->tb, h->tb_stride);
+}
+
+// cembed[block] = Wc silu(cond * mask) for every block from the condition fragments (one launch per block)
+void run_cond_embed(dsg_handle* h, int B, hipStream_t s) {
+    const int tpp = cdiv(B, 32), CG = groups_of(h->d.cond_dim);
+    for (const ResP& r : h->res) {
+        LinArgs a;
+        memset(&a, 0, sizeof a);
+        a.in.data = h->condfrag; a.in.groups = CG; a.in.width = h->d.cond_dim;
+        a.in_width = h->d.cond_dim; a.in_groups = CG;
+        a.W = h->arena + r.Wcp; a.bias = h->arena + h->zero_off;
+        a.out = h->cembed + r.ce_off * (cap_tiles_of(h) / 2); a.out_stats = h->ce_stats; a.out_width = r.N;
+        a.ntiles = tpp; a.tiles_per_pass = tpp; a.nrows = B;
+        launch_lin(r.N, IN_FRAG, OUT_FRAG, false, a, s);
+    }
 }
 
 int check_bound(const dsg_handle* h) {
@@ -1143,16 +1158,7 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
     hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tpp * CG * 256, 256)), dim3(256), 0, s, cond, (const float*)nullptr, B,
                        h->d.cond_dim, CG, h->condfrag, tpp);
     // condition embeddings of every block, once per call: cond is the same in all T steps (MSR.py:126-127)
-    for (const ResP& r : h->res) {
-        LinArgs a;
-        memset(&a, 0, sizeof a);
-        a.in.data = h->condfrag; a.in.groups = CG; a.in.width = h->d.cond_dim;
-        a.in_width = h->d.cond_dim; a.in_groups = CG;
-        a.W = h->arena + r.Wcp; a.bias = h->arena + h->zero_off;
-        a.out = h->cembed + r.ce_off * (cap_tiles_of(h) / 2); a.out_stats = h->ce_stats; a.out_width = r.N;
-        a.ntiles = tpp; a.tiles_per_pass = tpp; a.nrows = B;
-        launch_lin(r.N, IN_FRAG, OUT_FRAG, false, a, s);
-    }
+    run_cond_embed(h, B, s);
     if (y_T) HIPCK(hipMemcpyAsync(h->ywork, y_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     else hipLaunchKernelGGL(k_randn, dim3(2048), dim3(256), 0, s, h->ywork, n, seed, 0xFFFFFFFFu);
     const int start = T - 1;
@@ -1227,7 +1233,9 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tiles * CG * 256, 256)), dim3(256), 0, s, cond, cond_mask, B, C, CG, h->condfrag, tiles);
     hipLaunchKernelGGL(k_qsample, dim3(cdiv(tiles * DG * 256, 256)), dim3(256), 0, s, y, noise, h->tr_ts, sqrt_acp, sqrt_1m_acp, B, D,
                        h->tr_yt_rm, trp(h, h->tr_yt_frag), tiles);
-    RunCtx c{B, 1, 0, h->tr_yt_rm, h->eps, nullptr, h->tr_ts, true, false};
+    // the forward may run on the split-f16 kernels (they need the condition embeddings as an additive term)
+    if (h->use_split) run_cond_embed(h, B, s);
+    RunCtx c{B, 1, 0, h->tr_yt_rm, h->eps, nullptr, h->tr_ts, true, h->use_split};
     run_unet(h, c, s);
     hipLaunchKernelGGL(k_loss_grad, dim3(kRedBlocks), dim3(256), 0, s, h->eps, noise, B, D, trp(h, h->tr_deps), tiles, h->red);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, s, h->red, kRedBlocks, (double)B * (double)D, loss_out);

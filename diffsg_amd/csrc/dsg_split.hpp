@@ -191,7 +191,8 @@ struct BlockArgsH {
     const float* msc;
 };
 
-// Inference only (sampling): needs cond_pre (the condition embedding is added, never multiplied here).
+// Needs cond_pre: the condition embedding Wc silu(cond*mask) is precomputed per call (sampling) or per step (training)
+// and added here, never multiplied.
 template <int N, bool SCLIN>
 __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
@@ -244,6 +245,13 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         }
         acc_unscale_add<NT>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
     }
+    if (a.save_h1) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+            st4(a.save_h1 + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc1[G >> 2][4 * (G & 3)], acc1[G >> 2][4 * (G & 3) + 1], acc1[G >> 2][4 * (G & 3) + 2],
+                            acc1[G >> 2][4 * (G & 3) + 3]));
+    }
 
     // ---- stage 2
     f32x16 acc2[NT];
@@ -266,6 +274,13 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
             acc2[G >> 2][4 * (G & 3) + 0] += cv.x; acc2[G >> 2][4 * (G & 3) + 1] += cv.y;
             acc2[G >> 2][4 * (G & 3) + 2] += cv.z; acc2[G >> 2][4 * (G & 3) + 3] += cv.w;
         }
+    }
+    if (a.save_h2) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+            st4(a.save_h2 + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc2[G >> 2][4 * (G & 3)], acc2[G >> 2][4 * (G & 3) + 1], acc2[G >> 2][4 * (G & 3) + 2],
+                            acc2[G >> 2][4 * (G & 3) + 3]));
     }
 
     // ---- stage 3 (+ shortcut in the same scaled accumulator)
