@@ -29,6 +29,11 @@ class DDPM(DDPMCore):
         self._setup(T, model, alphas, device, data_size, custom_config, uncond_prob, ema_decay, ema_start,
                     ema_update_rate, debug)
 
+    def _decode_recorded(self, i, y):
+        """classifier_free_CO.py:94-96."""
+        from .decode import co_decode
+        return co_decode(y)
+
 
 def data_preprocess_co(X):
     """utils/dataset.py:26-51: (6 per-node + 7 common raw features) -> 3 cost features per node

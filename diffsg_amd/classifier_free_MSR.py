@@ -31,6 +31,11 @@ class DDPM(DDPMCore):
         self._setup(T, model, alphas, device, data_size, custom_config, uncond_prob, ema_decay, ema_start,
                     ema_update_rate, debug)
 
+    def _decode_recorded(self, i, y):
+        """classifier_free_MSR.py:145-151: row softmax for the first three recorded states, the MSR decoder afterwards."""
+        from .decode import msr_decode
+        return torch.softmax(y, dim=1) if i <= 2 else msr_decode(y)
+
 
 def msr_data_load(dataset_path):
     """classifier_free_MSR.py:159-184.  CSV columns: M gains | 1 rate | M powers.  W comes from the FILE NAME

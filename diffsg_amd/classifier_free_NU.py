@@ -29,6 +29,13 @@ class DDPM(DDPMCore):
         self._setup(T, model, alphas, device, data_size, custom_config, uncond_prob, ema_decay, ema_start,
                     ema_update_rate, debug)
 
+    def _decode_recorded(self, i, y):
+        """classifier_free_NU.py:174-176 (the reference's branch reads undefined globals; width / height come from
+        custom_config here)."""
+        from .decode import nu_decode
+        cc = self.custom_config or {}
+        return nu_decode(y, cc.get("width", 400), cc.get("height", 400), self.P_sum)
+
 
 def nu_data_load(dataset_path, width, height):
     """classifier_free_NU.py:184-210.  CSV columns: 2K user coords | 2 UAV coords | K powers | 1 rate.  P_sum comes

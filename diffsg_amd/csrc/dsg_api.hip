@@ -1128,6 +1128,7 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
         hipLaunchKernelGGL(k_renorm_sqdiff, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
         hipLaunchKernelGGL(k_renorm_apply, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
     }
+    hipLaunchKernelGGL(k_record, dim3(ublocks), dim3(256), 0, s, u.y, u.n, u.cp, u.step_ptr);
     hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, s, h->step_dev);
     HIPCK(hipGetLastError());
     if (ev) {
@@ -1142,8 +1143,16 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
     return 0;
 }
 
+int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed, float omega,
+                   const float* coef, int T, float* out, int B, int flags, float* rec_y, float* rec_eps, void* stream);
+
 int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed, float omega,
                const float* coef, int T, float* out, int B, int flags, void* stream) {
+    return dsg_sample_rec(h, cond, y_T, noise, seed, omega, coef, T, out, B, flags, nullptr, nullptr, stream);
+}
+
+int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed, float omega,
+                   const float* coef, int T, float* out, int B, int flags, float* rec_y, float* rec_eps, void* stream) {
     if (check_bound(h)) return 1;
     if (B < 1 || T < 1) return fail("B and T must be >= 1");
     if (!coef || !cond || !out) return fail("dsg_sample: null pointer argument");
@@ -1163,7 +1172,7 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
     else hipLaunchKernelGGL(k_randn, dim3(2048), dim3(256), 0, s, h->ywork, n, seed, 0xFFFFFFFFu);
     const int start = T - 1;
     HIPCK(hipMemcpyAsync(h->step_dev, &start, sizeof(int), hipMemcpyHostToDevice, s));
-    const CallParams cp{noise, coef, omega, T, seed};
+    const CallParams cp{noise, coef, omega, T, seed, rec_y, rec_eps};
     HIPCK(hipMemcpyAsync(h->call_dev, &cp, sizeof cp, hipMemcpyHostToDevice, s));
     HIPCK(hipStreamSynchronize(s));  // `start` and `cp` are host temporaries
 

@@ -386,7 +386,7 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
 template <int N, bool SCLIN>
 __global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.ntiles) return;
     resblock_body<N, SCLIN>(a, tile, lane);
 }
@@ -495,7 +495,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, const int tile, co
 template <int NT, int INMODE, int OUTMODE, bool LNACT>
 __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.ntiles) return;
     linear_body<NT, INMODE, OUTMODE, LNACT>(a, tile, lane);
 }
@@ -517,7 +517,7 @@ struct FusedOp {
 
 __global__ __launch_bounds__(256, 4) void k_fused_narrow(const FusedOp* __restrict__ ops, int nops, int ntiles) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= ntiles) return;
     for (int i = 0; i < nops; ++i) {
         const FusedOp& op = ops[i];
@@ -763,6 +763,8 @@ struct CallParams {
     float omega;
     int T;
     unsigned long long seed;
+    float* rec_y;         // record_denoise_path (MSR.py:139-141): [T][n] y after each step (after the renorm), or null
+    float* rec_eps;       // [T][n] guided eps of each step, or null
 };
 
 struct UpdateArgs {
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a) {
             if (i < a.n) {
                 if (zrow) zz[p] = zrow[i];
                 const float e = __fsub_rn(__fmul_rn(w1, a.eps[a.n + i]), __fmul_rn(omega, a.eps[i]));
+                if (cp.rec_eps) cp.rec_eps[(size_t)(cp.T - 1 - step) * a.n + i] = e;
                 const float v = __fmul_rn(__fsub_rn(a.y[i], __fmul_rn(c1, e)), c2);
                 a.y[i] = noisy ? __fadd_rn(v, __fmul_rn(c3, zz[p])) : v;
             }
@@ -806,6 +809,14 @@ __global__ void k_randn(float* __restrict__ y, size_t n, unsigned long long seed
         for (int p = 0; p < 4; ++p)
             if (i4 * 4 + p < n) y[i4 * 4 + p] = zz[p];
     }
+}
+
+// device-side trajectory ring (replaces the reference's per-step .cpu().numpy(), MSR.py:139-141); no-op when disabled
+__global__ void k_record(const float* __restrict__ y, size_t n, const CallParams* __restrict__ cp, const int* __restrict__ step_ptr) {
+    float* dst = cp->rec_y;
+    if (!dst) return;
+    dst += (size_t)(cp->T - 1 - *step_ptr) * n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = y[i];
 }
 
 __global__ void k_step_advance(int* step_ptr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr -= 1; }

@@ -330,7 +330,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
 template <int N, bool SCLIN>
 __global__ __launch_bounds__(256, 2) void k_resblock_h(const BlockArgsH ah) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= ah.b.ntiles) return;
     resblock_body_h<N, SCLIN>(ah, tile, lane);
 }
@@ -426,7 +426,7 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
 template <int NT, int INMODE, int OUTMODE, bool LNACT>
 __global__ __launch_bounds__(256) void k_linear_h(const LinArgsH a) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.l.ntiles) return;
     linear_body_h<NT, INMODE, OUTMODE, LNACT>(a, tile, lane);
 }
@@ -440,7 +440,7 @@ struct FusedOpH {
 
 __global__ __launch_bounds__(256, 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= ntiles) return;
     for (int i = 0; i < nops; ++i) {
         const FusedOpH& op = ops[i];

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_resblock_bwd(const BlockBwdArgs a) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
     constexpr int KGT = SCLIN ? (2 * NG + 3) / 4 : NT;  // 32-feature output tiles of dL/dx
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.ntiles) return;
     const int h = lane >> 5, j = lane & 31;
     const int KG = a.in0.groups + a.in1.groups;
@@ -357,7 +357,7 @@ struct LinBwdArgs {
 template <int OT, bool LNBWD>
 __global__ __launch_bounds__(256) void k_linear_bwd(const LinBwdArgs a) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.ntiles) return;
     const int h = lane >> 5, j = lane & 31;
     const int NGo = a.out_groups, KG = a.in.groups;

@@ -96,17 +96,28 @@ class DDPMCore(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         coef = self._coef_table()
         out = torch.empty(B, D, device=dev, dtype=torch.float32)
-        if self.record_denoise_path:
-            raise NotImplementedError("record_denoise_path (MSR.py:139-154) is SURVEY 8(f)-3, not built yet")
+        rec = torch.empty(2, T, B, D, device=dev, dtype=torch.float32) if self.record_denoise_path else None
         flags = 2 if profile else (0 if use_graph else 1)
         # T <= 2 has no noisy step (MSR.py:129): a null pointer (= device Philox) is then never dereferenced
         zptr = _lib.ptr(noise) if (noise is not None and noise.numel()) else _lib.ptr(None)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().dsg_sample(hd, _lib.ptr(cond), _lib.ptr(y_T), zptr, seed, float(omega), _lib.ptr(coef), T,
-                                             _lib.ptr(out), B, flags, _lib.stream_ptr()))
+            _lib.check(_lib.lib().dsg_sample_rec(hd, _lib.ptr(cond), _lib.ptr(y_T), zptr, seed, float(omega), _lib.ptr(coef), T,
+                                                 _lib.ptr(out), B, flags, _lib.ptr(rec[0]) if rec is not None else _lib.ptr(None),
+                                                 _lib.ptr(rec[1]) if rec is not None else _lib.ptr(None), _lib.stream_ptr()))
+        if rec is not None:
+            # one device-to-host copy of the whole trajectory instead of the reference's 2T per-step copies (MSR.py:140-141);
+            # then the reference's post-processing (MSR.py:143-154): decode every recorded y, lay out as (B, T*D)
+            ys = rec[0].cpu()
+            ys = torch.stack([self._decode_recorded(i, ys[i]) for i in range(T)]).numpy()
+            self.y_i_record = ys.transpose(1, 0, 2).reshape(B, -1)
+            self.eps_i_record = rec[1].cpu().numpy().transpose(1, 0, 2).reshape(B, -1)
         # the call only enqueues: keep its inputs alive until the next call on this object
         self._keepalive = (cond, y_T, noise, coef)
         return out
+
+    def _decode_recorded(self, i, y):
+        """Post-processing of the i-th recorded state (problem specific; overridden by the problem modules)."""
+        return y
 
     def op_profile(self):
         """[(name, algorithmic flops/row/step, algorithmic bytes/row/step, ms_total, launches)] of the last

@@ -75,6 +75,13 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
 int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed,
                float omega, const float* coef, int T, float* out, int B, int flags, void* stream);
 
+/* dsg_sample with the denoise trajectory recorded on the device (DDPM.record_denoise_path, classifier_free_MSR.py:139-141):
+ * rec_y / rec_eps [T][B][D] receive y_t (after the early-step renorm) and the guided eps of every step, first step first;
+ * either may be NULL.  Replaces the reference's per-step device-to-host copies. */
+int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed,
+                   float omega, const float* coef, int T, float* out, int B, int flags, float* rec_y, float* rec_eps,
+                   void* stream);
+
 /* One training step's forward + backward: loss = DDPM.forward(y, cond) (classifier_free_MSR.py:100-112) and
  * d(loss)/d(theta) for every denoiser tensor, as `loss.backward()` produces them (classifier_free_MSR.py:223-224).
  *   y [B][D], cond [B][C] row-major;  ts [B] int32 in [0,T);  noise [B][D];  cond_mask [B] (0/1) -- the three random

@@ -253,6 +253,14 @@ def g4():
             for omega in (0.0, 1.0, 3.0):
                 torch.manual_seed(seed)
                 out[f"om{omega:g}_y0"] = ddpm.sample(cond, omega).numpy()
+        if name == "tiny" and T == 8:
+            torch.manual_seed(seed)
+            ddpm.record_denoise_path = True
+            with torch.no_grad():
+                y0 = ddpm.sample(cond, 1.0)
+            save("g4_record_tiny_T8.npz", y_i_record=ddpm.y_i_record.astype(np.float32), eps_i_record=ddpm.eps_i_record.astype(np.float32),
+                 y0=y0.numpy())
+            ddpm.record_denoise_path = False
         save(f"g4_sample_{name}_T{T}.npz", **out)
 
 

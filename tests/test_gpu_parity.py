@@ -301,3 +301,20 @@ def test_entry_points_train_save_load_eval(tmp_path):
     ck = str(tmp_path / "ddpm_co.pt")
     torch.save(m.state_dict(), ck)
     assert np.isfinite(CO.load_test_co(ck, os.path.join(dd, "3nodes_200samples_ood.csv"), omega=1.0, log=logs.append)["exceeded_ratio"])
+
+
+def test_record_denoise_path(gold):
+    """record_denoise_path (classifier_free_MSR.py:139-154): the (B, T*D) trajectory arrays of the reference, filled from
+    the device-side ring instead of per-step host copies."""
+    T = 8
+    g, r = gold(f"g4_sample_tiny_T{T}.npz"), gold("g4_record_tiny_T8.npz")
+    plan, p = synth_params("tiny", 31)
+    ddpm = make_ddpm("tiny", p, T)
+    ddpm.record_denoise_path = True
+    y0 = ddpm.sample(torch.from_numpy(g["cond"]).cuda(), 1.0, y_T=torch.from_numpy(g["y_T"]), noise=_z(g, T))
+    assert rel(y0, r["y0"]) <= 1e-4
+    assert ddpm.y_i_record.shape == r["y_i_record"].shape and ddpm.eps_i_record.shape == r["eps_i_record"].shape
+    assert rel(ddpm.eps_i_record, r["eps_i_record"]) <= 1e-4
+    assert rel(ddpm.y_i_record, r["y_i_record"]) <= 1e-4
+    ddpm.record_denoise_path = False
+    assert torch.equal(ddpm.sample(torch.from_numpy(g["cond"]).cuda(), 1.0, y_T=torch.from_numpy(g["y_T"]), noise=_z(g, T)), y0)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Reverse-sampling throughput on the other BASELINE.json configs (single GPU): steps/s and row-steps/s.
+    python tools/bench_configs.py"""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import torch
+from weights import CONFIGS
+from diffsg_amd import UNet1D, generate_cosine_schedule, init_weights
+from diffsg_amd.classifier_free_MSR import DDPM
+
+dev = torch.device("cuda:0")
+out = []
+for name, B, T, omega in (("msr3", 8192, 1000, 1.0), ("msr3", 512, 20, 500.0), ("co3", 8192, 200, 1.0), ("nu3", 8192, 200, 1.0),
+                          ("msr80", 8192, 200, 1.0), ("msr80", 512, 20, 500.0)):
+    cfg = CONFIGS[name]
+    torch.manual_seed(0)
+    m = UNet1D(**cfg, is_attn=(False,) * len(cfg["dims"]))
+    D = cfg["input_dim"]
+    d = DDPM(T, m, D, 10.0, 1.0 - generate_cosine_schedule(T), dev, (1, D), None)
+    d.apply(init_weights)
+    d.to(dev)
+    cond = torch.rand(B, cfg["cond_dim"], device=dev)
+    d.sample(cond, omega, seed=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3 if T <= 20 else 1
+    for _ in range(reps):
+        y = d.sample(cond, omega, seed=2)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out.append(dict(config=name, B=B, T=T, omega=omega, ms_per_call=dt * 1e3, steps_per_s=T / dt, row_steps_per_s=B * T / dt,
+                    finite=bool(torch.isfinite(y).all())))
+    print(out[-1])
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
