@@ -587,6 +587,7 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
             FusedOpH& f = h->fusedh_host[i];
             memset(&f, 0, sizeof f);
             f.kind = kind; f.N = N; f.sclin = sclin;
+            f.store_out = (h->tensors[op.out].is_skip || i == n - 1) ? 1 : 0;
             if (kind == 0) fill_block_args_h(h, h->res[op.p], b, f.b); else fill_lin_args_h(h, h->lin[op.p], l, f.l);
         } else {
             FusedOp& f = h->fused_host[i];

@@ -96,9 +96,9 @@ __device__ __forceinline__ void act8(float (&v)[8], const float4 x0, const float
 template <int N, int NT>
 __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16 (&in)[NT], const uint4* __restrict__ wp,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float mean, float rstd,
-                                                 int lane, int h) {
+                                                 int lane, int h, size_t nt_stride_override = 0) {
     constexpr int KS = ((N + 7) / 8 + 1) / 2;
-    const size_t nt_stride = (size_t)KS * 128;
+    const size_t nt_stride = nt_stride_override ? nt_stride_override : (size_t)KS * 128;
     const float c = rstd, d = -mean * rstd;
     HFrag<NT> wn;
     float4 gn0, bn0, gn1, bn1;
@@ -121,6 +121,28 @@ __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16
         h8 bhi, blo;
         split8(v, bhi, blo);
         mfma_step_h<NT>(out, wc, bhi, blo);
+    }
+}
+
+// Register-fed RAW stage (no LayerNorm / SiLU): Linear shortcut and the plain Linears of the narrow run when their input
+// lives in registers.  `groups` (runtime, <= 4*NT) real groups; the missing group of an odd count is accumulator padding.
+template <int NT>
+__device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f32x16 (&in)[NT], int groups, const uint4* __restrict__ wp,
+                                                     size_t nt_stride, int lane) {
+    const int steps = (groups + 1) >> 1;
+#pragma unroll
+    for (int S = 0; S < 2 * NT; ++S) {
+        if (S < steps) {
+            HFrag<NT> w;
+            load_hfrag<NT>(w, wp + (size_t)S * 128 + lane, nt_stride);
+            const int t = S >> 1, r0 = 8 * (S & 1);
+            float v[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) v[p] = kRawScale * in[t][r0 + p];
+            h8 bhi, blo;
+            split8(v, bhi, blo);
+            mfma_step_h<NT>(out, w, bhi, blo);
+        }
     }
 }
 
@@ -193,8 +215,11 @@ struct BlockArgsH {
 
 // Needs cond_pre: the condition embedding Wc silu(cond*mask) is precomputed per call (sampling) or per step (training)
 // and added here, never multiplied.
-template <int N, bool SCLIN>
-__device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane) {
+// XREG (narrow run): in0 is not read from memory but handed over in registers `xr` with its row statistics, and the
+// output goes back into `xr` (it is stored only when `store_out`, i.e. when something outside this wave's run reads it).
+template <int N, bool SCLIN, bool XREG = false>
+__device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane, f32x16 (*xr)[(N + 31) / 32] = nullptr,
+                                                float* xr_mean = nullptr, float* xr_m2 = nullptr, bool store_out = true) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
     const BlockArgs& a = ah.b;
     const int h = lane >> 5, j = lane & 31;
@@ -204,8 +229,9 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     // ---- LN1 statistics (Chan merge of the producers' (mean, M2))
     float mean1, rstd1;
     {
-        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
-        float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
+        float mean, m2, n = (float)a.in0.width;
+        if (XREG) { mean = *xr_mean; m2 = *xr_m2; }
+        else { const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j]; mean = s0.x; m2 = s0.y; }
         if (a.in1.groups) {
             const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
             const float n1 = (float)a.in1.width, nt_ = n + n1;
@@ -229,8 +255,11 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
     {
         const size_t nt_stride = (size_t)KS1 * 128;
-        chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
-                                   a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
+        if (XREG)   // in0 has the block's own width N here (down / middle: in = N; up: cat(N, N))
+            chain_from_acc_h<N, NT>(acc1, *xr, ah.W1h, a.gamma1, a.beta1, mean1, rstd1, lane, h, nt_stride);
+        else
+            chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
+                                       a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
         if (a.in1.groups)
             chain_from_mem_h<NT, true>(acc1, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                        ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, a.gamma1 + 8 * a.in0.groups + 4 * h,
@@ -297,33 +326,48 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     }
     if (SCLIN) {
         const size_t nt_stride = (size_t)KS1 * 128;
-        chain_from_mem_h<NT, false>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
-                                    nullptr, nullptr, 0.f, 1.f);
+        if (XREG)
+            chain_raw_from_reg_h<NT>(acc3, *xr, a.in0.groups, ah.Wsch, nt_stride, lane);
+        else
+            chain_from_mem_h<NT, false>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
+                                        nullptr, nullptr, 0.f, 1.f);
         if (a.in1.groups)
             chain_from_mem_h<NT, false>(acc3, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                         ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f);
         acc_unscale_add<NT>(acc3, inv3, a.c3, h);
     } else {
         acc_unscale_add<NT>(acc3, inv3, a.c3, h);
-        const float* xp = a.in0.data + (size_t)tile * NG * 256 + lane * 4;
+        if (XREG) {
 #pragma unroll
-        for (int G = 0; G < NG; ++G) {
-            const float4 xv = ld4(xp + (size_t)G * 256);
-            acc3[G >> 2][4 * (G & 3) + 0] += xv.x; acc3[G >> 2][4 * (G & 3) + 1] += xv.y;
-            acc3[G >> 2][4 * (G & 3) + 2] += xv.z; acc3[G >> 2][4 * (G & 3) + 3] += xv.w;
+            for (int nt = 0; nt < NT; ++nt) acc3[nt] += (*xr)[nt];
+        } else {
+            const float* xp = a.in0.data + (size_t)tile * NG * 256 + lane * 4;
+#pragma unroll
+            for (int G = 0; G < NG; ++G) {
+                const float4 xv = ld4(xp + (size_t)G * 256);
+                acc3[G >> 2][4 * (G & 3) + 0] += xv.x; acc3[G >> 2][4 * (G & 3) + 1] += xv.y;
+                acc3[G >> 2][4 * (G & 3) + 2] += xv.z; acc3[G >> 2][4 * (G & 3) + 3] += xv.w;
+            }
         }
     }
 
-    // ---- store + statistics
+    // ---- statistics + store (XREG: hand the tensor on in registers; store only if something else reads it)
     {
         float mean, m2;
         acc_stats<N, NT>(acc3, h, mean, m2);
-        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
+        if (XREG) {
 #pragma unroll
-        for (int G = 0; G < NG; ++G)
-            st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
-                make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2],
-                            acc3[G >> 2][4 * (G & 3) + 3]));
+            for (int nt = 0; nt < NT; ++nt) (*xr)[nt] = acc3[nt];
+            *xr_mean = mean; *xr_m2 = m2;
+        }
+        if (!XREG || store_out) {
+            if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
+#pragma unroll
+            for (int G = 0; G < NG; ++G)
+                st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                    make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2],
+                                acc3[G >> 2][4 * (G & 3) + 3]));
+        }
     }
 }
 
@@ -431,39 +475,109 @@ __global__ __launch_bounds__(256) void k_linear_h(const LinArgsH a) {
     linear_body_h<NT, INMODE, OUTMODE, LNACT>(a, tile, lane);
 }
 
-// The narrow run on the split path (see k_fused_narrow).
+// The narrow run on the split path (see k_fused_narrow), with the running tensor kept in REGISTERS between operators:
+// every operator here is at most 32 wide (one accumulator tile), so `x` + its (mean, M2) are 18 registers.  An operator
+// stores its output only when `store_out` (skip tensors and the last operator); skip inputs still come from memory.
 struct FusedOpH {
-    int kind, N, sclin, pad;
+    int kind, N, sclin, store_out;
     BlockArgsH b;
     LinArgsH l;
 };
 
+// Linear with register input (in width <= 32) and register output (out width <= 32)
+__device__ __forceinline__ void linear_reg_h(const LinArgsH& ah, const int tile, const int lane, f32x16 (&x)[1], float& xmean, float& xm2,
+                                             bool store_out) {
+    const LinArgs& a = ah.l;
+    const int h = lane >> 5, j = lane & 31;
+    const int KS = (a.in_groups + 1) >> 1;
+    f32x16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+    chain_raw_from_reg_h<1>(acc, x, a.in_groups, ah.Wh, (size_t)KS * 128, lane);
+    acc_unscale_add<1>(acc, ldexpf(1.0f / kRawScale, -scale_exp(*ah.m)), a.bias, h);
+    const int NG = (a.out_width + 7) / 8;
+    float s = 0.f;
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (8 * G + 4 * h + p < a.out_width) s += acc[0][4 * G + p];
+    const float m = xhalf_sum(s) / (float)a.out_width;
+    float q = 0.f;
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (8 * G + 4 * h + p < a.out_width) { const float d = acc[0][4 * G + p] - m; q = fmaf(d, d, q); }
+    q = xhalf_sum(q);
+    x[0] = acc[0]; xmean = m; xm2 = q;
+    if (store_out) {
+        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
+#pragma unroll
+        for (int G = 0; G < 4; ++G)
+            if (G < NG) st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4, make_float4(acc[0][4 * G], acc[0][4 * G + 1], acc[0][4 * G + 2], acc[0][4 * G + 3]));
+    }
+}
+
 __global__ __launch_bounds__(256, 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles) {
     const int lane = threadIdx.x & 63;
-    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (tile >= ntiles) return;
+    const int h = lane >> 5, j = lane & 31;
+    f32x16 x[1];
+    float xmean = 0.f, xm2 = 0.f;
+    bool have_x = false;
     for (int i = 0; i < nops; ++i) {
         const FusedOpH& op = ops[i];
         if (op.kind == 0) {
+            if (!have_x) {  // first operator of the run: bring its (<= 32 wide) input into registers once
+                const Seg& s0 = op.b.b.in0;
+                const float2 st = reinterpret_cast<const float2*>(s0.stats)[(size_t)tile * 32 + j];
+                xmean = st.x; xm2 = st.y;
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (G < s0.groups) v = ld4(s0.data + ((size_t)tile * s0.groups + G) * 256 + lane * 4);
+                    x[0][4 * G] = v.x; x[0][4 * G + 1] = v.y; x[0][4 * G + 2] = v.z; x[0][4 * G + 3] = v.w;
+                }
+                have_x = true;
+            }
+            // skip tensors were stored by this wave earlier in the run: make sure those stores have landed
+            if (op.b.b.in1.groups) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bool st = op.store_out != 0;
             if (op.sclin) {
                 switch (op.N) {
-                    case 4: resblock_body_h<4, true>(op.b, tile, lane); break;
-                    case 8: resblock_body_h<8, true>(op.b, tile, lane); break;
-                    case 16: resblock_body_h<16, true>(op.b, tile, lane); break;
-                    default: resblock_body_h<32, true>(op.b, tile, lane); break;
+                    case 4: resblock_body_h<4, true, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 8: resblock_body_h<8, true, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 16: resblock_body_h<16, true, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    default: resblock_body_h<32, true, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
                 }
             } else {
                 switch (op.N) {
-                    case 4: resblock_body_h<4, false>(op.b, tile, lane); break;
-                    case 8: resblock_body_h<8, false>(op.b, tile, lane); break;
-                    case 16: resblock_body_h<16, false>(op.b, tile, lane); break;
-                    default: resblock_body_h<32, false>(op.b, tile, lane); break;
+                    case 4: resblock_body_h<4, false, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 8: resblock_body_h<8, false, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 16: resblock_body_h<16, false, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    default: resblock_body_h<32, false, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
                 }
             }
-        } else {
+        } else if (!have_x || op.l.l.in_groups > 4) {
+            // Linear whose input is wider than one tile (the entry of the run): memory in, memory out, then reload
             linear_body_h<1, IN_FRAG, OUT_FRAG, false>(op.l, tile, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const LinArgs& a = op.l.l;
+            const int NG = (a.out_width + 7) / 8;
+            const float2 st = reinterpret_cast<const float2*>(a.out_stats)[(size_t)tile * 32 + j];
+            xmean = st.x; xm2 = st.y;
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (G < NG) v = ld4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4);
+                x[0][4 * G] = v.x; x[0][4 * G + 1] = v.y; x[0][4 * G + 2] = v.z; x[0][4 * G + 3] = v.w;
+            }
+            have_x = true;
+        } else {
+            linear_reg_h(op.l, tile, lane, x, xmean, xm2, op.store_out != 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
