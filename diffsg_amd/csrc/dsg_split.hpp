@@ -414,10 +414,20 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
             HFrag<NT> wc;
             load_hfrag<NT>(wc, ah.Wh + (size_t)S * 128 + lane, nt_stride);
             float v[8];
+            if ((a.in_width & 3) == 0) {   // 16-byte aligned quads: two float4 loads per lane and step
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int f = 8 * (2 * S + (jj >> 2)) + 4 * h + (jj & 3);
-                v[jj] = (row < a.nrows && f < a.in_width) ? kRawScale * a.in_rm[(size_t)row * a.in_width + f] : 0.f;
+                for (int q = 0; q < 2; ++q) {
+                    const int f = 8 * (2 * S + q) + 4 * h;
+                    float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < a.nrows && f < a.in_width) x4 = ld4(a.in_rm + (size_t)row * a.in_width + f);
+                    v[4 * q] = kRawScale * x4.x; v[4 * q + 1] = kRawScale * x4.y; v[4 * q + 2] = kRawScale * x4.z; v[4 * q + 3] = kRawScale * x4.w;
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int f = 8 * (2 * S + (jj >> 2)) + 4 * h + (jj & 3);
+                    v[jj] = (row < a.nrows && f < a.in_width) ? kRawScale * a.in_rm[(size_t)row * a.in_width + f] : 0.f;
+                }
             }
             h8 bhi, blo;
             split8(v, bhi, blo);
@@ -456,13 +466,23 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
     } else {
         if (row < a.nrows) {
             float* o = a.out_rm + ((size_t)pass * a.nrows + row) * a.out_width;
+            if ((a.out_width & 3) == 0) {
 #pragma unroll
-            for (int G = 0; G < NT * 4; ++G)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int f = 8 * G + 4 * h + p;
-                    if (f < a.out_width) o[f] = acc[G >> 2][4 * (G & 3) + p];
+                for (int G = 0; G < NT * 4; ++G) {
+                    const int f = 8 * G + 4 * h;
+                    if (f < a.out_width)
+                        st4(o + f, make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2],
+                                               acc[G >> 2][4 * (G & 3) + 3]));
                 }
+            } else {
+#pragma unroll
+                for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int f = 8 * G + 4 * h + p;
+                        if (f < a.out_width) o[f] = acc[G >> 2][4 * (G & 3) + p];
+                    }
+            }
         }
     }
 }
