@@ -155,6 +155,8 @@ struct dsg_handle {
     FusedOp* fused_dev = nullptr;
     std::vector<FusedOp> fused_host;
     FusedOpH* fusedh_dev = nullptr;
+    FusedOp* ce_dev = nullptr;          // condition-embedding Linear table (narrow blocks, one launch)
+    std::vector<FusedOp> ce_host;
     std::vector<FusedOpH> fusedh_host;
 
     // cached step graphs
@@ -640,6 +642,9 @@ void run_time_path(dsg_handle* h, int entries, hipStream_t s, bool train = false
 // cembed[block] = Wc silu(cond * mask) for every block from the condition fragments (one launch per block)
 void run_cond_embed(dsg_handle* h, int B, hipStream_t s) {
     const int tpp = cdiv(B, 32), CG = groups_of(h->d.cond_dim);
+    // wide blocks: one launch each; all blocks <= 32 wide: ONE launch (a wave walks the list for its tile)
+    std::vector<FusedOp>& tab = h->ce_host;
+    tab.clear();
     for (const ResP& r : h->res) {
         LinArgs a;
         memset(&a, 0, sizeof a);
@@ -648,7 +653,16 @@ void run_cond_embed(dsg_handle* h, int B, hipStream_t s) {
         a.W = h->arena + r.Wcp; a.bias = h->arena + h->zero_off;
         a.out = h->cembed + r.ce_off * (cap_tiles_of(h) / 2); a.out_stats = h->ce_stats; a.out_width = r.N;
         a.ntiles = tpp; a.tiles_per_pass = tpp; a.nrows = B;
-        launch_lin(r.N, IN_FRAG, OUT_FRAG, false, a, s);
+        if (r.N > 32) { launch_lin(r.N, IN_FRAG, OUT_FRAG, false, a, s); continue; }
+        FusedOp f;
+        memset(&f, 0, sizeof f);
+        f.kind = 1; f.N = r.N; f.l = a;
+        tab.push_back(f);
+    }
+    if (!tab.empty()) {
+        (void)hipStreamSynchronize(s);  // ce_host may still be the source of the previous upload
+        (void)hipMemcpyAsync(h->ce_dev, tab.data(), tab.size() * sizeof(FusedOp), hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_fused_narrow, dim3(cdiv(tpp, kWavesPerBlock)), dim3(256), 0, s, h->ce_dev, (int)tab.size(), tpp);
     }
 }
 
@@ -682,7 +696,7 @@ int ensure_train_workspace(dsg_handle* h, int rows, int T) {
     HIPCK(hipMalloc(&h->tr_gsum, h->slab_stride * sizeof(float)));
     HIPCK(hipMalloc(&h->tr_ts, (size_t)nrows * sizeof(int)));
     HIPCK(hipMalloc(&h->tr_yt_rm, (size_t)nrows * D * sizeof(float)));
-    HIPCK(hipMalloc(&h->tr_tsave, ((size_t)T * 2 * half + (size_t)5 * T * td) * sizeof(float)));
+    HIPCK(hipMalloc(&h->tr_tsave, ((size_t)T * 2 * half + (size_t)(5 + kTimeChunks) * T * td) * sizeof(float)));
     return 0;
 }
 
@@ -899,7 +913,8 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         h->fuse_lo = best_lo; h->fuse_hi = best_hi;
     }
     if (const char* e = getenv("DSG_PRECISION")) h->use_split = strcmp(e, "f32") != 0;
-    bool ok = hipMalloc(&h->fusedh_dev, (h->ops.size() + 1) * sizeof(FusedOpH)) == hipSuccess &&
+    bool ok = hipMalloc(&h->ce_dev, (h->res.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
+              hipMalloc(&h->fusedh_dev, (h->ops.size() + 1) * sizeof(FusedOpH)) == hipSuccess &&
               hipMalloc(&h->maxabs, (h->params.size() + 1) * sizeof(float)) == hipSuccess &&
               hipMalloc(&h->fused_dev, (h->ops.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
               hipMalloc(&h->arena, h->arena_floats * sizeof(float)) == hipSuccess &&
@@ -927,7 +942,7 @@ void dsg_destroy(dsg_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev, h->maxabs,
-                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev, h->tw_dst_dev, (void*)h->tw_src_dev};
+                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->ce_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1307,12 +1322,13 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
         float* tpre = h1s + (size_t)T * td;
         float* d_st = tpre + (size_t)T * td;
         float* d_h1s = d_st + (size_t)T * td;
+        float* tpart = d_h1s + (size_t)T * td;   // [kTimeChunks][T][td]
         // all blocks at once: their dTB rows are contiguous from the first block's dtb_off
         const float* dtb_all = G + h->res[0].dtb_off;
         hipLaunchKernelGGL(k_time_wgrad, dim3(2048), dim3(256), 0, s, dtb_all, T, h->st, td, h->tw_dst_dev, G, h->tw_rows);
-        hipLaunchKernelGGL(k_time_dgrad, dim3(cdiv(T * td, 256)), dim3(256), 0, s, dtb_all, T, h->tw_src_dev, td, d_st, h->tw_rows);
+        hipLaunchKernelGGL(k_time_dgrad, dim3(cdiv(T * td, 256), kTimeChunks), dim3(256), 0, s, dtb_all, T, h->tw_src_dev, td, tpart, h->tw_rows);
         const unsigned eb = (unsigned)cdiv(T * td, 256);
-        hipLaunchKernelGGL(k_mul_silu_grad, dim3(eb), dim3(256), 0, s, d_st, tpre, (size_t)T * td);          // d temb (pre-Swish)
+        hipLaunchKernelGGL(k_time_dgrad_finish, dim3(eb), dim3(256), 0, s, tpart, tpre, d_st, (size_t)T * td);  // d temb (pre-Swish)
         small_gemm(d_st, 1, td, h1s, td, 1, G + P[h->temb_l2w].off, td, 1, td, td, T, 0, s);                   // d lin2.weight
         hipLaunchKernelGGL(k_col_sum_small, dim3(cdiv(td, 256)), dim3(256), 0, s, d_st, T, td, (long long)td, G + P[h->temb_l2b].off);
         small_gemm(d_st, td, 1, P[h->temb_l2w].ptr, td, 1, d_h1s, td, 1, T, td, td, 0, s);                     // d h1 (post-Swish)

@@ -443,8 +443,8 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const LinBwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Grouped weight gradient: for every Linear,  dW[n][k] = sum_rows G[row][n] * A[row][k].
 // The contraction runs over batch rows, which sit on the LANE axis of the fragment layout, so each 32-row tile of G
-// and A is transposed through LDS ([row][feature] images, rows padded by 4 floats: conflict-free b128 writes and
-// b32 reads) and fed to v_mfma_f32_32x32x2_f32 with i = out feature, j = in feature, k = row.
+// and A is transposed through LDS ([feature][row] images, 36-float rows: conflict-free b32 scatter writes and b128
+// reads) and fed to v_mfma_f32_32x32x2_f32 with i = out feature, j = in feature, k = row.
 // One workgroup = (descriptor, block of <=128 input features, row chunk); partial results go to slab[chunk].
 // ---------------------------------------------------------------------------------------------
 enum { A_RAW = 0, A_LNSILU = 1, A_ONEHOT = 2 };
@@ -465,20 +465,84 @@ struct WgradDesc {
 };
 struct WgradUnit { int desc; int kblk; int chunk; int pad; };
 
-constexpr int kWgLd = 132;  // padded row length of the LDS images (128 features + 4)
+constexpr int kWgLd = 36;      // floats per feature row of an LDS image: 32 batch rows + 4 (conflict-free b128 reads)
+constexpr int kWgImg = 128 * kWgLd;
+
+// Fetch this wave's share of one row tile into registers: G groups g = wave, wave+4, ... and A groups likewise.
+struct WgStage { float4 g[4]; float4 a[4]; };
+
+__device__ __forceinline__ void wgrad_fetch(const WgradDesc& d, WgStage& st, int tile, int wave, int lane, int NTp, int g_lo, int ngr, int KT) {
+    const int h = lane >> 5, j = lane & 31;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = wave + 4 * i;
+        float4 v = z4;
+        if (g < NTp * 4 && g < d.NG) {
+            v = ld4(d.G0 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
+            if (d.G1) {
+                const float4 w = ld4(d.G1 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+        }
+        st.g[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gi = wave + 4 * i;
+        const int G = g_lo + gi;
+        float4 v = z4;
+        if (gi < KT * 4 && gi < ngr) {
+            if (d.amode == A_ONEHOT) {
+                const int row = tile * 32 + j;
+                const int e = row < d.nrows ? d.ts[row] : -1;
+                const int f = 8 * G + 4 * h;
+                v = make_float4(e == f ? 1.f : 0.f, e == f + 1 ? 1.f : 0.f, e == f + 2 ? 1.f : 0.f, e == f + 3 ? 1.f : 0.f);
+            } else {
+                const bool first = G < d.a0.groups;
+                const Seg& sg = first ? d.a0 : d.a1;
+                const int gl = first ? G : G - d.a0.groups;
+                v = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                if (d.amode == A_LNSILU) {
+                    const float2 ms = reinterpret_cast<const float2*>(d.rs)[(size_t)tile * 32 + j];
+                    const float4 gm = ld4(d.gamma + 8 * G + 4 * h), bt = ld4(d.beta + 8 * G + 4 * h);
+                    v = ln_silu4(v, ms.x, ms.y, gm, bt);
+                }
+                if (tile * 32 + j >= d.nrows) v = z4;  // forward tensors of padded rows are not zero
+            }
+        }
+        st.a[i] = v;
+    }
+}
+
+// registers -> transposed LDS images [feature][row]: lane (row j, half h) scatters its 4 features, conflict-free
+__device__ __forceinline__ void wgrad_stage(const WgStage& st, float* Gimg, float* Aimg, int wave, int lane, int NTp, int KT) {
+    const int h = lane >> 5, j = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = wave + 4 * i;
+        if (g < NTp * 4) {
+            float* p = Gimg + (8 * g + 4 * h) * kWgLd + j;
+            p[0] = st.g[i].x; p[kWgLd] = st.g[i].y; p[2 * kWgLd] = st.g[i].z; p[3 * kWgLd] = st.g[i].w;
+        }
+        if (g < KT * 4) {
+            float* p = Aimg + (8 * g + 4 * h) * kWgLd + j;
+            p[0] = st.a[i].x; p[kWgLd] = st.a[i].y; p[2 * kWgLd] = st.a[i].z; p[3 * kWgLd] = st.a[i].w;
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void k_wgrad(const WgradDesc* __restrict__ descs, const WgradUnit* __restrict__ units,
                                                float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks) {
-    __shared__ __attribute__((aligned(16))) float img[2 * 32 * kWgLd];
-    float* Gimg = img;
-    float* Aimg = img + 32 * kWgLd;
+    // two (G, A) image pairs: tile t+1 is fetched during the MFMAs of tile t and staged after them; one barrier per tile
+    __shared__ __attribute__((aligned(16))) float img[2 * 2 * kWgImg];
     const WgradUnit un = units[blockIdx.x];
     const WgradDesc d = descs[un.desc];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
     const int NT = (d.N + 31) / 32;
     const int NTp = NT <= 1 ? 1 : (NT == 2 ? 2 : 4);      // n-tiles padded to a divisor of 4
-    const int rsplit = 4 / NTp;                           // waves sharing one n-tile split the 16 row-pair steps
+    const int rsplit = 4 / NTp;                           // waves sharing one n-tile split the 4 row quads
     const int my_nt = wave % NTp, my_part = wave / NTp;
     const int g_lo = un.kblk * 16;
     const int g_hi = (g_lo + 16 < d.KG) ? g_lo + 16 : d.KG;
@@ -490,58 +554,37 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradDesc* __restrict__ des
 
     f32x16 acc[4];
     acc_zero<4>(acc);
-
+    WgStage st;
+    if (t_lo < t_hi) {
+        wgrad_fetch(d, st, t_lo, wave, lane, NTp, g_lo, ngr, KT);
+        wgrad_stage(st, img, img + kWgImg, wave, lane, NTp, KT);
+    }
+    __syncthreads();
     for (int tile = t_lo; tile < t_hi; ++tile) {
-        // ---- stage G: NG groups spread over the 4 waves
-        for (int g = wave; g < NTp * 4; g += 4) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g < d.NG) {
-                v = ld4(d.G0 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
-                if (d.G1) {
-                    const float4 w = ld4(d.G1 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
-                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-                }
-            }
-            st4(&Gimg[j * kWgLd + 8 * g + 4 * h], v);
-        }
-        // ---- stage A
-        for (int gi = wave; gi < KT * 4; gi += 4) {
-            const int G = g_lo + gi;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gi < ngr) {
-                if (d.amode == A_ONEHOT) {
-                    int row = tile * 32 + j;
-                    const int e = row < d.nrows ? d.ts[row] : -1;
-                    const int f = 8 * G + 4 * h;
-                    v = make_float4(e == f ? 1.f : 0.f, e == f + 1 ? 1.f : 0.f, e == f + 2 ? 1.f : 0.f, e == f + 3 ? 1.f : 0.f);
-                } else {
-                    const bool first = G < d.a0.groups;
-                    const Seg& sg = first ? d.a0 : d.a1;
-                    const int gl = first ? G : G - d.a0.groups;
-                    v = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
-                    if (d.amode == A_LNSILU) {
-                        const float2 ms = reinterpret_cast<const float2*>(d.rs)[(size_t)tile * 32 + j];
-                        const float4 gm = ld4(d.gamma + 8 * G + 4 * h), bt = ld4(d.beta + 8 * G + 4 * h);
-                        v.x = silu(fmaf((v.x - ms.x) * ms.y, gm.x, bt.x)); v.y = silu(fmaf((v.y - ms.x) * ms.y, gm.y, bt.y));
-                        v.z = silu(fmaf((v.z - ms.x) * ms.y, gm.z, bt.z)); v.w = silu(fmaf((v.w - ms.x) * ms.y, gm.w, bt.w));
-                    }
-                    // rows beyond the batch must not contribute: forward tensors of padded rows are not zero
-                    if (tile * 32 + j >= d.nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            st4(&Aimg[j * kWgLd + 8 * gi + 4 * h], v);
-        }
-        __syncthreads();
-        // ---- MFMA: i = out feature (n-tile my_nt), j = in feature (k-tile kt), k = row pair
-        const int s_lo = my_part * (16 / rsplit), s_hi = s_lo + 16 / rsplit;
-        for (int s = s_lo; s < s_hi; ++s) {
-            const float av = Gimg[(2 * s + h) * kWgLd + 32 * my_nt + j];
+        const int b = (tile - t_lo) & 1;
+        const float* Gimg = img + b * 2 * kWgImg;
+        const float* Aimg = Gimg + kWgImg;
+        const bool more = tile + 1 < t_hi;
+        if (more) wgrad_fetch(d, st, tile + 1, wave, lane, NTp, g_lo, ngr, KT);
+        // MFMA: i = out feature (n-tile my_nt), j = in feature (k-tile kt), k = batch row.  Quad q covers rows 8q..8q+7:
+        // k-step s' of the quad pairs row 8q + s' (lane half 0) with row 8q + 4 + s' (half 1), so each lane needs 4
+        // CONSECUTIVE rows of its feature: one ds_read_b128 per operand per 4 MFMAs.
+        const int q_lo = my_part * (4 / rsplit), q_hi = q_lo + 4 / rsplit;
+        for (int q = q_lo; q < q_hi; ++q) {
+            const float4 av = *reinterpret_cast<const float4*>(Gimg + (32 * my_nt + j) * kWgLd + 8 * q + 4 * h);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
                 if (kt < KT) {
-                    const float bv = Aimg[(2 * s + h) * kWgLd + 32 * kt + j];
-                    DSG_MFMA(acc[kt], av, bv);
+                    const float4 bv = *reinterpret_cast<const float4*>(Aimg + (32 * kt + j) * kWgLd + 8 * q + 4 * h);
+                    DSG_MFMA(acc[kt], av.x, bv.x);
+                    DSG_MFMA(acc[kt], av.y, bv.y);
+                    DSG_MFMA(acc[kt], av.z, bv.z);
+                    DSG_MFMA(acc[kt], av.w, bv.w);
                 }
+        }
+        if (more) {
+            float* nG = img + (b ^ 1) * 2 * kWgImg;
+            wgrad_stage(st, nG, nG + kWgImg, wave, lane, NTp, KT);
         }
         __syncthreads();
     }
@@ -700,15 +743,26 @@ __global__ void k_time_wgrad(const float* __restrict__ dtb, int T, const float* 
         G[dst_row[r] + k] = s;
     }
 }
-//   d st[e][k] = sum_r dTB[r][e] * Wt_row(r)[k]
+//   d st[e][k] = sum_r dTB[r][e] * Wt_row(r)[k]   -- rows split over blockIdx.y into partial sums (fixed order)
+constexpr int kTimeChunks = 16;
 __global__ void k_time_dgrad(const float* __restrict__ dtb, int T, const float* const* __restrict__ wt_row, int td,
-                             float* __restrict__ d_st, int nrows_all) {
+                             float* __restrict__ part, int nrows_all) {
+    const int per = (nrows_all + kTimeChunks - 1) / kTimeChunks;
+    const int r_lo = blockIdx.y * per, r_hi = (r_lo + per < nrows_all) ? r_lo + per : nrows_all;
     const long long total = (long long)T * td;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int k = idx % td, e = idx / td;
         float s = 0.f;
-        for (int r = 0; r < nrows_all; ++r) s = fmaf(dtb[(size_t)r * T + e], wt_row[r][k], s);
-        d_st[idx] = s;
+        for (int r = r_lo; r < r_hi; ++r) s = fmaf(dtb[(size_t)r * T + e], wt_row[r][k], s);
+        part[(size_t)blockIdx.y * total + idx] = s;
+    }
+}
+// d_st[i] = (sum_c part[c][i]) * swish'(pre[i])
+__global__ void k_time_dgrad_finish(const float* __restrict__ part, const float* __restrict__ pre, float* __restrict__ d_st, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float t = 0.f;
+        for (int c = 0; c < kTimeChunks; ++c) t += part[(size_t)c * n + i];
+        d_st[i] = t * silu_grad(pre[i]);
     }
 }
 
