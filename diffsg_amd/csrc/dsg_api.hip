@@ -540,6 +540,27 @@ void launch_lin_h(int N, int inmode, int outmode, bool lnact, const LinArgsH& a,
     }
 }
 
+// block (64/128 wide) + the Linear that consumes it, in one launch; returns false if the shape pair is not instantiated
+bool launch_res_lin_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, const LinOpP& l, const LinArgs& la, bool final_op,
+                      bool store_block_out, hipStream_t s) {
+    BlockLinArgsH a;
+    fill_block_args_h(h, r, b, a.b);
+    fill_lin_args_h(h, l, la, a.l);
+    a.store_block_out = store_block_out ? 1 : 0;
+    const dim3 grid(cdiv(b.ntiles, kWavesPerBlock)), block(256);
+    const int NTO = cdiv(l.l.N, 32);
+#define DSG_TRY(N_, SC_, NTO_, FIN_)                                                                         \
+    if (r.N == N_ && r.sclin == SC_ && NTO == NTO_ && final_op == FIN_) {                                    \
+        hipLaunchKernelGGL((k_resblock_lin_h<N_, SC_, NTO_, FIN_>), grid, block, 0, s, a);                   \
+        return true;                                                                                         \
+    }
+    DSG_TRY(128, false, 2, false) DSG_TRY(128, false, 1, false) DSG_TRY(64, true, 4, false) DSG_TRY(64, false, 2, false)
+    DSG_TRY(64, true, 2, false) DSG_TRY(64, false, 1, false)
+    DSG_TRY(128, true, 1, true) DSG_TRY(128, true, 3, true) DSG_TRY(64, true, 1, true) DSG_TRY(64, true, 3, true)
+#undef DSG_TRY
+    return false;
+}
+
 bool split_ctx(const dsg_handle* h, const RunCtx& c) { return h->use_split && c.cond_pre; }
 
 void launch_op(const dsg_handle* h, const Op& op, const RunCtx& c, hipStream_t s) {
@@ -609,6 +630,22 @@ void launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     else hipLaunchKernelGGL(k_fused_narrow, grid, block, 0, s, h->fused_dev, h->fuse_hi - h->fuse_lo, ntiles);
 }
 
+// wide block followed by its consuming Linear (Down/Upsample or final), both outside the fused narrow run
+bool try_pair(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
+    if (!split_ctx(h, c) || c.train || i + 1 >= (int)h->ops.size()) return false;
+    const Op& a = h->ops[i];
+    const Op& b = h->ops[i + 1];
+    if (a.kind != OP_RES || (b.kind != OP_LIN && b.kind != OP_FINAL) || b.in0 != a.out) return false;
+    const bool fuse = h->fuse_hi - h->fuse_lo >= 2;
+    if (fuse && i + 1 >= h->fuse_lo && i < h->fuse_hi) return false;
+    const ResP& r = h->res[a.p];
+    if (r.N < 64) return false;
+    BlockArgs ba; LinArgs la;
+    fill_block_args(h, a, c, ba);
+    fill_lin_args(h, b, c, la);
+    return launch_res_lin_h(h, r, ba, h->lin[b.p], la, b.kind == OP_FINAL, h->tensors[a.out].is_skip, s);
+}
+
 void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     const bool fuse = !c.train && h->fuse_hi - h->fuse_lo >= 2;
     for (int i = 0; i < (int)h->ops.size(); ++i) {
@@ -617,6 +654,7 @@ void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
             i = h->fuse_hi - 1;
             continue;
         }
+        if (try_pair(h, i, c, s)) { ++i; continue; }
         launch_op(h, h->ops[i], c, s);
     }
 }
@@ -1127,11 +1165,15 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
                         hipEvent_t* ev = nullptr) {
     if (ev) {  // DSG_SAMPLE_PROFILE: one event pair per operator launch
         const bool fuse = h->fuse_hi - h->fuse_lo >= 2;
+        bool skip_next = false;
         for (size_t i = 0; i < h->ops.size(); ++i) {
             HIPCK(hipEventRecord(ev[2 * i], s));
             // the fused narrow run is one launch: its time is booked on its first operator, the others read ~0
             if (fuse && (int)i == h->fuse_lo) launch_fused(h, c, s);
-            else if (!(fuse && (int)i > h->fuse_lo && (int)i < h->fuse_hi)) launch_op(h, h->ops[i], c, s);
+            else if (fuse && (int)i > h->fuse_lo && (int)i < h->fuse_hi) {}
+            else if (skip_next) { skip_next = false; }   // consumed by the pair launch booked on the previous operator
+            else if (try_pair(h, (int)i, c, s)) skip_next = true;
+            else launch_op(h, h->ops[i], c, s);
             HIPCK(hipEventRecord(ev[2 * i + 1], s));
         }
     } else {

@@ -93,8 +93,8 @@ __device__ __forceinline__ void act8(float (&v)[8], const float4 x0, const float
 
 // Register-fed stage (stages 2 and 3): B = split(16 * silu(LN(in))).  An odd group count (N = 8, 4) pairs the last group
 // with the accumulator's zero padding (rows >= N of the producer's packed weights and biases are zero).
-template <int N, int NT>
-__device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16 (&in)[NT], const uint4* __restrict__ wp,
+template <int N, int NT, int NTI = NT>
+__device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16 (&in)[NTI], const uint4* __restrict__ wp,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float mean, float rstd,
                                                  int lane, int h, size_t nt_stride_override = 0) {
     constexpr int KS = ((N + 7) / 8 + 1) / 2;
@@ -126,12 +126,12 @@ __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16
 
 // Register-fed RAW stage (no LayerNorm / SiLU): Linear shortcut and the plain Linears of the narrow run when their input
 // lives in registers.  `groups` (runtime, <= 4*NT) real groups; the missing group of an odd count is accumulator padding.
-template <int NT>
-__device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f32x16 (&in)[NT], int groups, const uint4* __restrict__ wp,
+template <int NT, int NTI = NT>
+__device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f32x16 (&in)[NTI], int groups, const uint4* __restrict__ wp,
                                                      size_t nt_stride, int lane) {
     const int steps = (groups + 1) >> 1;
 #pragma unroll
-    for (int S = 0; S < 2 * NT; ++S) {
+    for (int S = 0; S < 2 * NTI; ++S) {
         if (S < steps) {
             HFrag<NT> w;
             load_hfrag<NT>(w, wp + (size_t)S * 128 + lane, nt_stride);
@@ -215,9 +215,9 @@ struct BlockArgsH {
 
 // Needs cond_pre: the condition embedding Wc silu(cond*mask) is precomputed per call (sampling) or per step (training)
 // and added here, never multiplied.
-// XREG (narrow run): in0 is not read from memory but handed over in registers `xr` with its row statistics, and the
-// output goes back into `xr` (it is stored only when `store_out`, i.e. when something outside this wave's run reads it).
-template <int N, bool SCLIN, bool XREG = false>
+// XIN: in0 is not read from memory but handed over in registers `xr` with its row statistics (narrow run).
+// XOUT: the output goes (back) into `xr`; it is stored only when `store_out` (something outside this wave reads it).
+template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN>
 __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane, f32x16 (*xr)[(N + 31) / 32] = nullptr,
                                                 float* xr_mean = nullptr, float* xr_m2 = nullptr, bool store_out = true) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
@@ -230,7 +230,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     float mean1, rstd1;
     {
         float mean, m2, n = (float)a.in0.width;
-        if (XREG) { mean = *xr_mean; m2 = *xr_m2; }
+        if (XIN) { mean = *xr_mean; m2 = *xr_m2; }
         else { const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j]; mean = s0.x; m2 = s0.y; }
         if (a.in1.groups) {
             const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
@@ -255,7 +255,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
     {
         const size_t nt_stride = (size_t)KS1 * 128;
-        if (XREG)   // in0 has the block's own width N here (down / middle: in = N; up: cat(N, N))
+        if (XIN)    // in0 has the block's own width N here (down / middle: in = N; up: cat(N, N))
             chain_from_acc_h<N, NT>(acc1, *xr, ah.W1h, a.gamma1, a.beta1, mean1, rstd1, lane, h, nt_stride);
         else
             chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
@@ -326,7 +326,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     }
     if (SCLIN) {
         const size_t nt_stride = (size_t)KS1 * 128;
-        if (XREG)
+        if (XIN)
             chain_raw_from_reg_h<NT>(acc3, *xr, a.in0.groups, ah.Wsch, nt_stride, lane);
         else
             chain_from_mem_h<NT, false>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
@@ -337,7 +337,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         acc_unscale_add<NT>(acc3, inv3, a.c3, h);
     } else {
         acc_unscale_add<NT>(acc3, inv3, a.c3, h);
-        if (XREG) {
+        if (XIN) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc3[nt] += (*xr)[nt];
         } else {
@@ -355,12 +355,12 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     {
         float mean, m2;
         acc_stats<N, NT>(acc3, h, mean, m2);
-        if (XREG) {
+        if (XOUT) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) (*xr)[nt] = acc3[nt];
             *xr_mean = mean; *xr_m2 = m2;
         }
-        if (!XREG || store_out) {
+        if (!XOUT || store_out) {
             if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
 #pragma unroll
             for (int G = 0; G < NG; ++G)
@@ -379,12 +379,96 @@ __global__ __launch_bounds__(256, 2) void k_resblock_h(const BlockArgsH ah) {
     resblock_body_h<N, SCLIN>(ah, tile, lane);
 }
 
+// A wide block followed by the Linear that consumes it (Down/Upsample: raw; final: LayerNorm + SiLU, row-major out),
+// fused: the block's output stays in registers, which saves one launch, one store (unless it is a skip) and one reload.
+struct LinArgsH;
+template <int NTO, int NTI, bool FINAL>
+__device__ __forceinline__ void linear_epilogue_h(const LinArgsH& ah, int tile, int lane, const f32x16 (&x)[NTI], float xmean, float xm2);
+
 // Plain Linear on the split path (feature_proj, Down/Upsample, final): same contract as linear_body.
 struct LinArgsH {
     LinArgs l;
     const uint4* Wh;   // [NT][ceil(KG/2)][2][64]
     const float* m;    // max|W|
 };
+
+template <int NTO, int NTI, bool FINAL>
+__device__ __forceinline__ void linear_epilogue_h(const LinArgsH& ah, int tile, int lane, const f32x16 (&x)[NTI], float xmean, float xm2) {
+    const LinArgs& a = ah.l;
+    const int h = lane >> 5, j = lane & 31;
+    const int KS = (a.in_groups + 1) >> 1;
+    const size_t nt_stride = (size_t)KS * 128;
+    f32x16 acc[NTO];
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    if (FINAL) {
+        const float rstd = rsqrtf(xm2 / (float)a.in_width + kLnEps);
+        chain_from_acc_h<NTI * 32, NTO, NTI>(acc, x, ah.Wh, a.gamma, a.beta, xmean, rstd, lane, h, nt_stride);
+    } else {
+        chain_raw_from_reg_h<NTO, NTI>(acc, x, a.in_groups, ah.Wh, nt_stride, lane);
+    }
+    acc_unscale_add<NTO>(acc, ldexpf(1.0f / (FINAL ? kActScale : kRawScale), -scale_exp(*ah.m)), a.bias, h);
+    if (!FINAL) {
+        const int NG = (a.out_width + 7) / 8;
+        float s = 0.f;
+#pragma unroll
+        for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (8 * G + 4 * h + p < a.out_width) s += acc[G >> 2][4 * (G & 3) + p];
+        const float m = xhalf_sum(s) / (float)a.out_width;
+        float q = 0.f;
+#pragma unroll
+        for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (8 * G + 4 * h + p < a.out_width) { const float d = acc[G >> 2][4 * (G & 3) + p] - m; q = fmaf(d, d, q); }
+        q = xhalf_sum(q);
+        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
+#pragma unroll
+        for (int G = 0; G < NTO * 4; ++G)
+            if (G < NG)
+                st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                    make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
+    } else {
+        const int ptile = tile % a.tiles_per_pass, pass = tile / a.tiles_per_pass, row = ptile * 32 + j;
+        if (row < a.nrows) {
+            float* o = a.out_rm + ((size_t)pass * a.nrows + row) * a.out_width;
+            if ((a.out_width & 3) == 0) {
+#pragma unroll
+                for (int G = 0; G < NTO * 4; ++G) {
+                    const int f = 8 * G + 4 * h;
+                    if (f < a.out_width)
+                        st4(o + f, make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
+                }
+            } else {
+#pragma unroll
+                for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int f = 8 * G + 4 * h + p;
+                        if (f < a.out_width) o[f] = acc[G >> 2][4 * (G & 3) + p];
+                    }
+            }
+        }
+    }
+}
+
+struct BlockLinArgsH { BlockArgsH b; LinArgsH l; int store_block_out; };
+
+template <int N, bool SCLIN, int NTO, bool FINAL>
+__global__ __launch_bounds__(256, 2) void k_resblock_lin_h(const BlockLinArgsH a) {
+    constexpr int NT = (N + 31) / 32;
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (tile >= a.b.b.ntiles) return;
+    f32x16 x[NT];
+    float xmean = 0.f, xm2 = 0.f;
+    resblock_body_h<N, SCLIN, false, true>(a.b, tile, lane, &x, &xmean, &xm2, a.store_block_out != 0);
+    linear_epilogue_h<NTO, NT, FINAL>(a.l, tile, lane, x, xmean, xm2);
+}
 
 template <int NT, int INMODE, int OUTMODE, bool LNACT>
 __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile, const int lane) {

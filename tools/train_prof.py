@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""N MSR-80c training steps at 32768 rows (for rocprofv3 kernel-trace): python tools/train_prof.py [steps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import torch, bench
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+dev = torch.device("cuda:0")
+ddpm = bench.build_model(dev, 20)
+opt = torch.optim.Adam(ddpm.parameters(), lr=0.005, fused=True)
+B = 32768
+cond = torch.rand(B, 80, device=dev); y = torch.rand(B, 80, device=dev) * 0.25
+def one():
+    loss = ddpm(y, cond); loss.backward(); opt.step(); opt.zero_grad(); return loss
+for _ in range(3): one()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(steps): one()
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"train: {dt/steps*1e3:.3f} ms/step, {B*steps/dt/1e6:.2f} M samples/s")
