@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <vector>
 
 using namespace dsg;
@@ -810,6 +811,16 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
     for (size_t i = 0; i < wd.size(); ++i)
         for (int kb = 0; kb < cdiv(wd[i].KG, 16); ++kb)
             for (int c = 0; c < h->tr_chunks; ++c) wu.push_back(WgradUnit{(int)i, kb, c, 0});
+    // longest units first: the proj_dim-wide up blocks come last in op order and would otherwise form the tail
+    {
+        auto cost = [&](const WgradUnit& u) {
+            const WgradDesc& d = wd[u.desc];
+            const int nt = cdiv(d.N, 32), ntp = nt <= 1 ? 1 : (nt == 2 ? 2 : 4);
+            const int ngr = d.KG - u.kblk * 16 < 16 ? d.KG - u.kblk * 16 : 16;
+            return ntp * cdiv(ngr, 4);
+        };
+        std::stable_sort(wu.begin(), wu.end(), [&](const WgradUnit& a, const WgradUnit& b) { return cost(a) > cost(b); });
+    }
     std::vector<ColsumUnit> cu;
     for (size_t i = 0; i < cd.size(); ++i)
         for (int g = 0; g < cd[i].groups; ++g)

@@ -465,129 +465,150 @@ struct WgradDesc {
 };
 struct WgradUnit { int desc; int kblk; int chunk; int pad; };
 
-constexpr int kWgLd = 36;      // floats per feature row of an LDS image: 32 batch rows + 4 (conflict-free b128 reads)
+constexpr int kWgLd = 36;      // floats per feature row of a 1-tile LDS image: 32 batch rows + 4 (conflict-free b128 reads)
 constexpr int kWgImg = 128 * kWgLd;
+constexpr int kWgTB = 4;       // small units (one out tile, <= 64 in features) take 4 row tiles per barrier interval
+constexpr int kWgLdB = 32 * kWgTB + 4;
+constexpr int kWgLdsFloats = 2 * 2 * kWgImg;   // 72 KiB: two (G, A) image pairs of the 1-tile form; the 4-tile form fits in it
 
-// Fetch this wave's share of one row tile into registers: G groups g = wave, wave+4, ... and A groups likewise.
-struct WgStage { float4 g[4]; float4 a[4]; };
-
-__device__ __forceinline__ void wgrad_fetch(const WgradDesc& d, WgStage& st, int tile, int wave, int lane, int NTp, int g_lo, int ngr, int KT) {
+// this wave's share of one row tile: G group `g` and A group index `gi` (relative to the unit's first A group)
+__device__ __forceinline__ float4 wgrad_load_g(const WgradDesc& d, int tile, int g, int lane) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < d.NG) {
+        v = ld4(d.G0 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
+        if (d.G1) {
+            const float4 w = ld4(d.G1 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ float4 wgrad_load_a(const WgradDesc& d, int tile, int G, int lane) {
     const int h = lane >> 5, j = lane & 31;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = wave + 4 * i;
-        float4 v = z4;
-        if (g < NTp * 4 && g < d.NG) {
-            v = ld4(d.G0 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
-            if (d.G1) {
-                const float4 w = ld4(d.G1 + ((size_t)tile * d.NG + g) * 256 + lane * 4);
-                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-            }
-        }
-        st.g[i] = v;
+    float4 v;
+    if (d.amode == A_ONEHOT) {
+        const int row = tile * 32 + j;
+        const int e = row < d.nrows ? d.ts[row] : -1;
+        const int f = 8 * G + 4 * h;
+        return make_float4(e == f ? 1.f : 0.f, e == f + 1 ? 1.f : 0.f, e == f + 2 ? 1.f : 0.f, e == f + 3 ? 1.f : 0.f);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gi = wave + 4 * i;
-        const int G = g_lo + gi;
-        float4 v = z4;
-        if (gi < KT * 4 && gi < ngr) {
-            if (d.amode == A_ONEHOT) {
-                const int row = tile * 32 + j;
-                const int e = row < d.nrows ? d.ts[row] : -1;
-                const int f = 8 * G + 4 * h;
-                v = make_float4(e == f ? 1.f : 0.f, e == f + 1 ? 1.f : 0.f, e == f + 2 ? 1.f : 0.f, e == f + 3 ? 1.f : 0.f);
-            } else {
-                const bool first = G < d.a0.groups;
-                const Seg& sg = first ? d.a0 : d.a1;
-                const int gl = first ? G : G - d.a0.groups;
-                v = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
-                if (d.amode == A_LNSILU) {
-                    const float2 ms = reinterpret_cast<const float2*>(d.rs)[(size_t)tile * 32 + j];
-                    const float4 gm = ld4(d.gamma + 8 * G + 4 * h), bt = ld4(d.beta + 8 * G + 4 * h);
-                    v = ln_silu4(v, ms.x, ms.y, gm, bt);
-                }
-                if (tile * 32 + j >= d.nrows) v = z4;  // forward tensors of padded rows are not zero
-            }
-        }
-        st.a[i] = v;
+    const bool first = G < d.a0.groups;
+    const Seg& sg = first ? d.a0 : d.a1;
+    const int gl = first ? G : G - d.a0.groups;
+    v = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+    if (d.amode == A_LNSILU) {
+        const float2 ms = reinterpret_cast<const float2*>(d.rs)[(size_t)tile * 32 + j];
+        const float4 gm = ld4(d.gamma + 8 * G + 4 * h), bt = ld4(d.beta + 8 * G + 4 * h);
+        v = ln_silu4(v, ms.x, ms.y, gm, bt);
     }
+    if (tile * 32 + j >= d.nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);  // forward tensors of padded rows are not zero
+    return v;
+}
+// lane (row j of tile `tt`, half h) scatters its 4 features of group g into a transposed image [feature][row]
+__device__ __forceinline__ void wgrad_scatter(float* img, int ld, int g, int tt, int lane, const float4 v) {
+    const int h = lane >> 5, j = lane & 31;
+    float* p = img + (8 * g + 4 * h) * ld + 32 * tt + j;
+    p[0] = v.x; p[ld] = v.y; p[2 * ld] = v.z; p[3 * ld] = v.w;
 }
 
-// registers -> transposed LDS images [feature][row]: lane (row j, half h) scatters its 4 features, conflict-free
-__device__ __forceinline__ void wgrad_stage(const WgStage& st, float* Gimg, float* Aimg, int wave, int lane, int NTp, int KT) {
+// One unit.  TB = row tiles per barrier interval; DB = double-buffered images (TB == 1) or single (TB == 4).
+// MFMA: i = out feature (n-tile my_nt), j = in feature (k-tile kt), k = batch row.  Quad q covers rows 8q..8q+7: k-step s' of
+// the quad pairs row 8q + s' (lane half 0) with row 8q + 4 + s' (half 1), so each lane needs 4 CONSECUTIVE rows of its
+// feature: one ds_read_b128 per operand per 4 MFMAs.
+template <int TB>
+__device__ __forceinline__ void wgrad_unit(const WgradDesc& d, const WgradUnit& un, float* __restrict__ img, f32x16 (&acc)[4], int ntiles,
+                                           int nchunks, int wave, int lane, int NTp, int KT, int g_lo, int ngr, int my_nt, int my_part,
+                                           int rsplit) {
+    constexpr int LD = TB == 1 ? kWgLd : kWgLdB;
+    constexpr int NGW = TB == 1 ? 4 : 1 * TB;     // G float4 per wave per interval (TB==4: NTp == 1 -> 4 groups x 4 tiles / 4 waves)
+    constexpr int NAW = TB == 1 ? 4 : 2 * TB;     // A float4 per wave per interval (TB==4: KT <= 2 -> 8 groups x 4 tiles / 4 waves)
     const int h = lane >> 5, j = lane & 31;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = wave + 4 * i;
-        if (g < NTp * 4) {
-            float* p = Gimg + (8 * g + 4 * h) * kWgLd + j;
-            p[0] = st.g[i].x; p[kWgLd] = st.g[i].y; p[2 * kWgLd] = st.g[i].z; p[3 * kWgLd] = st.g[i].w;
-        }
-        if (g < KT * 4) {
-            float* p = Aimg + (8 * g + 4 * h) * kWgLd + j;
-            p[0] = st.a[i].x; p[kWgLd] = st.a[i].y; p[2 * kWgLd] = st.a[i].z; p[3 * kWgLd] = st.a[i].w;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_wgrad(const WgradDesc* __restrict__ descs, const WgradUnit* __restrict__ units,
-                                               float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks) {
-    // two (G, A) image pairs: tile t+1 is fetched during the MFMAs of tile t and staged after them; one barrier per tile
-    __shared__ __attribute__((aligned(16))) float img[2 * 2 * kWgImg];
-    const WgradUnit un = units[blockIdx.x];
-    const WgradDesc d = descs[un.desc];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = lane >> 5, j = lane & 31;
-    const int NT = (d.N + 31) / 32;
-    const int NTp = NT <= 1 ? 1 : (NT == 2 ? 2 : 4);      // n-tiles padded to a divisor of 4
-    const int rsplit = 4 / NTp;                           // waves sharing one n-tile split the 4 row quads
-    const int my_nt = wave % NTp, my_part = wave / NTp;
-    const int g_lo = un.kblk * 16;
-    const int g_hi = (g_lo + 16 < d.KG) ? g_lo + 16 : d.KG;
-    const int ngr = g_hi - g_lo;                          // A groups handled here (<= 16)
-    const int KT = (ngr + 3) / 4;
+    const int gimg = TB == 1 ? kWgImg : 32 * LD;  // floats of the G image
+    const int pair = TB == 1 ? 2 * kWgImg : 0;    // distance between the two buffers (TB == 1 only)
     const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
     const int t_lo = un.chunk * tiles_per_chunk;
     const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
-
-    f32x16 acc[4];
-    acc_zero<4>(acc);
-    WgStage st;
-    if (t_lo < t_hi) {
-        wgrad_fetch(d, st, t_lo, wave, lane, NTp, g_lo, ngr, KT);
-        wgrad_stage(st, img, img + kWgImg, wave, lane, NTp, KT);
-    }
+    float4 sg[NGW], sa[NAW];
+    // item i of this wave: (group, tile-in-interval)
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < NGW; ++i) {
+            const int item = wave + 4 * i, g = TB == 1 ? item : item % 4, tt = TB == 1 ? 0 : item / 4;
+            sg[i] = (g < NTp * 4 && t0 + tt < t_hi) ? wgrad_load_g(d, t0 + tt, g, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NAW; ++i) {
+            const int item = wave + 4 * i, gi = TB == 1 ? item : item % 8, tt = TB == 1 ? 0 : item / 8;
+            sa[i] = (gi < KT * 4 && gi < ngr && t0 + tt < t_hi) ? wgrad_load_a(d, t0 + tt, g_lo + gi, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](float* G, float* A) {
+#pragma unroll
+        for (int i = 0; i < NGW; ++i) {
+            const int item = wave + 4 * i, g = TB == 1 ? item : item % 4, tt = TB == 1 ? 0 : item / 4;
+            if (g < NTp * 4) wgrad_scatter(G, LD, g, tt, lane, sg[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NAW; ++i) {
+            const int item = wave + 4 * i, gi = TB == 1 ? item : item % 8, tt = TB == 1 ? 0 : item / 8;
+            if (gi < KT * 4) wgrad_scatter(A, LD, gi, tt, lane, sa[i]);
+        }
+    };
+    if (t_lo < t_hi) { fetch(t_lo); stage(img, img + gimg); }
     __syncthreads();
-    for (int tile = t_lo; tile < t_hi; ++tile) {
-        const int b = (tile - t_lo) & 1;
-        const float* Gimg = img + b * 2 * kWgImg;
-        const float* Aimg = Gimg + kWgImg;
-        const bool more = tile + 1 < t_hi;
-        if (more) wgrad_fetch(d, st, tile + 1, wave, lane, NTp, g_lo, ngr, KT);
-        // MFMA: i = out feature (n-tile my_nt), j = in feature (k-tile kt), k = batch row.  Quad q covers rows 8q..8q+7:
-        // k-step s' of the quad pairs row 8q + s' (lane half 0) with row 8q + 4 + s' (half 1), so each lane needs 4
-        // CONSECUTIVE rows of its feature: one ds_read_b128 per operand per 4 MFMAs.
-        const int q_lo = my_part * (4 / rsplit), q_hi = q_lo + 4 / rsplit;
-        for (int q = q_lo; q < q_hi; ++q) {
-            const float4 av = *reinterpret_cast<const float4*>(Gimg + (32 * my_nt + j) * kWgLd + 8 * q + 4 * h);
+    int buf = 0;
+    for (int t0 = t_lo; t0 < t_hi; t0 += TB) {
+        const float* Gimg = img + buf * pair;
+        const float* Aimg = Gimg + gimg;
+        const bool more = t0 + TB < t_hi;
+        if (more) fetch(t0 + TB);
+        const int nq = 4 * TB / rsplit, q_lo = my_part * nq;
+        for (int q = q_lo; q < q_lo + nq; ++q) {
+            const float4 av = *reinterpret_cast<const float4*>(Gimg + (32 * my_nt + j) * LD + 8 * q + 4 * h);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
                 if (kt < KT) {
-                    const float4 bv = *reinterpret_cast<const float4*>(Aimg + (32 * kt + j) * kWgLd + 8 * q + 4 * h);
+                    const float4 bv = *reinterpret_cast<const float4*>(Aimg + (32 * kt + j) * LD + 8 * q + 4 * h);
                     DSG_MFMA(acc[kt], av.x, bv.x);
                     DSG_MFMA(acc[kt], av.y, bv.y);
                     DSG_MFMA(acc[kt], av.z, bv.z);
                     DSG_MFMA(acc[kt], av.w, bv.w);
                 }
         }
-        if (more) {
-            float* nG = img + (b ^ 1) * 2 * kWgImg;
-            wgrad_stage(st, nG, nG + kWgImg, wave, lane, NTp, KT);
+        if (TB == 1) {
+            if (more) { float* nG = img + (buf ^ 1) * pair; stage(nG, nG + gimg); }
+            __syncthreads();
+            buf ^= 1;
+        } else {
+            __syncthreads();            // everyone is done reading the single image pair
+            if (more) stage(img, img + gimg);
+            __syncthreads();
         }
-        __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad(const WgradDesc* __restrict__ descs, const WgradUnit* __restrict__ units,
+                                               float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks) {
+    __shared__ __attribute__((aligned(16))) float img[kWgLdsFloats];
+    const WgradUnit un = units[blockIdx.x];
+    const WgradDesc d = descs[un.desc];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int NT = (d.N + 31) / 32;
+    const int NTp = NT <= 1 ? 1 : (NT == 2 ? 2 : 4);      // n-tiles padded to a divisor of 4
+    const int rsplit = 4 / NTp;                           // waves sharing one n-tile split the row quads
+    const int my_nt = wave % NTp, my_part = wave / NTp;
+    const int g_lo = un.kblk * 16;
+    const int g_hi = (g_lo + 16 < d.KG) ? g_lo + 16 : d.KG;
+    const int ngr = g_hi - g_lo;                          // A groups handled here (<= 16)
+    const int KT = (ngr + 3) / 4;
+
+    f32x16 acc[4];
+    acc_zero<4>(acc);
+    // small units are latency-bound per barrier interval: give them 4 row tiles per interval
+    if (NTp == 1 && KT <= 2) wgrad_unit<kWgTB>(d, un, img, acc, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+    else wgrad_unit<1>(d, un, img, acc, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+
     // ---- waves that split the rows of one n-tile add their partial tiles through LDS, then the first writes the slab
     if (rsplit > 1) {
         float* red = img;  // <= 2 n-tiles x 4 k-tiles x 16 regs x 64 lanes = 32 KiB <= sizeof(img)
@@ -664,22 +685,33 @@ __global__ __launch_bounds__(256) void k_colsum(const ColsumDesc* __restrict__ d
     const bool want2 = d.out2_off >= 0;
     const int g0x = d.x0.groups;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int tile = t_lo; tile < t_hi; ++tile) {
-        if (tile * 32 + j >= nrows) continue;
-        float4 p = ld4(d.P0 + ((size_t)tile * d.groups + G) * 256 + lane * 4);
-        if (want2) {
-            const Seg& sg = G < g0x ? d.x0 : d.x1;
-            const int gl = G < g0x ? G : G - g0x;
-            const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
-            const float2 ms = reinterpret_cast<const float2*>(d.rs)[(size_t)tile * 32 + j];
-            q[0] = fmaf(p.x, (xv.x - ms.x) * ms.y, q[0]); q[1] = fmaf(p.y, (xv.y - ms.x) * ms.y, q[1]);
-            q[2] = fmaf(p.z, (xv.z - ms.x) * ms.y, q[2]); q[3] = fmaf(p.w, (xv.w - ms.x) * ms.y, q[3]);
+    const Seg& sg = G < g0x ? d.x0 : d.x1;
+    const int gl = G < g0x ? G : G - g0x;
+    // 4 tiles per trip, all loads issued before the first use: the wave is latency-bound otherwise
+    for (int t0 = t_lo; t0 < t_hi; t0 += 4) {
+        float4 p[4], w[4], xv[4];
+        float2 ms[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tile = t0 + i < t_hi ? t0 + i : t_hi - 1;
+            p[i] = ld4(d.P0 + ((size_t)tile * d.groups + G) * 256 + lane * 4);
+            if (d.P1) w[i] = ld4(d.P1 + ((size_t)tile * d.groups + G) * 256 + lane * 4);
+            if (want2) {
+                xv[i] = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                ms[i] = reinterpret_cast<const float2*>(d.rs)[(size_t)tile * 32 + j];
+            }
         }
-        if (d.P1) {
-            const float4 w = ld4(d.P1 + ((size_t)tile * d.groups + G) * 256 + lane * 4);
-            p.x += w.x; p.y += w.y; p.z += w.z; p.w += w.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool live = t0 + i < t_hi && (t0 + i) * 32 + j < nrows;
+            const float k = live ? 1.f : 0.f;
+            if (want2) {
+                q[0] = fmaf(k * p[i].x, (xv[i].x - ms[i].x) * ms[i].y, q[0]); q[1] = fmaf(k * p[i].y, (xv[i].y - ms[i].x) * ms[i].y, q[1]);
+                q[2] = fmaf(k * p[i].z, (xv[i].z - ms[i].x) * ms[i].y, q[2]); q[3] = fmaf(k * p[i].w, (xv[i].w - ms[i].x) * ms[i].y, q[3]);
+            }
+            if (d.P1) { p[i].x += w[i].x; p[i].y += w[i].y; p[i].z += w[i].z; p[i].w += w[i].w; }
+            s[0] = fmaf(k, p[i].x, s[0]); s[1] = fmaf(k, p[i].y, s[1]); s[2] = fmaf(k, p[i].z, s[2]); s[3] = fmaf(k, p[i].w, s[3]);
         }
-        s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1)
