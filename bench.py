@@ -102,7 +102,8 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=3):
     DDPM.forward (q_sample + denoiser forward + backward in libdiffsg_hip) + ONE all-reduce of the flat 6.6 MB gradient
     bucket (RCCL, world > 1) + Adam.step + re-pack of the updated weights."""
     ddpm = build_model(dev, 20)
-    opt = torch.optim.Adam(ddpm.parameters(), lr=0.005, fused=True)
+    from diffsg_amd.train import FlatAdam
+    opt = FlatAdam(ddpm, lr=0.005)
     g = torch.Generator().manual_seed(100 + rank)
     cond = torch.rand(B, 80, generator=g).to(dev)
     y = (torch.rand(B, 80, generator=g) * (20.0 / 80)).to(dev)

@@ -88,12 +88,28 @@ class Downsample(_LinHolder):
     """UNetCF.py:245-248."""
 
 
+# In-place parameter updates that PyTorch's tensor version counters do not see (fused optimizers -- torch._fused_adam_ leaves
+# `_version` untouched -- and anything that writes through raw pointers) would leave the library's packed weights stale.
+# Every optimizer step in the process therefore bumps this counter, and every UNet1D re-packs on its next call.
+_OPT_EPOCH = [0]
+
+
+def _on_optimizer_step(*_args, **_kw):
+    _OPT_EPOCH[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook  # noqa: E402
+
+_reg_post_hook(_on_optimizer_step)
+
+
 class _Native:
     """Owner of the dsg_handle; never copied or pickled with the module."""
 
     def __init__(self):
         self.handle = None
         self.bound_key = None
+        self.epoch = 0
 
     def __deepcopy__(self, memo):
         return _Native()
@@ -104,6 +120,7 @@ class _Native:
     def __setstate__(self, state):
         self.handle = None
         self.bound_key = None
+        self.epoch = 0
 
     def __del__(self):
         try:
@@ -182,7 +199,7 @@ class UNet1D(nn.Module):
             for i, (k, v) in enumerate(params):
                 if v.numel() != L.dsg_param_numel(hd, i):
                     raise RuntimeError(f"size mismatch for {k}")
-        key = tuple((v.data_ptr(), v._version) for _, v in params)
+        key = (nat.epoch, _OPT_EPOCH[0]) + tuple((v.data_ptr(), v._version) for _, v in params)
         if key != nat.bound_key:
             for k, v in params:
                 if v.dtype != torch.float32 or not v.is_contiguous():
@@ -192,6 +209,10 @@ class UNet1D(nn.Module):
                 _lib.check(L.dsg_bind_weights(nat.handle, arr, len(params), _lib.stream_ptr()))
             nat.bound_key = key
         return nat.handle
+
+    def mark_weights_changed(self):
+        """Parameters were updated in place through an aliasing tensor (train.FlatAdam): re-pack on the next call."""
+        self._native.epoch += 1
 
     def set_precision(self, mode):
         """Arithmetic of the >= 64-wide blocks inside DDPM.sample: "split_f16" (default; float32-accurate hi/lo fp16

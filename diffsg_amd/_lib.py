@@ -31,7 +31,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(p) for p in deps)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+    # -fno-slp-vectorize: with the SLP vectoriser on, the packed-f32 code it forms in k_wgrad_h gave run-to-run different
+    # results on gfx950 ("Build flags"); without it the library is deterministic and 2-5 % faster.
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-fno-slp-vectorize",
            "-o", LIB_PATH] + SOURCES
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -77,7 +77,8 @@ def train_ddpm_msr(dataset_path=DEFAULT_DATASET, epochs=200, T=20, use_ema=False
     diffusion_model = build_model(M, custom_config['sfn'] * M, device, T, custom_config, W)
     diffusion_model.apply(init_weights)
     diffusion_model.to(device)
-    optimizer = optim.Adam(diffusion_model.parameters(), lr=lr, fused=True)  # same update rule, one multi-tensor kernel
+    from .train import FlatAdam
+    optimizer = FlatAdam(diffusion_model, lr=lr)  # torch Adam, same update rule, over one flat tensor (one launch)
     scheduler = optim.lr_scheduler.MultiStepLR(optimizer, list(milestones))
     from .train import run_epochs
     run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log)

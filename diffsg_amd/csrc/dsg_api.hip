@@ -4,6 +4,7 @@
 #include "dsg_kernels.hpp"
 #include "dsg_train.hpp"
 #include "dsg_split.hpp"
+#include "dsg_train_split.hpp"
 #include "../../include/diffsg.h"
 
 #include <math.h>
@@ -171,6 +172,8 @@ struct dsg_handle {
     float* tr_ws = nullptr;
     float* tr_slabs = nullptr;   // [chunks][slab_stride]
     float* tr_gsum = nullptr;    // [slab_stride]
+    unsigned* tr_gmax = nullptr; // max|G| per gradient tensor (float bits), zeroed every step
+    int n_gmax = 0;
     size_t slab_stride = 0;
     int* tr_ts = nullptr;        // [rows]
     float* tr_yt_rm = nullptr;   // [rows][D]
@@ -305,13 +308,15 @@ void free_graphs(dsg_handle* h) {
     h->g_rows = -1;
 }
 
+constexpr int kMaxGmax = 1024;   // distinct gradient tensors whose max|G| is tracked (3 per block + 1 per Linear)
+
 void free_train_workspace(dsg_handle* h) {
     void* ptrs[] = {h->tr_ws, h->tr_slabs, h->tr_gsum, h->tr_ts, h->tr_yt_rm, h->tr_tsave, h->wg_desc_dev, h->wg_unit_dev,
-                    h->cs_desc_dev, h->cs_unit_dev};
+                    h->cs_desc_dev, h->cs_unit_dev, h->tr_gmax};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->tr_ws = h->tr_slabs = h->tr_gsum = h->tr_yt_rm = h->tr_tsave = nullptr;
-    h->tr_ts = nullptr;
+    h->tr_ts = nullptr; h->tr_gmax = nullptr;
     h->wg_desc_dev = nullptr; h->wg_unit_dev = nullptr; h->cs_desc_dev = nullptr; h->cs_unit_dev = nullptr;
     h->wg_units = h->cs_units = 0;
     h->tr_rows = h->tr_T = 0;
@@ -733,6 +738,7 @@ int ensure_train_workspace(dsg_handle* h, int rows, int T) {
     HIPCK(hipMalloc(&h->tr_slabs, (size_t)max_chunks * h->slab_stride * sizeof(float)));
     HIPCK(hipMemset(h->tr_slabs, 0, (size_t)max_chunks * h->slab_stride * sizeof(float)));
     HIPCK(hipMalloc(&h->tr_gsum, h->slab_stride * sizeof(float)));
+    HIPCK(hipMalloc(&h->tr_gmax, kMaxGmax * sizeof(unsigned)));
     HIPCK(hipMalloc(&h->tr_ts, (size_t)nrows * sizeof(int)));
     HIPCK(hipMalloc(&h->tr_yt_rm, (size_t)nrows * D * sizeof(float)));
     HIPCK(hipMalloc(&h->tr_tsave, ((size_t)T * 2 * half + (size_t)(5 + kTimeChunks) * T * td) * sizeof(float)));
@@ -748,7 +754,15 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
     const int tiles = cdiv(B, 32);
     h->tr_chunks = tiles < 32 ? tiles : 32;
     std::vector<WgradDesc> wd;
+    std::vector<int> wd_op;            // operator each descriptor belongs to
+    int cur_op = 0;
     std::vector<ColsumDesc> cd;
+    std::vector<const float*> gsrc;    // distinct G tensors, by first pointer: slot of max|G|
+    auto slot_of = [&](const float* g) {
+        for (size_t i = 0; i < gsrc.size(); ++i) if (gsrc[i] == g) return (int)i;
+        gsrc.push_back(g);
+        return (int)gsrc.size() - 1;
+    };
     auto gseg = [&](const float* data, int width) { Seg sg; sg.data = data; sg.stats = nullptr; sg.groups = groups_of(width); sg.width = width; return sg; };
     auto none = [&]() { Seg sg; sg.data = nullptr; sg.stats = nullptr; sg.groups = 0; sg.width = 0; return sg; };
     auto wgrad = [&](const float* G0, const float* G1, int N, int amode, Seg a0, Seg a1, const float* rs, const float* gm,
@@ -759,7 +773,9 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
         d.ts = h->tr_ts; d.onehot_n = T; d.out_off = out_off; d.ld = ld;
         d.KG = amode == A_ONEHOT ? groups_of(T) : a0.groups + a1.groups;
         d.nrows = B;
+        d.gmax_slot = slot_of(G0);
         wd.push_back(d);
+        wd_op.push_back(cur_op);
     };
     auto colsum = [&](const float* P0, const float* P1, int groups, Seg x0, Seg x1, const float* rs, int w0, int w1, long long o1,
                       long long o1b, long long o2) {
@@ -767,12 +783,14 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
         memset(&d, 0, sizeof d);
         d.P0 = P0; d.P1 = P1; d.groups = groups; d.x0 = x0; d.x1 = x1; d.rs = rs; d.w0 = w0; d.w1 = w1;
         d.out_off = o1; d.out_off_b = o1b; d.out2_off = o2;
+        d.gmax_slot = o2 < 0 ? slot_of(P0) : -1;     // the plain sums are exactly the G tensors of the weight gradients
         cd.push_back(d);
     };
     auto grad_a = [&](int tid) { return (const float*)trp(h, h->tensors[tid].ga); };
     auto grad_b = [&](int tid) { return h->tensors[tid].is_skip ? (const float*)trp(h, h->tensors[tid].gb) : (const float*)nullptr; };
 
     for (const Op& op : h->ops) {
+        ++cur_op;
         if (op.kind == OP_RES) {
             const ResP& r = h->res[op.p];
             const Seg in0 = seg_of(h, op.in0), in1 = op.in1 >= 0 ? seg_of(h, op.in1) : none();
@@ -807,19 +825,41 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
             }
         }
     }
-    std::vector<WgradUnit> wu;
-    for (size_t i = 0; i < wd.size(); ++i)
-        for (int kb = 0; kb < cdiv(wd[i].KG, 16); ++kb)
-            for (int c = 0; c < h->tr_chunks; ++c) wu.push_back(WgradUnit{(int)i, kb, c, 0});
-    // longest units first: the proj_dim-wide up blocks come last in op order and would otherwise form the tail
+    // every G tensor of a weight gradient must be covered by a plain column sum (each Linear has a bias), or its scale is never set
     {
-        auto cost = [&](const WgradUnit& u) {
-            const WgradDesc& d = wd[u.desc];
+        std::vector<char> seen(gsrc.size(), 0);
+        for (const ColsumDesc& c : cd) if (c.gmax_slot >= 0) seen[c.gmax_slot] = 1;
+        for (const WgradDesc& w : wd) if (!seen[w.gmax_slot]) { fail("internal: weight-gradient operand without a tracked maximum"); return 1; }
+        if ((int)gsrc.size() > kMaxGmax) { fail("internal: too many gradient tensors (%d)", (int)gsrc.size()); return 1; }
+        h->n_gmax = (int)gsrc.size();
+    }
+    // Launch order of the (descriptor, k-block, row-chunk) units:
+    //   * operators with the longest units first (the proj_dim-wide up blocks come last in op order and would form the tail);
+    //   * inside an operator, 8 row chunks at a time, every unit of the operator over those 8 chunks: workgroup i runs on XCD
+    //     i % 8, so the units that re-read the same rows of dh1 / dh2 / dout / the block input are neighbours in time on the
+    //     same XCD and find them in its L2.
+    std::vector<WgradUnit> wu;
+    {
+        auto cost = [&](int di, int kb) {
+            const WgradDesc& d = wd[di];
             const int nt = cdiv(d.N, 32), ntp = nt <= 1 ? 1 : (nt == 2 ? 2 : 4);
-            const int ngr = d.KG - u.kblk * 16 < 16 ? d.KG - u.kblk * 16 : 16;
+            const int ngr = d.KG - kb * 16 < 16 ? d.KG - kb * 16 : 16;
             return ntp * cdiv(ngr, 4);
         };
-        std::stable_sort(wu.begin(), wu.end(), [&](const WgradUnit& a, const WgradUnit& b) { return cost(a) > cost(b); });
+        struct OpUnits { int cost; std::vector<std::pair<int, int>> u; };
+        std::vector<OpUnits> ou;
+        for (size_t i = 0; i < wd.size(); ++i) {
+            if (i == 0 || wd_op[i] != wd_op[i - 1]) ou.push_back(OpUnits{0, {}});
+            for (int kb = 0; kb < cdiv(wd[i].KG, 16); ++kb) {
+                ou.back().u.push_back({(int)i, kb});
+                ou.back().cost = std::max(ou.back().cost, cost((int)i, kb));
+            }
+        }
+        std::stable_sort(ou.begin(), ou.end(), [](const OpUnits& a, const OpUnits& b) { return a.cost > b.cost; });
+        for (const OpUnits& o : ou)
+            for (int c0 = 0; c0 < h->tr_chunks; c0 += 8)
+                for (const auto& u : o.u)
+                    for (int c = c0; c < c0 + 8 && c < h->tr_chunks; ++c) wu.push_back(WgradUnit{u.first, u.second, c, 0});
     }
     std::vector<ColsumUnit> cu;
     for (size_t i = 0; i < cd.size(); ++i)
@@ -849,7 +889,7 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
 void small_gemm(const float* A, long long ai, long long al, const float* B, long long bl, long long bj, float* C, long long ci,
                 long long cj, int M, int N, int L, int acc, hipStream_t s) {
     const long long total = (long long)M * N;
-    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const unsigned blocks = (unsigned)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
     hipLaunchKernelGGL(k_small_gemm, dim3(blocks), dim3(256), 0, s, A, ai, al, B, bl, bj, C, ci, cj, M, N, L, acc);
 }
 
@@ -1359,10 +1399,15 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
         }
     }
     // ---- weight / bias / LayerNorm gradients: two grouped launches into per-chunk slabs, then a fixed-order reduce
-    hipLaunchKernelGGL(k_wgrad, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_slabs, h->slab_stride, tiles,
-                       h->tr_chunks);
+    HIPCK(hipMemsetAsync(h->tr_gmax, 0, (size_t)h->n_gmax * sizeof(unsigned), s));
     hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->cs_units, 4)), dim3(256), 0, s, h->cs_desc_dev, h->cs_unit_dev, h->cs_units, h->tr_slabs,
-                       h->slab_stride, tiles, h->tr_chunks, B);
+                       h->slab_stride, tiles, h->tr_chunks, B, h->tr_gmax);
+    if (h->use_split)
+        hipLaunchKernelGGL(k_wgrad_h, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_gmax, h->tr_slabs,
+                           h->slab_stride, tiles, h->tr_chunks);
+    else
+        hipLaunchKernelGGL(k_wgrad, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_slabs, h->slab_stride, tiles,
+                           h->tr_chunks);
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((h->slab_stride + 255) / 256 < 4096 ? (h->slab_stride + 255) / 256 : 4096)), dim3(256),
                        0, s, h->tr_slabs, h->slab_stride, h->tr_chunks, h->tr_gsum, h->slab_stride);
 

@@ -462,6 +462,7 @@ struct WgradDesc {
     int ld;                             // row stride of dW (= Ktot)
     int KG;                             // total A groups
     int nrows;
+    int gmax_slot;                      // split path: index of max|G| (tracked by k_colsum) that sets the operand scale
 };
 struct WgradUnit { int desc; int kblk; int chunk; int pad; };
 
@@ -668,11 +669,13 @@ struct ColsumDesc {
     long long out_off;          // sum P      -> slab[out_off + col]   (or -1)
     long long out_off_b;        // second destination of the same sum (or -1)
     long long out2_off;         // sum P*xhat -> slab[out2_off + col]  (or -1)
+    int gmax_slot;              // >= 0: also track max|P0 + P1| into gmax[slot] (operand scale of the split weight gradient)
 };
 struct ColsumUnit { int desc; int group; int chunk; int pad; };
 
 __global__ __launch_bounds__(256) void k_colsum(const ColsumDesc* __restrict__ descs, const ColsumUnit* __restrict__ units, int nunits,
-                                                float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks, int nrows) {
+                                                float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks, int nrows,
+                                                unsigned* __restrict__ gmax) {
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (u >= nunits) return;
     const ColsumUnit un = units[u];
@@ -685,6 +688,7 @@ __global__ __launch_bounds__(256) void k_colsum(const ColsumDesc* __restrict__ d
     const bool want2 = d.out2_off >= 0;
     const int g0x = d.x0.groups;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned mx = 0u;                 // max |P0 + P1| as float bits (orders like the value; NaN sorts above everything)
     const Seg& sg = G < g0x ? d.x0 : d.x1;
     const int gl = G < g0x ? G : G - g0x;
     // 4 tiles per trip, all loads issued before the first use: the wave is latency-bound otherwise
@@ -711,7 +715,22 @@ __global__ __launch_bounds__(256) void k_colsum(const ColsumDesc* __restrict__ d
             }
             if (d.P1) { p[i].x += w[i].x; p[i].y += w[i].y; p[i].z += w[i].z; p[i].w += w[i].w; }
             s[0] = fmaf(k, p[i].x, s[0]); s[1] = fmaf(k, p[i].y, s[1]); s[2] = fmaf(k, p[i].z, s[2]); s[3] = fmaf(k, p[i].w, s[3]);
+            if (live) {
+                const unsigned a0 = __float_as_uint(p[i].x) & 0x7fffffffu, a1 = __float_as_uint(p[i].y) & 0x7fffffffu;
+                const unsigned a2 = __float_as_uint(p[i].z) & 0x7fffffffu, a3 = __float_as_uint(p[i].w) & 0x7fffffffu;
+                const unsigned m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3;
+                const unsigned m = m01 > m23 ? m01 : m23;
+                mx = mx > m ? mx : m;
+            }
         }
+    }
+    if (d.gmax_slot >= 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned t = (unsigned)__shfl_xor((int)mx, o);
+            mx = mx > t ? mx : t;
+        }
+        if (lane == 0 && mx) atomicMax(gmax + d.gmax_slot, mx);
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1)
@@ -750,15 +769,40 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, size_t slab_stri
 // Time-path backward on the [entries x .] tables: tiny dense products, one thread per output.
 //   C[i][j] (+)= sum_l A[i*ai + l*al] * B[l*bl + j*bj]      (optional elementwise factor on A: swish'(Apre))
 // ---------------------------------------------------------------------------------------------
-__global__ void k_small_gemm(const float* __restrict__ A, long long ai, long long al, const float* __restrict__ B, long long bl,
-                             long long bj, float* __restrict__ C, long long ci, long long cj, int M, int N, int L, int accumulate) {
+__global__ __launch_bounds__(256) void k_small_gemm(const float* __restrict__ A, long long ai, long long al, const float* __restrict__ B,
+                                                    long long bl, long long bj, float* __restrict__ C, long long ci, long long cj, int M, int N,
+                                                    int L, int accumulate) {
+    // 64 outputs per block, the contraction cut into 4 slices (one per wave) with 4 independent partial sums each: the
+    // tables are tiny, so the kernel is bound by the length of one thread's dependent load chain, not by bandwidth
+    __shared__ float part[4][64];
     const long long total = (long long)M * N;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int jn = idx % N, im = idx / N;
-        float s = 0.f;
-        for (int l = 0; l < L; ++l) s = fmaf(A[im * ai + l * al], B[l * bl + jn * bj], s);
-        float* c = C + im * ci + jn * cj;
-        *c = accumulate ? *c + s : s;
+    const int t = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int l0 = (int)((long long)L * sl / 4), l1 = (int)((long long)L * (sl + 1) / 4);
+    for (long long base = blockIdx.x * 64LL; base < total; base += (long long)gridDim.x * 64) {
+        const long long idx = base + t;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (idx < total) {
+            const int jn = idx % N, im = idx / N;
+            const float* a = A + im * ai;
+            const float* b = B + jn * bj;
+            int l = l0;
+            for (; l + 3 < l1; l += 4) {
+                s0 = fmaf(a[l * al], b[l * bl], s0);
+                s1 = fmaf(a[(l + 1) * al], b[(l + 1) * bl], s1);
+                s2 = fmaf(a[(l + 2) * al], b[(l + 2) * bl], s2);
+                s3 = fmaf(a[(l + 3) * al], b[(l + 3) * bl], s3);
+            }
+            for (; l < l1; ++l) s0 = fmaf(a[l * al], b[l * bl], s0);
+        }
+        part[sl][t] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (sl == 0 && idx < total) {
+            const int jn = idx % N, im = idx / N;
+            const float v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+            float* c = C + im * ci + jn * cj;
+            *c = accumulate ? *c + v : v;
+        }
+        __syncthreads();
     }
 }
 

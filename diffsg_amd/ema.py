@@ -43,4 +43,6 @@ class ExponentialMovingAverage(nn.Module):
             else:
                 raise RuntimeError("ExponentialMovingAverage.update_parameters: averaged weights are not on a HIP "
                                    "device; there is no CPU path")
+        if hasattr(self.module, "mark_weights_changed"):
+            self.module.mark_weights_changed()     # dsg_ema_update writes through raw pointers: tensor versions do not move
         self.n_averaged += 1

@@ -8,6 +8,54 @@ not communicated.
 """
 from __future__ import annotations
 
+import torch
+
+
+def flatten_parameters(unet):
+    """Re-point every parameter of `unet` at a slice of ONE flat float32 tensor (state-dict order = the order of the
+    gradient bucket, `DDPM.grad_bucket`) and return that tensor.  `state_dict()` / `load_state_dict()` are unchanged: the
+    parameters are still separate `nn.Parameter`s, they only share storage."""
+    params = list(unet.parameters())
+    flat = torch.empty(sum(p.numel() for p in params), device=params[0].device, dtype=params[0].dtype)
+    off = 0
+    for p in params:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view_as(p)
+        off += n
+    return flat
+
+
+class FlatAdam(torch.optim.Adam):
+    """torch.optim.Adam (the reference's optimizer, classifier_free_MSR.py:209) applied to the model's parameters as ONE
+    flat tensor whose gradient is the flat bucket written by dsg_train_step: the update is elementwise, so it is the same
+    arithmetic as Adam over the ~330 separate tensors, in one kernel launch instead of one multi-tensor launch per chunk
+    of tensors.  A torch `Optimizer`, so MultiStepLR drives it as it drives the reference's."""
+
+    def __init__(self, diffusion_model, lr=1e-3, **kw):
+        self._ddpm = diffusion_model
+        self._flat = torch.nn.Parameter(flatten_parameters(diffusion_model.model))
+        kw.setdefault("fused", True)
+        super().__init__([self._flat], lr=lr, **kw)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        bucket = self._ddpm.grad_bucket
+        if bucket is None or next(self._ddpm.model.parameters()).grad is None:
+            return None                    # no backward since the last zero_grad
+        self._flat.grad = bucket
+        out = super().step(closure)
+        self._ddpm.model.mark_weights_changed()   # in-place update through an alias: the per-parameter versions do not move
+        return out
+
+    def zero_grad(self, set_to_none=True):
+        self._flat.grad = None
+        for p in self._ddpm.model.parameters():
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
 
 
 def run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log=print):

@@ -272,6 +272,108 @@ def test_training_reduces_loss_and_matches_cpu_adam():
         assert rel(v, cpu[k].detach()) <= 1e-3, k
 
 
+@pytest.mark.parametrize("name,B", [("msr3", 512), ("msr80", 96)])
+def test_train_step_is_run_to_run_deterministic(name, B):
+    """Same inputs -> bit-identical loss and gradients, 12 times (every reduction has a fixed order; this also guards the
+    build flags: SLP-vectorised packed-f32 code made k_wgrad_h differ from run to run on gfx950)."""
+    plan, p = synth_params(name, 9)
+    T = 20
+    ddpm = make_ddpm(name, p, T)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(B + 1)
+    y = torch.rand(B, cfg["input_dim"], generator=g).cuda()
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    ts = torch.randint(0, T, (1, B), generator=g).cuda()
+    noise = torch.randn(B, cfg["input_dim"], generator=g).cuda()
+    mask = (torch.rand(B, 1, generator=g) < 0.9).float().cuda()
+    first = None
+    for rep in range(12):
+        for q in ddpm.model.parameters():
+            q.grad = None
+        loss = ddpm(y, cond, ts=ts, noise=noise, cond_mask=mask)
+        loss.backward()
+        cur = [float(loss)] + [q.grad.detach().clone() for q in ddpm.model.parameters()]
+        if first is None:
+            first = cur
+            continue
+        assert cur[0] == first[0], rep
+        for (k, _), a, b in zip(ddpm.model.named_parameters(), cur[1:], first[1:]):
+            assert torch.equal(a, b), (rep, k)
+
+
+def test_sampling_is_run_to_run_deterministic():
+    """Same seed -> bit-identical samples (device Philox noise, fixed-order renorm reductions)."""
+    name, T, B = "msr80", 20, 4096
+    plan, p = synth_params(name, 4)
+    ddpm = make_ddpm(name, p, T)
+    cond = torch.rand(B, CONFIGS[name]["cond_dim"], generator=torch.Generator().manual_seed(1)).cuda()
+    outs = [ddpm.sample(cond, 1.0, seed=7).clone() for _ in range(4)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+def test_fused_optimizer_updates_are_seen_by_the_library():
+    """torch's fused Adam updates the parameters without moving their `_version`; the packed weights must follow anyway
+    (optimizer-step hook in UNetCF).  Trajectory = the one of the default (foreach) Adam; EMA weights likewise."""
+    name, T, B = "tiny", 20, 96
+    plan, p = synth_params(name, 21)
+    a, b = make_ddpm(name, p, T), make_ddpm(name, p, T)
+    cfg = CONFIGS[name]
+    opt_a = torch.optim.Adam(a.parameters(), lr=2e-3, fused=True)
+    opt_b = torch.optim.Adam(b.parameters(), lr=2e-3)
+    g = torch.Generator().manual_seed(6)
+    for step in range(3):
+        y = torch.rand(B, cfg["input_dim"], generator=g).cuda()
+        cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+        ts = torch.randint(0, T, (1, B), generator=g).cuda()
+        noise = torch.randn(B, cfg["input_dim"], generator=g).cuda()
+        mask = (torch.rand(B, 1, generator=g) < 0.9).float().cuda()
+        la = a(y, cond, ts=ts, noise=noise, cond_mask=mask); la.backward(); opt_a.step(); opt_a.zero_grad()
+        lb = b(y, cond, ts=ts, noise=noise, cond_mask=mask); lb.backward(); opt_b.step(); opt_b.zero_grad()
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), step
+    # EMA: the averaged copy is written through raw pointers; sampling from it must use the new weights
+    a.ema.update_parameters(a.model)
+    cond = torch.rand(64, cfg["cond_dim"], generator=g).cuda()
+    s0 = a.ema.module  # first update = copy of the model
+    x = torch.rand(64, cfg["input_dim"], generator=g).cuda()
+    t = torch.full((64, 1), 0.5).cuda()
+    m = torch.ones(64, 1).cuda()
+    assert rel(s0(x, t, cond, m).cpu(), a.model(x, t, cond, m).cpu()) <= 1e-6
+    other = make_ddpm(name, synth_params(name, 22)[1], T).model     # different weights to average towards
+    a.ema.update_parameters(other)
+    out1 = s0(x, t, cond, m).clone()
+    a.ema.update_parameters(other)
+    assert not torch.equal(out1, s0(x, t, cond, m))
+
+
+def test_flat_adam_is_adam_bit_for_bit():
+    """train.FlatAdam (one flat tensor, one launch) makes exactly the updates torch.optim.Adam makes on the separate
+    parameters, and the re-pointed parameters keep the state-dict layout and stay bound to the library."""
+    from diffsg_amd.train import FlatAdam
+    name, T, B = "tiny", 20, 96
+    plan, p = synth_params(name, 17)
+    a, b = make_ddpm(name, p, T), make_ddpm(name, p, T)
+    cfg = CONFIGS[name]
+    keys = list(a.model.state_dict())
+    opt_a = torch.optim.Adam(a.parameters(), lr=2e-3, fused=True)
+    opt_b = FlatAdam(b, lr=2e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt_b, [2])
+    sched_a = torch.optim.lr_scheduler.MultiStepLR(opt_a, [2])
+    assert list(b.model.state_dict()) == keys
+    g = torch.Generator().manual_seed(5)
+    for step in range(4):
+        y = torch.rand(B, cfg["input_dim"], generator=g).cuda()
+        cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+        ts = torch.randint(0, T, (1, B), generator=g).cuda()
+        noise = torch.randn(B, cfg["input_dim"], generator=g).cuda()
+        mask = (torch.rand(B, 1, generator=g) < 0.9).float().cuda()
+        la = a(y, cond, ts=ts, noise=noise, cond_mask=mask); la.backward(); opt_a.step(); opt_a.zero_grad(); sched_a.step()
+        lb = b(y, cond, ts=ts, noise=noise, cond_mask=mask); lb.backward(); opt_b.step(); opt_b.zero_grad(); sched.step()
+        assert float(la) == float(lb), step
+    for (k, va), vb in zip(a.model.state_dict().items(), b.model.state_dict().values()):
+        assert torch.equal(va, vb), k
+
+
 def test_entry_points_train_save_load_eval(tmp_path):
     """train_ddpm_msr -> torch.save(state_dict) -> load_test_msr on the committed 200-row CSV slice (the reference's
     call sequence, classifier_free_MSR.py:347-355), plus the NU and CO loaders through their train entry points."""

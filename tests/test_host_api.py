@@ -131,3 +131,23 @@ def test_compute_entry_points_fail_loudly_without_gpu():
         d(x, c)
     with pytest.raises(RuntimeError):
         train_ddpm_msr(os.path.join(GOLD, "data", "3c_10w_200samples.csv"), epochs=1)
+
+
+def test_flatten_parameters_keeps_state_dict_and_aliases_one_buffer():
+    """train.flatten_parameters: same keys, shapes and values; every parameter is a slice of the flat tensor in
+    state-dict order (the order of the gradient bucket)."""
+    from diffsg_amd import UNet1D
+    from diffsg_amd.train import flatten_parameters
+    torch.manual_seed(0)
+    net = UNet1D(3, 16, 6, dims=(8, 4), is_attn=(False, False), n_blocks=1)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    flat = flatten_parameters(net)
+    after = net.state_dict()
+    assert list(after) == list(before) and flat.numel() == sum(v.numel() for v in before.values())
+    off = 0
+    for k, v in after.items():
+        assert torch.equal(v, before[k]), k
+        assert v.data_ptr() == flat.data_ptr() + 4 * off, k
+        off += v.numel()
+    flat.mul_(2.0)
+    assert torch.equal(net.state_dict()[list(before)[0]], 2.0 * before[list(before)[0]])

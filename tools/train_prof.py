@@ -7,7 +7,8 @@ import torch, bench
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device("cuda:0")
 ddpm = bench.build_model(dev, 20)
-opt = torch.optim.Adam(ddpm.parameters(), lr=0.005, fused=True)
+from diffsg_amd.train import FlatAdam
+opt = FlatAdam(ddpm, lr=0.005) if not os.environ.get('PLAIN_ADAM') else torch.optim.Adam(ddpm.parameters(), lr=0.005, fused=True)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 cond = torch.rand(B, 80, device=dev); y = torch.rand(B, 80, device=dev) * 0.25
 def one():
