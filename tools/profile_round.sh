@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profile: kernel-trace stats of the bench command + PMC passes (separate runs), summaries under gpurun_out/prof_round/
+# usage (on the GPU box): bash tools/profile_round.sh
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_round
+mkdir -p $OUT
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-train --no-cpu-baseline > $OUT/kt.log 2>&1
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_bench_sampling.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktt -o kt -- python3 tools/train_prof.py 10 65536 > $OUT/ktt.log 2>&1
+cp $(find $OUT/ktt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_train_65536.csv
+bash tools/pmc_bench.sh $OUT/pmc
+for k in "k_resblock_h<128, true>" "k_fused_narrow_h" "k_resblock_lin_h<128"; do
+  echo "== $k"; python3 tools/pmc_summary.py $OUT/pmc "$k"
+done > $OUT/pmc_summary.txt
+rm -rf $OUT/kt $OUT/ktt $OUT/pmc/p1 $OUT/pmc/p2 $OUT/pmc/p3 $OUT/pmc/p4
