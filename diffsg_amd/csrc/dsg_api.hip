@@ -66,6 +66,7 @@ struct ResP {              // ResidualBlock (UNetCF.py:49-95)
     size_t W1p, g1p, b1p, W2p, g2p, b2p, c2p, Wcp, W3p, g3p, b3p, c3p, Wscp;
     size_t W1T, W2T, W3T, WscT;  // transposed packs (data gradients)
     size_t W1h = 0, W2h = 0, W3h = 0, Wsch = 0;  // fp16-split planes (blocks >= 64 wide, sampling)
+    size_t W1Th = 0, W2Th = 0, W3Th = 0, WscTh = 0;  // transposed fp16-split planes (data gradients)
     bool split = false;
     // training workspace (per-tile float offsets)
     size_t h1, h2, du1, du2, du3, dh1, dh2, rs1, rs2, rs3;
@@ -269,6 +270,11 @@ void carve(dsg_handle* h) {
             r.W2h = c.take((size_t)NT * ((NG + 1) / 2) * 128 * 4);
             r.W3h = c.take((size_t)NT * ((NG + 1) / 2) * 128 * 4);
             r.Wsch = r.sclin ? c.take((size_t)NT * KS1 * 128 * 4) : 0;
+            const size_t KSn = (size_t)(NG + 1) / 2;
+            r.W1Th = c.take((size_t)OT1 * KSn * 128 * 4);
+            r.W2Th = c.take((size_t)NT * KSn * 128 * 4);
+            r.W3Th = c.take((size_t)NT * KSn * 128 * 4);
+            r.WscTh = r.sclin ? c.take((size_t)OT1 * KSn * 128 * 4) : 0;
         }
     }
     for (auto& l : h->lin) {
@@ -392,6 +398,22 @@ void launch_res_bwd_n(bool sclin, const BlockBwdArgs& a, hipStream_t s) {
     const dim3 grid(cdiv(a.ntiles, kWavesPerBlock)), block(256);
     if (sclin) hipLaunchKernelGGL((k_resblock_bwd<N, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_resblock_bwd<N, false>), grid, block, 0, s, a);
+}
+template <int N>
+void launch_res_bwd_h_n(bool sclin, const BlockBwdArgsH& a, hipStream_t s) {
+    const dim3 grid(cdiv(a.b.ntiles, kWavesPerBlock)), block(256);
+    if (sclin) hipLaunchKernelGGL((k_resblock_bwd_h<N, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_resblock_bwd_h<N, false>), grid, block, 0, s, a);
+}
+void launch_res_bwd_h(int N, bool sclin, const BlockBwdArgsH& a, hipStream_t s) {
+    switch (N) {
+        case 4: launch_res_bwd_h_n<4>(sclin, a, s); break;
+        case 8: launch_res_bwd_h_n<8>(sclin, a, s); break;
+        case 16: launch_res_bwd_h_n<16>(sclin, a, s); break;
+        case 32: launch_res_bwd_h_n<32>(sclin, a, s); break;
+        case 64: launch_res_bwd_h_n<64>(sclin, a, s); break;
+        case 128: launch_res_bwd_h_n<128>(sclin, a, s); break;
+    }
 }
 void launch_res_bwd(int N, bool sclin, const BlockBwdArgs& a, hipStream_t s) {
     switch (N) {
@@ -1123,6 +1145,16 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
                 const int NT = cdiv(l.N, 32), KS = (groups_of(w0) + 1) / 2 + (groups_of(w1) + 1) / 2;
                 d.W = P[l.w].ptr; d.dst = reinterpret_cast<uint4*>(A + off); d.m_self = h->maxabs + l.w; d.m_pair = pair ? h->maxabs + pair->w : nullptr;
                 d.role = role; d.N = l.N; d.Ktot = l.K; d.w0 = w0; d.w1 = w1; d.NT = NT; d.total = (long long)NT * KS * 128; d.blk_begin = hb;
+                d.transposed = 0;
+                hb += (d.total + 255) / 256;
+                hd.push_back(d);
+            };
+            auto pushhT = [&](const LinearP& l, const LinearP* pair, int role, int w0, int w1, size_t off) {
+                PackHDesc d;
+                const int OT = cdiv(groups_of(w0) + groups_of(w1), 4), KS = (groups_of(l.N) + 1) / 2;
+                d.W = P[l.w].ptr; d.dst = reinterpret_cast<uint4*>(A + off); d.m_self = h->maxabs + l.w; d.m_pair = pair ? h->maxabs + pair->w : nullptr;
+                d.role = role; d.N = l.N; d.Ktot = l.K; d.w0 = w0; d.w1 = w1; d.NT = OT; d.total = (long long)OT * KS * 128; d.blk_begin = hb;
+                d.transposed = 1;
                 hb += (d.total + 255) / 256;
                 hd.push_back(d);
             };
@@ -1134,6 +1166,10 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
                 pushh(r.l2, nullptr, 0, r.N, 0, r.W2h);
                 if (r.sclin) { pushh(r.l3, &r.sc, 1, r.N, 0, r.W3h); pushh(r.sc, &r.l3, 2, r.in0, r.in1, r.Wsch); }
                 else pushh(r.l3, nullptr, 0, r.N, 0, r.W3h);
+                pushhT(r.l1, nullptr, 0, r.in0, r.in1, r.W1Th);
+                pushhT(r.l2, nullptr, 0, r.N, 0, r.W2Th);
+                if (r.sclin) { pushhT(r.l3, &r.sc, 1, r.N, 0, r.W3Th); pushhT(r.sc, &r.l3, 2, r.in0, r.in1, r.WscTh); }
+                else pushhT(r.l3, nullptr, 0, r.N, 0, r.W3Th);
             }
             for (const LinOpP& l : h->lin) { want(l.l); pushh(l.l, nullptr, 0, l.l.K, 0, l.Wh); }
             h->mx_n = (int)mp.size(); h->packh_n = (int)hd.size(); h->packh_blocks = hb;
@@ -1378,7 +1414,18 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
             a.du1 = trp(h, r.du1); a.du2 = trp(h, r.du2); a.du3 = trp(h, r.du3); a.dh1 = trp(h, r.dh1); a.dh2 = trp(h, r.dh2);
             a.rs1 = trp(h, r.rs1); a.rs2 = trp(h, r.rs2); a.rs3 = trp(h, r.rs3);
             a.ntiles = tiles;
-            launch_res_bwd(r.N, r.sclin, a, s);
+            if (h->use_split) {
+                BlockBwdArgsH ah;
+                ah.b = a;
+                ah.W3Th = reinterpret_cast<const uint4*>(A + r.W3Th); ah.W2Th = reinterpret_cast<const uint4*>(A + r.W2Th);
+                ah.W1Th = reinterpret_cast<const uint4*>(A + r.W1Th);
+                ah.WscTh = r.sclin ? reinterpret_cast<const uint4*>(A + r.WscTh) : nullptr;
+                ah.m1 = h->maxabs + r.l1.w; ah.m2 = h->maxabs + r.l2.w; ah.m3 = h->maxabs + r.l3.w;
+                ah.msc = r.sclin ? h->maxabs + r.sc.w : nullptr;
+                launch_res_bwd_h(r.N, r.sclin, ah, s);
+            } else {
+                launch_res_bwd(r.N, r.sclin, a, s);
+            }
         } else {
             const LinOpP& l = h->lin[op.p];
             LinBwdArgs a;

@@ -711,6 +711,7 @@ struct PackHDesc {
     const float* m_pair;  // lin3 <-> shortcut partner or null
     int role;             // 0: standalone, 1: lin3 with shortcut partner, 2: shortcut with lin3 partner
     int N, Ktot, w0, w1, NT;
+    int transposed;       // 1: A operand = W^T (rows = input features in padded group order, k = output features): data gradients
     long long total;      // uint4 elements of dst
     long long blk_begin;
 };
@@ -732,10 +733,28 @@ __global__ __launch_bounds__(256) void k_pack_h(const PackHDesc* __restrict__ de
     const int lane = idx & 63, plane = (idx >> 6) & 1;
     const long long ts = idx >> 7;
     const int g0 = (d.w0 + 7) / 8, g1 = (d.w1 + 7) / 8;
+    const int h = lane >> 5;
+    h8 out;
+    if (d.transposed) {
+        const int KS = ((d.N + 7) / 8 + 1) >> 1;
+        const int S = ts % KS, nt = ts / KS;
+        // row of W^T = input feature in padded group order (each concat segment padded to whole groups)
+        const int r = 32 * nt + (lane & 31), G = r >> 3, e = r & 7;
+        int col = -1;
+        if (G < g0) { if (8 * G + e < d.w0) col = 8 * G + e; }
+        else if (G < g0 + g1) { const int c = 8 * (G - g0) + e; if (c < d.w1) col = d.w0 + c; }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int kf = 8 * (2 * S + (jj >> 2)) + 4 * h + (jj & 3);
+            float v = 0.f;
+            if (col >= 0 && kf < d.N) v = d.W[(size_t)kf * d.Ktot + col] * sc;
+            const _Float16 vh = (_Float16)v;
+            out[jj] = plane == 0 ? vh : (_Float16)(v - (float)vh);
+        }
+    } else {
     const int ks0 = (g0 + 1) >> 1, KS = ks0 + ((g1 + 1) >> 1);
     const int S = ts % KS, nt = ts / KS;
-    const int n = 32 * nt + (lane & 31), h = lane >> 5;
-    h8 out;
+    const int n = 32 * nt + (lane & 31);
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
         const int p = jj & 3;
@@ -751,6 +770,7 @@ __global__ __launch_bounds__(256) void k_pack_h(const PackHDesc* __restrict__ de
         if (col >= 0 && n < d.N) v = d.W[(size_t)n * d.Ktot + col] * sc;
         const _Float16 vh = (_Float16)v;
         out[jj] = plane == 0 ? vh : (_Float16)(v - (float)vh);
+    }
     }
     d.dst[idx] = __builtin_bit_cast(uint4, out);
 }

@@ -200,14 +200,23 @@ struct BlockBwdArgs {
     int ntiles;
 };
 
+// The four data-gradient GEMMs of a block go through a policy object (`gemm.run<NGin, NTin, NTout>(out, in, which, accumulate)`,
+// which = 3, 2, 1 for W3^T, W2^T, W1^T and 0 for the Linear shortcut): exact f32 MFMA here, split-f16 in dsg_train_split.hpp.
+struct BwdGemmF32 {
+    const BlockBwdArgs& a;
+    int lane;
+    template <int NGin, int NTin, int NTout>
+    __device__ __forceinline__ void run(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], int which, bool /*accumulate*/) const {
+        const float* wp = which == 3 ? a.W3T : (which == 2 ? a.W2T : (which == 1 ? a.W1T : a.WscT));
+        chain_raw_from_acc<NGin, NTin, NTout>(out, in, wp, lane);
+    }
+};
+
 // SCLIN <=> the block has a concat input (up blocks): the stage-1 data gradient then spans 2*NG groups.
-template <int N, bool SCLIN>
-__global__ __launch_bounds__(256) void k_resblock_bwd(const BlockBwdArgs a) {
+template <int N, bool SCLIN, class Gemm>
+__device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const Gemm& gemm, int tile, int lane) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
     constexpr int KGT = SCLIN ? (2 * NG + 3) / 4 : NT;  // 32-feature output tiles of dL/dx
-    const int lane = threadIdx.x & 63;
-    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
-    if (tile >= a.ntiles) return;
     const int h = lane >> 5, j = lane & 31;
     const int KG = a.in0.groups + a.in1.groups;
     const size_t tN = (size_t)tile * NG * 256 + lane * 4;
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256) void k_resblock_bwd(const BlockBwdArgs a) {
     // ---- stage 3: d a3 = W3^T g ; LN3/SiLU backward with h2
     f32x16 d[NT], x[NT];
     acc_zero<NT>(d);
-    chain_raw_from_acc<NG, NT, NT>(d, g, a.W3T, lane);
+    gemm.template run<NG, NT, NT>(d, g, 3, false);
     acc_load<NG, NT>(x, a.h2 + tN);
     {
         float mean, m2;
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256) void k_resblock_bwd(const BlockBwdArgs a) {
     // ---- stage 2: d a2 = W2^T dh2 ; LN2/SiLU backward with h1
     f32x16 (&d1)[NT] = g;  // reuse: g is re-read from memory for the shortcut
     acc_zero<NT>(d1);
-    chain_raw_from_acc<NG, NT, NT>(d1, d, a.W2T, lane);
+    gemm.template run<NG, NT, NT>(d1, d, 2, false);
     acc_load<NG, NT>(x, a.h1 + tN);
     {
         float mean, m2;
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256) void k_resblock_bwd(const BlockBwdArgs a) {
     }
     f32x16 dx[KGT];
     acc_zero<KGT>(dx);
-    chain_raw_from_acc<NG, NT, KGT>(dx, d1, a.W1T, lane);
+    gemm.template run<NG, NT, KGT>(dx, d1, 1, false);
     {
         // pass 1: du, t = du*gamma, row sums (x streamed from memory, group by group)
         float s1 = 0.f, s2 = 0.f;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256) void k_resblock_bwd(const BlockBwdArgs a) {
         acc_load<NG, NT>(gg, a.gout_a + tN);
         if (a.gout_b) acc_load_add<NG, NT>(gg, a.gout_b + tN);
         if (SCLIN) {
-            chain_raw_from_acc<NG, NT, KGT>(dx, gg, a.WscT, lane);
+            gemm.template run<NG, NT, KGT>(dx, gg, 0, true);
         } else {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) dx[nt] += gg[nt];
@@ -336,6 +345,14 @@ __global__ __launch_bounds__(256) void k_resblock_bwd(const BlockBwdArgs a) {
             else st4(a.gin1 + ((size_t)tile * a.in1.groups + (G - a.in0.groups)) * 256 + lane * 4, v);
         }
     }
+}
+
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256) void k_resblock_bwd(const BlockBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
+    if (tile >= a.ntiles) return;
+    resblock_bwd_body<N, SCLIN>(a, BwdGemmF32{a, lane}, tile, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

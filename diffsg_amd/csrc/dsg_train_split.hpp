@@ -237,4 +237,101 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h(const WgradDesc* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Activation gradients on the split path: dX = W^T dY as 3x v_mfma_f32_32x32x16_f16 per k16-step, with the gradient rows
+// scaled one by one.  A row of dY lives in two lanes (j, j + 32); its largest element picks the power of two that puts the
+// row's maximum into [2^11, 2^12), the weights carry the same 2^e as in the forward packs, and the accumulator is unscaled
+// per lane afterwards -- exact powers of two, so the only rounding is the 22-bit operand split.
+// ---------------------------------------------------------------------------------------------
+struct BlockBwdArgsH {
+    BlockBwdArgs b;
+    const uint4* W3Th; const uint4* W2Th; const uint4* W1Th; const uint4* WscTh;   // transposed planes [OT][KS][2][64]
+    const float* m1; const float* m2; const float* m3; const float* msc;          // max|W| (k_maxabs)
+};
+
+template <int NT>
+__device__ __forceinline__ void row_scale(const f32x16 (&g)[NT], float& s, float& sinv) {
+    unsigned m = 0u;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned a = __float_as_uint(g[nt][r]) & 0x7fffffffu;
+            m = m > a ? m : a;
+        }
+    const unsigned o = (unsigned)__shfl_xor((int)m, 32);
+    m = m > o ? m : o;
+    const int be = (int)(m >> 23);
+    int e = be == 0 ? 0 : 11 - (be - 127);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    s = __int_as_float((127 + e) << 23);
+    sinv = __int_as_float((127 - e) << 23);
+}
+
+// out[CH tiles] += planes x split(s * in): k over NG groups held in accumulator order, weight planes prefetched one step ahead
+template <int NG, int NTI, int CH>
+__device__ __forceinline__ void chain_scaled_chunk_h(f32x16* __restrict__ out, const f32x16 (&in)[NTI], const uint4* __restrict__ wp,
+                                                     size_t nt_stride, int lane, float s) {
+    constexpr int KS = (NG + 1) / 2;
+    f32x16 (&o)[CH] = *reinterpret_cast<f32x16 (*)[CH]>(out);
+    HFrag<CH> wn;
+    load_hfrag<CH>(wn, wp + lane, nt_stride);
+#pragma unroll
+    for (int S = 0; S < KS; ++S) {
+        HFrag<CH> wc = wn;
+        if (S + 1 < KS) load_hfrag<CH>(wn, wp + (size_t)(S + 1) * 128 + lane, nt_stride);
+        __builtin_amdgcn_sched_barrier(0);
+        const int t = S >> 1, r0 = 8 * (S & 1);
+        float v[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v[p] = s * in[t][r0 + p];
+        h8 bhi, blo;
+        split8(v, bhi, blo);
+        mfma_step_h<CH>(o, wc, bhi, blo);
+    }
+}
+
+struct BwdGemmSplit {
+    const BlockBwdArgsH& a;
+    int lane;
+    bool sclin;
+    template <int NGin, int NTin, int NTout>
+    __device__ __forceinline__ void run(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], int which, bool accumulate) const {
+        constexpr int CH = NTout < 4 ? NTout : 4;
+        constexpr int KS = (NGin + 1) / 2;
+        const uint4* wp = which == 3 ? a.W3Th : (which == 2 ? a.W2Th : (which == 1 ? a.W1Th : a.WscTh));
+        int e;
+        if (which == 3) e = sclin ? scale_exp_lin3(*a.m3, *a.msc) : scale_exp(*a.m3);
+        else if (which == 2) e = scale_exp(*a.m2);
+        else if (which == 1) e = scale_exp(*a.m1);
+        else e = scale_exp_lin3(*a.m3, *a.msc) + 4;
+        float s, sinv;
+        row_scale<NTin>(in, s, sinv);
+        const float winv = __int_as_float((127 - e) << 23), wsc = __int_as_float((127 + e) << 23);
+        if (accumulate) {
+            const float pre = s * wsc;
+#pragma unroll
+            for (int nt = 0; nt < NTout; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[nt][r] *= pre;
+        }
+#pragma unroll
+        for (int o0 = 0; o0 < NTout; o0 += CH)
+            chain_scaled_chunk_h<NGin, NTin, CH>(&out[o0], in, wp + (size_t)o0 * KS * 128, (size_t)KS * 128, lane, s);
+        const float post = sinv * winv;
+#pragma unroll
+        for (int nt = 0; nt < NTout; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[nt][r] *= post;
+    }
+};
+
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256) void k_resblock_bwd_h(const BlockBwdArgsH a) {
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (tile >= a.b.ntiles) return;
+    resblock_bwd_body<N, SCLIN>(a.b, BwdGemmSplit{a, lane, SCLIN}, tile, lane);
+}
+
 }  // namespace dsg
