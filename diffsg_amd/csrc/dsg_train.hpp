@@ -201,14 +201,14 @@ struct BlockBwdArgs {
 };
 
 // The four data-gradient GEMMs of a block go through a policy object (`gemm.run<NGin, NTin, NTout>(out, in, which, accumulate)`,
-// which = 3, 2, 1 for W3^T, W2^T, W1^T and 0 for the Linear shortcut): exact f32 MFMA here, split-f16 in dsg_train_split.hpp.
+// which = 3, 2, 1 for W3^T, W2^T, W1^T and 0 for the Linear shortcut; o0 = first output tile): exact f32 MFMA here, split-f16 in dsg_train_split.hpp.
 struct BwdGemmF32 {
     const BlockBwdArgs& a;
     int lane;
     template <int NGin, int NTin, int NTout>
-    __device__ __forceinline__ void run(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], int which, bool /*accumulate*/) const {
+    __device__ __forceinline__ void run(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], int which, bool /*accumulate*/, int o0 = 0) const {
         const float* wp = which == 3 ? a.W3T : (which == 2 ? a.W2T : (which == 1 ? a.W1T : a.WscT));
-        chain_raw_from_acc<NGin, NTin, NTout>(out, in, wp, lane);
+        chain_raw_from_acc<NGin, NTin, NTout>(out, in, wp + (size_t)o0 * NGin * 256, lane);
     }
 };
 
@@ -271,6 +271,85 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
         rstd1 = rsqrtf(m2 / n + kLnEps);
         if (h == 0) reinterpret_cast<float2*>(a.rs1)[(size_t)tile * 32 + j] = make_float2(mean1, rstd1);
     }
+    if constexpr (KGT > 4) {
+        // 256-wide concat input: dL/dx in two halves of 4 output tiles so that the kernel fits two waves per SIMD.
+        // Pass A: GEMM half, dL/du (stored: it is also the LayerNorm gamma/beta operand) and the two row sums.
+        // Pass B: dL/du re-read, LayerNorm backward, + shortcut GEMM half, store.
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < KGT / 4; ++hb) {
+            f32x16 dxh[4];
+            acc_zero<4>(dxh);
+            gemm.template run<NG, NT, 4>(dxh, d1, 1, false, 4 * hb);
+#pragma unroll
+            for (int Gl = 0; Gl < 16; ++Gl) {
+                const int G = 16 * hb + Gl;
+                if (G < KG) {
+                    const bool first = G < a.in0.groups;
+                    const Seg& sg = first ? a.in0 : a.in1;
+                    const int gl = first ? G : G - a.in0.groups;
+                    const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                    const float4 gm = ld4(a.gamma1 + 8 * G + 4 * h), bt = ld4(a.beta1 + 8 * G + 4 * h);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+                    float duv[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const bool ok = 8 * gl + 4 * h + p < sg.width;
+                        const float xh = (xs[p] - mean1) * rstd1;
+                        const float u = fmaf(xh, gmv[p], btv[p]);
+                        const float du = ok ? dxh[Gl >> 2][4 * (Gl & 3) + p] * silu_grad(u) : 0.f;
+                        duv[p] = du;
+                        const float t = du * gmv[p];
+                        s1 += t;
+                        s2 = fmaf(t, xh, s2);
+                    }
+                    st4(a.du1 + ((size_t)tile * KG + G) * 256 + lane * 4, make_float4(duv[0], duv[1], duv[2], duv[3]));
+                }
+            }
+        }
+        s1 = xhalf_sum(s1) / wtot;
+        s2 = xhalf_sum(s2) / wtot;
+        f32x16 (&gg)[NT] = x;
+        acc_load<NG, NT>(gg, a.gout_a + tN);
+        if (a.gout_b) acc_load_add<NG, NT>(gg, a.gout_b + tN);
+#pragma unroll
+        for (int hb = 0; hb < KGT / 4; ++hb) {
+            f32x16 dxh[4];
+#pragma unroll
+            for (int Gl = 0; Gl < 16; ++Gl) {
+                const int G = 16 * hb + Gl;
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
+                if (G < KG) {
+                    const bool first = G < a.in0.groups;
+                    const Seg& sg = first ? a.in0 : a.in1;
+                    const int gl = first ? G : G - a.in0.groups;
+                    const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                    const float4 dv = ld4(a.du1 + ((size_t)tile * KG + G) * 256 + lane * 4);
+                    const float4 gm = ld4(a.gamma1 + 8 * G + 4 * h);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, dus[4] = {dv.x, dv.y, dv.z, dv.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const bool ok = 8 * gl + 4 * h + p < sg.width;
+                        const float xh = (xs[p] - mean1) * rstd1;
+                        o[p] = ok ? rstd1 * (dus[p] * gmv[p] - s1 - xh * s2) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) dxh[Gl >> 2][4 * (Gl & 3) + p] = o[p];
+            }
+            gemm.template run<NG, NT, 4>(dxh, gg, 0, true, 4 * hb);
+#pragma unroll
+            for (int Gl = 0; Gl < 16; ++Gl) {
+                const int G = 16 * hb + Gl;
+                if (G < KG) {
+                    const float4 v = make_float4(dxh[Gl >> 2][4 * (Gl & 3)], dxh[Gl >> 2][4 * (Gl & 3) + 1], dxh[Gl >> 2][4 * (Gl & 3) + 2],
+                                                 dxh[Gl >> 2][4 * (Gl & 3) + 3]);
+                    if (G < a.in0.groups) st4(a.gin0 + ((size_t)tile * a.in0.groups + G) * 256 + lane * 4, v);
+                    else st4(a.gin1 + ((size_t)tile * a.in1.groups + (G - a.in0.groups)) * 256 + lane * 4, v);
+                }
+            }
+        }
+    } else {
     f32x16 dx[KGT];
     acc_zero<KGT>(dx);
     gemm.template run<NG, NT, KGT>(dx, d1, 1, false);
@@ -344,6 +423,7 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
             if (G < a.in0.groups) st4(a.gin0 + ((size_t)tile * a.in0.groups + G) * 256 + lane * 4, v);
             else st4(a.gin1 + ((size_t)tile * a.in1.groups + (G - a.in0.groups)) * 256 + lane * 4, v);
         }
+    }
     }
 }
 

@@ -296,10 +296,10 @@ struct BwdGemmSplit {
     int lane;
     bool sclin;
     template <int NGin, int NTin, int NTout>
-    __device__ __forceinline__ void run(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], int which, bool accumulate) const {
+    __device__ __forceinline__ void run(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], int which, bool accumulate, int o0 = 0) const {
         constexpr int CH = NTout < 4 ? NTout : 4;
         constexpr int KS = (NGin + 1) / 2;
-        const uint4* wp = which == 3 ? a.W3Th : (which == 2 ? a.W2Th : (which == 1 ? a.W1Th : a.WscTh));
+        const uint4* wp = (which == 3 ? a.W3Th : (which == 2 ? a.W2Th : (which == 1 ? a.W1Th : a.WscTh))) + (size_t)o0 * KS * 128;
         int e;
         if (which == 3) e = sclin ? scale_exp_lin3(*a.m3, *a.msc) : scale_exp(*a.m3);
         else if (which == 2) e = scale_exp(*a.m2);
@@ -316,8 +316,8 @@ struct BwdGemmSplit {
                 for (int r = 0; r < 16; ++r) out[nt][r] *= pre;
         }
 #pragma unroll
-        for (int o0 = 0; o0 < NTout; o0 += CH)
-            chain_scaled_chunk_h<NGin, NTin, CH>(&out[o0], in, wp + (size_t)o0 * KS * 128, (size_t)KS * 128, lane, s);
+        for (int c0 = 0; c0 < NTout; c0 += CH)
+            chain_scaled_chunk_h<NGin, NTin, CH>(&out[c0], in, wp + (size_t)c0 * KS * 128, (size_t)KS * 128, lane, s);
         const float post = sinv * winv;
 #pragma unroll
         for (int nt = 0; nt < NTout; ++nt)
@@ -327,7 +327,7 @@ struct BwdGemmSplit {
 };
 
 template <int N, bool SCLIN>
-__global__ __launch_bounds__(256) void k_resblock_bwd_h(const BlockBwdArgsH a) {
+__global__ __launch_bounds__(256, 2) void k_resblock_bwd_h(const BlockBwdArgsH a) {
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (tile >= a.b.ntiles) return;
