@@ -69,7 +69,9 @@ struct ResP {              // ResidualBlock (UNetCF.py:49-95)
     size_t W1Th = 0, W2Th = 0, W3Th = 0, WscTh = 0;  // transposed fp16-split planes (data gradients)
     bool split = false;
     // training workspace (per-tile float offsets)
-    size_t h1, h2, du1, du2, du3, dh1, dh2, rs1, rs2, rs3;
+    size_t h1, h2, du1, dh1, dh2, rs1, rs2, rs3;
+    size_t cs_off = 0, cs_stride = 0;   // this block's column-sum region (float offset in tr_cs) and its per-tile row length
+    int gslot_out = -1, gslot_h2 = -1, gslot_h1 = -1;   // max|G| slots of dout, dh2, dh1
     long long dtb_off;     // slab scratch: dTB_b [N][T]
 };
 
@@ -173,7 +175,12 @@ struct dsg_handle {
     float* tr_ws = nullptr;
     float* tr_slabs = nullptr;   // [chunks][slab_stride]
     float* tr_gsum = nullptr;    // [slab_stride]
-    unsigned* tr_gmax = nullptr; // max|G| per gradient tensor (float bits), zeroed every step
+    unsigned* tr_gmax = nullptr; // max|G| per gradient tensor (float bits)
+    unsigned* tr_gmax_t = nullptr; // [kMaxGmax][gmax_ld] per-tile words, zeroed every step
+    int gmax_ld = 0;
+    float* tr_cs = nullptr;      // per block: [tiles][cs_stride of the block] column sums
+    int4* cs_map_dev = nullptr;  // [cs_slots] (slab destination, second destination, region base + slot, row stride)
+    int cs_slots = 0;
     int n_gmax = 0;
     size_t slab_stride = 0;
     int* tr_ts = nullptr;        // [rows]
@@ -298,7 +305,7 @@ void carve(dsg_handle* h) {
     }
     for (auto& r : h->res) {
         const size_t NGf = (size_t)groups_of(r.N) * 256, KGf = (size_t)(groups_of(r.in0) + groups_of(r.in1)) * 256;
-        r.h1 = take(NGf); r.h2 = take(NGf); r.du1 = take(KGf); r.du2 = take(NGf); r.du3 = take(NGf);
+        r.h1 = take(NGf); r.h2 = take(NGf); r.du1 = take(KGf);
         r.dh1 = take(NGf); r.dh2 = take(NGf); r.rs1 = take(64); r.rs2 = take(64); r.rs3 = take(64);
     }
     for (auto& l : h->lin)
@@ -314,15 +321,15 @@ void free_graphs(dsg_handle* h) {
     h->g_rows = -1;
 }
 
-constexpr int kMaxGmax = 1024;   // distinct gradient tensors whose max|G| is tracked (3 per block + 1 per Linear)
+constexpr int kMaxGmax = 256;   // distinct gradient tensors whose max|G| is tracked (3 per block + 1 per Linear)
 
 void free_train_workspace(dsg_handle* h) {
     void* ptrs[] = {h->tr_ws, h->tr_slabs, h->tr_gsum, h->tr_ts, h->tr_yt_rm, h->tr_tsave, h->wg_desc_dev, h->wg_unit_dev,
-                    h->cs_desc_dev, h->cs_unit_dev, h->tr_gmax};
+                    h->cs_desc_dev, h->cs_unit_dev, h->tr_gmax, h->tr_gmax_t, h->tr_cs, h->cs_map_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->tr_ws = h->tr_slabs = h->tr_gsum = h->tr_yt_rm = h->tr_tsave = nullptr;
-    h->tr_ts = nullptr; h->tr_gmax = nullptr;
+    h->tr_ts = nullptr; h->tr_gmax = nullptr; h->tr_gmax_t = nullptr; h->tr_cs = nullptr; h->cs_map_dev = nullptr;
     h->wg_desc_dev = nullptr; h->wg_unit_dev = nullptr; h->cs_desc_dev = nullptr; h->cs_unit_dev = nullptr;
     h->wg_units = h->cs_units = 0;
     h->tr_rows = h->tr_T = 0;
@@ -760,7 +767,49 @@ int ensure_train_workspace(dsg_handle* h, int rows, int T) {
     HIPCK(hipMalloc(&h->tr_slabs, (size_t)max_chunks * h->slab_stride * sizeof(float)));
     HIPCK(hipMemset(h->tr_slabs, 0, (size_t)max_chunks * h->slab_stride * sizeof(float)));
     HIPCK(hipMalloc(&h->tr_gsum, h->slab_stride * sizeof(float)));
-    HIPCK(hipMalloc(&h->tr_gmax, kMaxGmax * sizeof(unsigned)));
+    HIPCK(hipMalloc(&h->tr_gmax, (size_t)kMaxGmax * sizeof(unsigned)));
+    h->gmax_ld = (int)tiles;
+    HIPCK(hipMalloc(&h->tr_gmax_t, (size_t)kMaxGmax * h->gmax_ld * sizeof(unsigned)));
+    {   // per-tile column sums of the residual blocks, one contiguous [tile][slot] region per block:
+        // [dout | dh2 | dh1 | beta3 | gamma3 | beta2 | gamma2] x NP, [beta1 | gamma1] x KP
+        const Param* P = h->params.data();
+        size_t off = 0;
+        std::vector<int4> map;
+        size_t base = 0, stride = 0, slot = 0;
+        auto vec = [&](int width_pad, int w0, int w1, long long d0, long long d1) {
+            // padded feature order: each concat segment padded to whole groups
+            const int g0 = groups_of(w0);
+            for (int f = 0; f < width_pad; ++f, ++slot) {
+                const int G = f >> 3, e = f & 7;
+                int col = -1;
+                if (G < g0) { if (8 * G + e < w0) col = 8 * G + e; }
+                else { const int c = 8 * (G - g0) + e; if (c < w1) col = w0 + c; }
+                map.push_back(make_int4(col >= 0 ? (int)(d0 + col) : -1, (col >= 0 && d1 >= 0) ? (int)(d1 + col) : -1, (int)(base + slot), (int)stride));
+            }
+        };
+        for (auto& r : h->res) {
+            const int NP = cdiv(r.N, 32) * 32;
+            const int KGT = r.sclin ? cdiv(2 * groups_of(r.N), 4) : cdiv(r.N, 32);   // as resblock_bwd_body
+            const int KP = KGT * 32;
+            r.cs_off = off; r.cs_stride = (size_t)7 * NP + 2 * KP;
+            base = off; stride = r.cs_stride; slot = 0;
+            vec(NP, r.N, 0, P[r.l3.b].off, r.sclin ? P[r.sc.b].off : -1);
+            vec(NP, r.N, 0, P[r.l2.b].off, P[r.ce.b].off);
+            vec(NP, r.N, 0, P[r.l1.b].off, P[r.te.b].off);
+            vec(NP, r.N, 0, P[r.n3.b].off, -1);
+            vec(NP, r.N, 0, P[r.n3.w].off, -1);
+            vec(NP, r.N, 0, P[r.n2.b].off, -1);
+            vec(NP, r.N, 0, P[r.n2.w].off, -1);
+            vec(KP, r.in0, r.in1, P[r.n1.b].off, -1);
+            vec(KP, r.in0, r.in1, P[r.n1.w].off, -1);
+            off += tiles * r.cs_stride;
+        }
+        if (off >= ((size_t)1 << 31)) { fail("training batch too large for the column-sum index (%zu floats)", off); return 1; }
+        h->cs_slots = (int)map.size();
+        HIPCK(hipMalloc(&h->tr_cs, off * sizeof(float)));
+        HIPCK(hipMalloc(&h->cs_map_dev, map.size() * sizeof(int4)));
+        HIPCK(hipMemcpy(h->cs_map_dev, map.data(), map.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
     HIPCK(hipMalloc(&h->tr_ts, (size_t)nrows * sizeof(int)));
     HIPCK(hipMalloc(&h->tr_yt_rm, (size_t)nrows * D * sizeof(float)));
     HIPCK(hipMalloc(&h->tr_tsave, ((size_t)T * 2 * half + (size_t)(5 + kTimeChunks) * T * td) * sizeof(float)));
@@ -779,6 +828,7 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
     std::vector<int> wd_op;            // operator each descriptor belongs to
     int cur_op = 0;
     std::vector<ColsumDesc> cd;
+    std::vector<int> bwd_slots;        // slots tracked by the block backward kernels
     std::vector<const float*> gsrc;    // distinct G tensors, by first pointer: slot of max|G|
     auto slot_of = [&](const float* g) {
         for (size_t i = 0; i < gsrc.size(); ++i) if (gsrc[i] == g) return (int)i;
@@ -825,12 +875,11 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
             wgrad(dh2, nullptr, r.N, A_RAW, gseg(h->condfrag, h->d.cond_dim), none(), nullptr, nullptr, nullptr, P[r.ce.w].off, h->d.cond_dim);
             wgrad(ga, gb, r.N, A_LNSILU, gseg(trp(h, r.h2), r.N), none(), trp(h, r.rs3), A + r.g3p, A + r.b3p, P[r.l3.w].off, r.N);
             wgrad(dh1, nullptr, r.N, A_ONEHOT, none(), none(), nullptr, nullptr, nullptr, r.dtb_off, T);
-            colsum(trp(h, r.du1), nullptr, in0.groups + in1.groups, in0, in1, trp(h, r.rs1), r.in0, r.in1, P[r.n1.b].off, -1, P[r.n1.w].off);
-            colsum(trp(h, r.du2), nullptr, groups_of(r.N), gseg(trp(h, r.h1), r.N), none(), trp(h, r.rs2), r.N, 0, P[r.n2.b].off, -1, P[r.n2.w].off);
-            colsum(trp(h, r.du3), nullptr, groups_of(r.N), gseg(trp(h, r.h2), r.N), none(), trp(h, r.rs3), r.N, 0, P[r.n3.b].off, -1, P[r.n3.w].off);
-            colsum(dh1, nullptr, groups_of(r.N), none(), none(), nullptr, r.N, 0, P[r.l1.b].off, P[r.te.b].off, -1);
-            colsum(dh2, nullptr, groups_of(r.N), none(), none(), nullptr, r.N, 0, P[r.l2.b].off, P[r.ce.b].off, -1);
-            colsum(ga, gb, groups_of(r.N), none(), none(), nullptr, r.N, 0, P[r.l3.b].off, r.sclin ? P[r.sc.b].off : -1, -1);
+            // bias and LayerNorm gradients of the block come from the backward kernel's own column sums (k_cs_reduce); so does
+            // max|G| of its three gradient tensors
+            ResP& rw = h->res[op.p];
+            rw.gslot_out = slot_of(ga); rw.gslot_h2 = slot_of(dh2); rw.gslot_h1 = slot_of(dh1);
+            bwd_slots.push_back(rw.gslot_out); bwd_slots.push_back(rw.gslot_h2); bwd_slots.push_back(rw.gslot_h1);
         } else {
             const LinOpP& l = h->lin[op.p];
             if (op.kind == OP_FINAL) {
@@ -851,6 +900,7 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
     {
         std::vector<char> seen(gsrc.size(), 0);
         for (const ColsumDesc& c : cd) if (c.gmax_slot >= 0) seen[c.gmax_slot] = 1;
+        for (int sl : bwd_slots) seen[sl] = 1;
         for (const WgradDesc& w : wd) if (!seen[w.gmax_slot]) { fail("internal: weight-gradient operand without a tracked maximum"); return 1; }
         if ((int)gsrc.size() > kMaxGmax) { fail("internal: too many gradient tensors (%d)", (int)gsrc.size()); return 1; }
         h->n_gmax = (int)gsrc.size();
@@ -884,9 +934,10 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
                     for (int c = c0; c < c0 + 8 && c < h->tr_chunks; ++c) wu.push_back(WgradUnit{u.first, u.second, c, 0});
     }
     std::vector<ColsumUnit> cu;
+    // chunk-major, group-minor: neighbouring waves stream neighbouring 1 KiB fragments of the same row tiles
     for (size_t i = 0; i < cd.size(); ++i)
-        for (int g = 0; g < cd[i].groups; ++g)
-            for (int c = 0; c < h->tr_chunks; ++c) cu.push_back(ColsumUnit{(int)i, g, c, 0});
+        for (int c = 0; c < h->tr_chunks; ++c)
+            for (int g = 0; g < cd[i].groups; ++g) cu.push_back(ColsumUnit{(int)i, g, c, 0});
     if (!h->wg_desc_dev) {
         HIPCK(hipMalloc(&h->wg_desc_dev, wd.size() * sizeof(WgradDesc)));
         HIPCK(hipMalloc(&h->cs_desc_dev, cd.size() * sizeof(ColsumDesc)));
@@ -1395,6 +1446,7 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, s, h->red, kRedBlocks, (double)B * (double)D, loss_out);
 
     // ---- backward: activation gradients in reverse operator order
+    HIPCK(hipMemsetAsync(h->tr_gmax_t, 0, (size_t)h->n_gmax * h->gmax_ld * sizeof(unsigned), s));
     for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
         const Op& op = h->ops[oi];
         if (op.kind == OP_PROJ) continue;
@@ -1411,7 +1463,8 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
             a.gamma1 = A + r.g1p; a.beta1 = A + r.b1p; a.gamma2 = A + r.g2p; a.beta2 = A + r.b2p; a.gamma3 = A + r.g3p; a.beta3 = A + r.b3p;
             a.gin0 = trp(h, h->tensors[op.in0].ga);
             a.gin1 = op.in1 >= 0 ? trp(h, h->tensors[op.in1].gb) : nullptr;
-            a.du1 = trp(h, r.du1); a.du2 = trp(h, r.du2); a.du3 = trp(h, r.du3); a.dh1 = trp(h, r.dh1); a.dh2 = trp(h, r.dh2);
+            a.du1 = trp(h, r.du1); a.dh1 = trp(h, r.dh1); a.dh2 = trp(h, r.dh2);
+            a.cs = h->tr_cs + r.cs_off; a.cs_stride = r.cs_stride;
             a.rs1 = trp(h, r.rs1); a.rs2 = trp(h, r.rs2); a.rs3 = trp(h, r.rs3);
             a.ntiles = tiles;
             if (h->use_split) {
@@ -1422,6 +1475,7 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
                 ah.WscTh = r.sclin ? reinterpret_cast<const uint4*>(A + r.WscTh) : nullptr;
                 ah.m1 = h->maxabs + r.l1.w; ah.m2 = h->maxabs + r.l2.w; ah.m3 = h->maxabs + r.l3.w;
                 ah.msc = r.sclin ? h->maxabs + r.sc.w : nullptr;
+                ah.gmax_t = h->tr_gmax_t; ah.gmax_ld = h->gmax_ld; ah.slot_out = r.gslot_out; ah.slot_h2 = r.gslot_h2; ah.slot_h1 = r.gslot_h1;
                 launch_res_bwd_h(r.N, r.sclin, ah, s);
             } else {
                 launch_res_bwd(r.N, r.sclin, a, s);
@@ -1446,9 +1500,11 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
         }
     }
     // ---- weight / bias / LayerNorm gradients: two grouped launches into per-chunk slabs, then a fixed-order reduce
-    HIPCK(hipMemsetAsync(h->tr_gmax, 0, (size_t)h->n_gmax * sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_cs_reduce, dim3(cdiv(h->cs_slots, 256), h->tr_chunks), dim3(256), 0, s, h->tr_cs, h->cs_map_dev, h->cs_slots,
+                       h->tr_slabs, h->slab_stride, tiles, h->tr_chunks);
     hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->cs_units, 4)), dim3(256), 0, s, h->cs_desc_dev, h->cs_unit_dev, h->cs_units, h->tr_slabs,
-                       h->slab_stride, tiles, h->tr_chunks, B, h->tr_gmax);
+                       h->slab_stride, tiles, h->tr_chunks, B, h->tr_gmax_t, h->gmax_ld);
+    hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, s, h->tr_gmax_t, h->gmax_ld, h->tr_gmax);
     if (h->use_split)
         hipLaunchKernelGGL(k_wgrad_h, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_gmax, h->tr_slabs,
                            h->slab_stride, tiles, h->tr_chunks);

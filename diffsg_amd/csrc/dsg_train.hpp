@@ -75,6 +75,69 @@ __global__ void k_loss_final(const double* __restrict__ part, int nparts, double
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column sums over the 32 rows of a tile, in registers (bias and LayerNorm gamma/beta gradients of the residual blocks).
+// v[r], r < R (R a power of two <= 32), holds one value per row (lane & 31) for R different columns.  Afterwards lane l
+// returns the sum over the 32 lanes of its half of column l & (R - 1).  Butterfly: each level halves the registers -- the
+// lane keeps the half selected by one lane bit and adds its partner's copy of that half -- so the whole reduction costs
+// about 3R VALU instead of 5R shuffles.  xor 1, 2: DPP quad_perm; xor 4, 8, 16: ds_swizzle (crossbar only, no LDS memory).
+// ---------------------------------------------------------------------------------------------
+template <int X>
+__device__ __forceinline__ float lane_xor(float v) {
+    if constexpr (X == 1) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
+    else if constexpr (X == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
+    else return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x1f | (X << 10)));
+}
+template <int CNT, int X>
+__device__ __forceinline__ void colsum_level(float* v, int lane) {
+    if constexpr (CNT >= 2) {
+        const bool b = lane & X;
+#pragma unroll
+        for (int i = 0; i < CNT / 2; ++i) {
+            const float lo = v[2 * i], hi = v[2 * i + 1];
+            v[i] = (b ? hi : lo) + lane_xor<X>(b ? lo : hi);
+        }
+    } else {
+        v[0] += lane_xor<X>(v[0]);
+    }
+}
+template <int R>
+__device__ __forceinline__ float tile_colsum(float (&v)[R], int lane) {
+    static_assert(R == 4 || R == 8 || R == 16 || R == 32, "tile_colsum: R");
+    colsum_level<R, 1>(v, lane);
+    colsum_level<(R >= 2 ? R / 2 : 1), 2>(v, lane);
+    colsum_level<(R >= 4 ? R / 4 : 1), 4>(v, lane);
+    colsum_level<(R >= 8 ? R / 8 : 1), 8>(v, lane);
+    colsum_level<(R >= 16 ? R / 16 : 1), 16>(v, lane);
+    return v[0];
+}
+// groups per reduction block of an NG-group tensor, and the store of a block's result: register r of the block is
+// (group G0 + r/4, element r%4), i.e. feature 8*(G0 + r/4) + 4h + r%4 of the padded feature order
+template <int NGX>
+struct CsBlock { static constexpr int GB = NGX >= 8 ? 8 : (NGX >= 4 ? 4 : (NGX >= 2 ? 2 : 1)); };
+template <int R>
+__device__ __forceinline__ void colsum_store(float* __restrict__ dst, int G0, float s, int lane, int h) {
+    const int r = lane & (R - 1);
+    if ((lane & 31) < R) dst[8 * (G0 + (r >> 2)) + 4 * h + (r & 3)] = s;
+}
+// column sums of an accumulator-resident tensor (NG groups) -> dst[padded feature]
+template <int NG, int NT>
+__device__ __forceinline__ void acc_colsum_store(const f32x16 (&a)[NT], float* __restrict__ dst, int lane, int h) {
+    constexpr int GB = CsBlock<NG>::GB;
+#pragma unroll
+    for (int G0 = 0; G0 < NG; G0 += GB) {
+        float v[GB * 4];
+#pragma unroll
+        for (int Gl = 0; Gl < GB; ++Gl)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int G = G0 + Gl;
+                v[4 * Gl + p] = G < NG ? a[G >> 2][4 * (G & 3) + p] : 0.f;
+            }
+        colsum_store<GB * 4>(dst, G0, tile_colsum<GB * 4>(v, lane), lane, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm + SiLU backward on an accumulator-resident gradient (in place):
 //   in : da[f] = dL/d silu(u[f]),  x[f] = LN input,  u = xhat*gamma + beta
 //   out: da[f] <- dL/dx[f] ;  du_out[f] = dL/du[f] (stored for the gamma/beta column sums)
@@ -86,29 +149,42 @@ __device__ __forceinline__ float silu_grad(float u) {
 }
 
 // NG groups held in acc arrays da[], x[] (accumulator order).  W = true width.
+// cs_beta / cs_gamma: this tile's column-sum vectors (sum_rows du, sum_rows du*xhat) in padded feature order.
 template <int NG, int NT>
 __device__ __forceinline__ void ln_silu_bwd_acc(f32x16 (&da)[NT], const f32x16 (&x)[NT], const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, float mean, float rstd, int W, int h,
-                                                float* __restrict__ du_out /* + lane*4, group stride 256 */) {
+                                                const float* __restrict__ beta, float mean, float rstd, int W, int h, int lane,
+                                                float* __restrict__ cs_beta, float* __restrict__ cs_gamma) {
+    constexpr int GB = CsBlock<NG>::GB;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int G = 0; G < NG; ++G) {
-        const float4 gm = ld4(gamma + 8 * G + 4 * h), bt = ld4(beta + 8 * G + 4 * h);
-        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
-        float duv[4];
+    for (int G0 = 0; G0 < NG; G0 += GB) {
+        float db[GB * 4], dg[GB * 4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const bool ok = 8 * G + 4 * h + p < W;
-            const float xh = (x[G >> 2][4 * (G & 3) + p] - mean) * rstd;
-            const float u = fmaf(xh, gmv[p], btv[p]);
-            const float du = ok ? da[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
-            duv[p] = du;
-            const float t = du * gmv[p];
-            da[G >> 2][4 * (G & 3) + p] = t;
-            s1 += t;
-            s2 = fmaf(t, xh, s2);
+        for (int Gl = 0; Gl < GB; ++Gl) {
+            const int G = G0 + Gl;
+            if (G < NG) {
+                const float4 gm = ld4(gamma + 8 * G + 4 * h), bt = ld4(beta + 8 * G + 4 * h);
+                const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool ok = 8 * G + 4 * h + p < W;
+                    const float xh = (x[G >> 2][4 * (G & 3) + p] - mean) * rstd;
+                    const float u = fmaf(xh, gmv[p], btv[p]);
+                    const float du = ok ? da[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
+                    db[4 * Gl + p] = du;
+                    dg[4 * Gl + p] = du * xh;
+                    const float t = du * gmv[p];
+                    da[G >> 2][4 * (G & 3) + p] = t;
+                    s1 += t;
+                    s2 = fmaf(t, xh, s2);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { db[4 * Gl + p] = 0.f; dg[4 * Gl + p] = 0.f; }
+            }
         }
-        st4(du_out + (size_t)G * 256, make_float4(duv[0], duv[1], duv[2], duv[3]));
+        colsum_store<GB * 4>(cs_beta, G0, tile_colsum<GB * 4>(db, lane), lane, h);
+        colsum_store<GB * 4>(cs_gamma, G0, tile_colsum<GB * 4>(dg, lane), lane, h);
     }
     s1 = xhalf_sum(s1) * (1.0f / W);
     s2 = xhalf_sum(s2) * (1.0f / W);
@@ -194,9 +270,11 @@ struct BlockBwdArgs {
     const float* gamma3; const float* beta3;
     float* gin0;             // dL/d(in0) [tiles][g0][256]
     float* gin1;             // dL/d(in1) [tiles][g1][256] or null
-    float* du1; float* du2; float* du3;   // dL/du of the three LayerNorm+SiLU stages (fragment layout)
+    float* du1;                           // dL/du of stage 1, fragment layout: scratch of the two-half variant only
     float* dh1; float* dh2;               // dL/dh1, dL/dh2 (G operands of the weight gradients)
     float* rs1; float* rs2; float* rs3;   // per-row (mean, rstd) of LN1/2/3 for the weight-gradient A operands
+    float* cs;               // this block's column-sum region: cs[tile * cs_stride + ...], layout in resblock_bwd_body
+    size_t cs_stride;
     int ntiles;
 };
 
@@ -221,10 +299,16 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     const int KG = a.in0.groups + a.in1.groups;
     const size_t tN = (size_t)tile * NG * 256 + lane * 4;
 
+    // per-tile column sums (bias and LayerNorm gradients), padded feature order; gathered by k_cs_reduce:
+    //   [dout | dh2 | dh1 | beta3 | gamma3 | beta2 | gamma2] x NP, then [beta1 | gamma1] x KP
+    constexpr int NP = NT * 32, KP = KGT * 32;
+    float* const csb = a.cs + (size_t)tile * a.cs_stride;
+
     // ---- dL/d(out)
     f32x16 g[NT];
     acc_load<NG, NT>(g, a.gout_a + tN);
     if (a.gout_b) acc_load_add<NG, NT>(g, a.gout_b + tN);
+    acc_colsum_store<NG, NT>(g, csb, lane, h);
 
     // ---- stage 3: d a3 = W3^T g ; LN3/SiLU backward with h2
     f32x16 d[NT], x[NT];
@@ -236,9 +320,10 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
         acc_stats<N, NT>(x, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
         if (h == 0) reinterpret_cast<float2*>(a.rs3)[(size_t)tile * 32 + j] = make_float2(mean, rstd);
-        ln_silu_bwd_acc<NG, NT>(d, x, a.gamma3, a.beta3, mean, rstd, N, h, a.du3 + tN);
+        ln_silu_bwd_acc<NG, NT>(d, x, a.gamma3, a.beta3, mean, rstd, N, h, lane, csb + 3 * NP, csb + 4 * NP);
     }
     acc_store<NG, NT>(d, a.dh2 + tN);
+    acc_colsum_store<NG, NT>(d, csb + NP, lane, h);
 
     // ---- stage 2: d a2 = W2^T dh2 ; LN2/SiLU backward with h1
     f32x16 (&d1)[NT] = g;  // reuse: g is re-read from memory for the shortcut
@@ -250,9 +335,10 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
         acc_stats<N, NT>(x, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
         if (h == 0) reinterpret_cast<float2*>(a.rs2)[(size_t)tile * 32 + j] = make_float2(mean, rstd);
-        ln_silu_bwd_acc<NG, NT>(d1, x, a.gamma2, a.beta2, mean, rstd, N, h, a.du2 + tN);
+        ln_silu_bwd_acc<NG, NT>(d1, x, a.gamma2, a.beta2, mean, rstd, N, h, lane, csb + 5 * NP, csb + 6 * NP);
     }
     acc_store<NG, NT>(d1, a.dh1 + tN);
+    acc_colsum_store<NG, NT>(d1, csb + 2 * NP, lane, h);
 
     // ---- stage 1: d a1 = W1^T dh1 over the concat width; LN1/SiLU backward with x = cat(in0, in1)
     float mean1, rstd1, wtot;
@@ -282,29 +368,39 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
             acc_zero<4>(dxh);
             gemm.template run<NG, NT, 4>(dxh, d1, 1, false, 4 * hb);
 #pragma unroll
-            for (int Gl = 0; Gl < 16; ++Gl) {
-                const int G = 16 * hb + Gl;
-                if (G < KG) {
-                    const bool first = G < a.in0.groups;
-                    const Seg& sg = first ? a.in0 : a.in1;
-                    const int gl = first ? G : G - a.in0.groups;
-                    const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
-                    const float4 gm = ld4(a.gamma1 + 8 * G + 4 * h), bt = ld4(a.beta1 + 8 * G + 4 * h);
-                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
-                    float duv[4];
+            for (int B8 = 0; B8 < 2; ++B8) {
+                float db[32], dg[32];
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const bool ok = 8 * gl + 4 * h + p < sg.width;
-                        const float xh = (xs[p] - mean1) * rstd1;
-                        const float u = fmaf(xh, gmv[p], btv[p]);
-                        const float du = ok ? dxh[Gl >> 2][4 * (Gl & 3) + p] * silu_grad(u) : 0.f;
-                        duv[p] = du;
-                        const float t = du * gmv[p];
-                        s1 += t;
-                        s2 = fmaf(t, xh, s2);
+                for (int G8 = 0; G8 < 8; ++G8) {
+                    const int Gl = 8 * B8 + G8, G = 16 * hb + Gl;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { db[4 * G8 + p] = 0.f; dg[4 * G8 + p] = 0.f; }
+                    if (G < KG) {
+                        const bool first = G < a.in0.groups;
+                        const Seg& sg = first ? a.in0 : a.in1;
+                        const int gl = first ? G : G - a.in0.groups;
+                        const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                        const float4 gm = ld4(a.gamma1 + 8 * G + 4 * h), bt = ld4(a.beta1 + 8 * G + 4 * h);
+                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+                        float duv[4];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const bool ok = 8 * gl + 4 * h + p < sg.width;
+                            const float xh = (xs[p] - mean1) * rstd1;
+                            const float u = fmaf(xh, gmv[p], btv[p]);
+                            const float du = ok ? dxh[Gl >> 2][4 * (Gl & 3) + p] * silu_grad(u) : 0.f;
+                            duv[p] = du;
+                            db[4 * G8 + p] = du;
+                            dg[4 * G8 + p] = du * xh;
+                            const float t = du * gmv[p];
+                            s1 += t;
+                            s2 = fmaf(t, xh, s2);
+                        }
+                        st4(a.du1 + ((size_t)tile * KG + G) * 256 + lane * 4, make_float4(duv[0], duv[1], duv[2], duv[3]));
                     }
-                    st4(a.du1 + ((size_t)tile * KG + G) * 256 + lane * 4, make_float4(duv[0], duv[1], duv[2], duv[3]));
                 }
+                colsum_store<32>(csb + 7 * NP, 16 * hb + 8 * B8, tile_colsum<32>(db, lane), lane, h);
+                colsum_store<32>(csb + 7 * NP + KP, 16 * hb + 8 * B8, tile_colsum<32>(dg, lane), lane, h);
             }
         }
         s1 = xhalf_sum(s1) / wtot;
@@ -354,32 +450,42 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     acc_zero<KGT>(dx);
     gemm.template run<NG, NT, KGT>(dx, d1, 1, false);
     {
-        // pass 1: du, t = du*gamma, row sums (x streamed from memory, group by group)
+        // pass 1: du, t = du*gamma, row sums (x streamed from memory, group by group); column sums of du and du*xhat per
+        // block of groups
+        constexpr int GB1 = KGT >= 2 ? 8 : 4;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int G = 0; G < KGT * 4; ++G) {
-            if (G < KG) {
-                const bool first = G < a.in0.groups;
-                const Seg& sg = first ? a.in0 : a.in1;
-                const int gl = first ? G : G - a.in0.groups;
-                const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
-                const float4 gm = ld4(a.gamma1 + 8 * G + 4 * h), bt = ld4(a.beta1 + 8 * G + 4 * h);
-                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
-                float duv[4];
+        for (int G0 = 0; G0 < KGT * 4; G0 += GB1) {
+            float db[GB1 * 4], dg[GB1 * 4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const bool ok = 8 * gl + 4 * h + p < sg.width;
-                    const float xh = (xs[p] - mean1) * rstd1;
-                    const float u = fmaf(xh, gmv[p], btv[p]);
-                    const float du = ok ? dx[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
-                    duv[p] = du;
-                    const float t = du * gmv[p];
-                    dx[G >> 2][4 * (G & 3) + p] = t;
-                    s1 += t;
-                    s2 = fmaf(t, xh, s2);
+            for (int Gl = 0; Gl < GB1; ++Gl) {
+                const int G = G0 + Gl;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { db[4 * Gl + p] = 0.f; dg[4 * Gl + p] = 0.f; }
+                if (G < KG) {
+                    const bool first = G < a.in0.groups;
+                    const Seg& sg = first ? a.in0 : a.in1;
+                    const int gl = first ? G : G - a.in0.groups;
+                    const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                    const float4 gm = ld4(a.gamma1 + 8 * G + 4 * h), bt = ld4(a.beta1 + 8 * G + 4 * h);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const bool ok = 8 * gl + 4 * h + p < sg.width;
+                        const float xh = (xs[p] - mean1) * rstd1;
+                        const float u = fmaf(xh, gmv[p], btv[p]);
+                        const float du = ok ? dx[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
+                        db[4 * Gl + p] = du;
+                        dg[4 * Gl + p] = du * xh;
+                        const float t = du * gmv[p];
+                        dx[G >> 2][4 * (G & 3) + p] = t;
+                        s1 += t;
+                        s2 = fmaf(t, xh, s2);
+                    }
                 }
-                st4(a.du1 + ((size_t)tile * KG + G) * 256 + lane * 4, make_float4(duv[0], duv[1], duv[2], duv[3]));
             }
+            colsum_store<GB1 * 4>(csb + 7 * NP, G0, tile_colsum<GB1 * 4>(db, lane), lane, h);
+            colsum_store<GB1 * 4>(csb + 7 * NP + KP, G0, tile_colsum<GB1 * 4>(dg, lane), lane, h);
         }
         s1 = xhalf_sum(s1) / wtot;
         s2 = xhalf_sum(s2) / wtot;
@@ -562,6 +668,10 @@ struct WgradDesc {
     int gmax_slot;                      // split path: index of max|G| (tracked by k_colsum) that sets the operand scale
 };
 struct WgradUnit { int desc; int kblk; int chunk; int pad; };
+
+// max|G| of a gradient tensor is tracked as one word per row tile (gmax_t[slot][tile], plain stores from the backward
+// kernels, atomicMax from k_colsum's units) and reduced by k_gmax_reduce: thousands of waves updating or even just reading ONE
+// word serialise on a single L2 channel for ~30 us per kernel.
 
 constexpr int kWgLd = 36;      // floats per feature row of a 1-tile LDS image: 32 batch rows + 4 (conflict-free b128 reads)
 constexpr int kWgImg = 128 * kWgLd;
@@ -772,7 +882,7 @@ struct ColsumUnit { int desc; int group; int chunk; int pad; };
 
 __global__ __launch_bounds__(256) void k_colsum(const ColsumDesc* __restrict__ descs, const ColsumUnit* __restrict__ units, int nunits,
                                                 float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks, int nrows,
-                                                unsigned* __restrict__ gmax) {
+                                                unsigned* __restrict__ gmax_t, int gmax_ld) {
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (u >= nunits) return;
     const ColsumUnit un = units[u];
@@ -827,7 +937,7 @@ __global__ __launch_bounds__(256) void k_colsum(const ColsumDesc* __restrict__ d
             const unsigned t = (unsigned)__shfl_xor((int)mx, o);
             mx = mx > t ? mx : t;
         }
-        if (lane == 0 && mx) atomicMax(gmax + d.gmax_slot, mx);
+        if (lane == 0 && mx) atomicMax(gmax_t + (size_t)d.gmax_slot * gmax_ld + (u % gmax_ld), mx);
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1)
@@ -850,6 +960,51 @@ __global__ __launch_bounds__(256) void k_colsum(const ColsumDesc* __restrict__ d
                 if (want2) out[d.out2_off + col] = q[p];
             }
         }
+    }
+}
+
+// Per-tile column sums of the residual blocks (written by resblock_bwd_body, one contiguous [tile][slot] region per
+// block) -> per-chunk slabs, fixed order.  map[s] = (destination, second destination or -1, region base, region row
+// stride) for every slot of every block; destination -1 = padding slot.
+__global__ __launch_bounds__(256) void k_cs_reduce(const float* __restrict__ cs, const int4* __restrict__ map, int nslots,
+                                                   float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks) {
+    const int sidx = blockIdx.x * 256 + threadIdx.x;
+    if (sidx >= nslots) return;
+    const int4 m = map[sidx];
+    if (m.x < 0) return;
+    const int c = blockIdx.y;
+    const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+    const int t_lo = c * tiles_per_chunk;
+    const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
+    const float* p = cs + (size_t)(unsigned)m.z;
+    const size_t st = (size_t)m.w;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int t = t_lo;
+    for (; t + 3 < t_hi; t += 4) {
+        a0 += p[(size_t)t * st];
+        a1 += p[(size_t)(t + 1) * st];
+        a2 += p[(size_t)(t + 2) * st];
+        a3 += p[(size_t)(t + 3) * st];
+    }
+    for (; t < t_hi; ++t) a0 += p[(size_t)t * st];
+    const float v = (a0 + a1) + (a2 + a3);
+    float* out = slabs + (size_t)c * slab_stride;
+    out[m.x] = v;
+    if (m.y >= 0) out[m.y] = v;
+}
+
+// gmax[slot] = max over the per-tile words
+__global__ __launch_bounds__(256) void k_gmax_reduce(const unsigned* __restrict__ gmax_t, int ld, unsigned* __restrict__ gmax) {
+    __shared__ unsigned sm[4];
+    unsigned m = 0u;
+    for (int i = threadIdx.x; i < ld; i += 256) { const unsigned v = gmax_t[(size_t)blockIdx.x * ld + i]; m = m > v ? m : v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = m > t ? m : t; }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+        gmax[blockIdx.x] = a > b ? a : b;
     }
 }
 

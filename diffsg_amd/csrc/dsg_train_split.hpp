@@ -247,10 +247,12 @@ struct BlockBwdArgsH {
     BlockBwdArgs b;
     const uint4* W3Th; const uint4* W2Th; const uint4* W1Th; const uint4* WscTh;   // transposed planes [OT][KS][2][64]
     const float* m1; const float* m2; const float* m3; const float* msc;          // max|W| (k_maxabs)
+    unsigned* gmax_t; int gmax_ld;                    // per-tile max|G| words [slot][tile] (operand scales of k_wgrad_h)
+    int slot_out, slot_h2, slot_h1;                   // slots of dout, dh2, dh1
 };
 
 template <int NT>
-__device__ __forceinline__ void row_scale(const f32x16 (&g)[NT], float& s, float& sinv) {
+__device__ __forceinline__ void row_scale(const f32x16 (&g)[NT], float& s, float& sinv, unsigned& mbits) {
     unsigned m = 0u;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -261,6 +263,7 @@ __device__ __forceinline__ void row_scale(const f32x16 (&g)[NT], float& s, float
         }
     const unsigned o = (unsigned)__shfl_xor((int)m, 32);
     m = m > o ? m : o;
+    mbits = m;
     const int be = (int)(m >> 23);
     int e = be == 0 ? 0 : 11 - (be - 127);
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
@@ -295,6 +298,7 @@ struct BwdGemmSplit {
     const BlockBwdArgsH& a;
     int lane;
     bool sclin;
+    int tile;
     template <int NGin, int NTin, int NTout>
     __device__ __forceinline__ void run(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], int which, bool accumulate, int o0 = 0) const {
         constexpr int CH = NTout < 4 ? NTout : 4;
@@ -306,7 +310,16 @@ struct BwdGemmSplit {
         else if (which == 1) e = scale_exp(*a.m1);
         else e = scale_exp_lin3(*a.m3, *a.msc) + 4;
         float s, sinv;
-        row_scale<NTin>(in, s, sinv);
+        unsigned m;
+        row_scale<NTin>(in, s, sinv, m);
+        if (which != 0) {       // the same rows are the G operand of this block's weight gradients: track the tensor maximum
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                const unsigned t = (unsigned)__shfl_xor((int)m, o);
+                m = m > t ? m : t;
+            }
+            if (lane == 0) a.gmax_t[(size_t)(which == 3 ? a.slot_out : (which == 2 ? a.slot_h2 : a.slot_h1)) * a.gmax_ld + tile] = m;
+        }
         const float winv = __int_as_float((127 - e) << 23), wsc = __int_as_float((127 + e) << 23);
         if (accumulate) {
             const float pre = s * wsc;
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_h(const BlockBwdArgsH a
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (tile >= a.b.ntiles) return;
-    resblock_bwd_body<N, SCLIN>(a.b, BwdGemmSplit{a, lane, SCLIN}, tile, lane);
+    resblock_bwd_body<N, SCLIN>(a.b, BwdGemmSplit{a, lane, SCLIN, tile}, tile, lane);
 }
 
 }  // namespace dsg
