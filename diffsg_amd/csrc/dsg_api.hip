@@ -67,6 +67,7 @@ struct ResP {              // ResidualBlock (UNetCF.py:49-95)
     size_t W1T, W2T, W3T, WscT;  // transposed packs (data gradients)
     size_t W1h = 0, W2h = 0, W3h = 0, Wsch = 0;  // fp16-split planes (blocks >= 64 wide, sampling)
     size_t W1Th = 0, W2Th = 0, W3Th = 0, WscTh = 0;  // transposed fp16-split planes (data gradients)
+    size_t Wch = 0;        // fp16-split planes of the condition embedding
     bool split = false;
     // training workspace (per-tile float offsets)
     size_t h1, h2, du1, dh1, dh2, rs1, rs2, rs3;
@@ -162,6 +163,7 @@ struct dsg_handle {
     FusedOpH* fusedh_dev = nullptr;
     FusedOp* ce_dev = nullptr;          // condition-embedding Linear table (narrow blocks, one launch)
     std::vector<FusedOp> ce_host;
+    CondTile* ctile_dev = nullptr; int ctile_n = 0; const float* ctile_key = nullptr; size_t ctile_cap = 0;
     std::vector<FusedOpH> fusedh_host;
 
     // cached step graphs
@@ -292,6 +294,10 @@ void carve(dsg_handle* h) {
         l.betap = l.lnact ? c.take((size_t)KG * 8 + 32) : 0;
         l.WT = c.take((size_t)cdiv(KG, 4) * groups_of(l.l.N) * 256);
         l.Wh = c.take((size_t)NT * ((KG + 1) / 2) * 128 * 4);
+    }
+    {   // condition-embedding planes of every block, consecutive: one grouped launch walks them (k_cond_embed_h)
+        const size_t KSc = (size_t)(CG + 1) / 2;
+        for (auto& r : h->res) r.Wch = c.take((size_t)cdiv(r.N, 32) * KSc * 128 * 4);
     }
     h->zero_off = c.take(128);
     h->arena_floats = c.off;
@@ -709,12 +715,35 @@ void run_time_path(dsg_handle* h, int entries, hipStream_t s, bool train = false
                        P[h->temb_l1b].ptr, td, h1s, emb, h1pre);
     hipLaunchKernelGGL(k_time_embed2, grid, dim3(256), td * sizeof(float), s, h1s, P[h->temb_l2w].ptr, P[h->temb_l2b].ptr, td, h->st, tpre);
     const int nb = (int)h->res.size();
-    hipLaunchKernelGGL(k_time_table, dim3(entries, nb), dim3(256), td * sizeof(float), s, h->st, td, h->tdesc_dev, nb, h->tb, h->tb_stride);
+    hipLaunchKernelGGL(k_time_table, dim3(entries, nb * 8), dim3(256), td * sizeof(float), s, h->st, td, h->tdesc_dev, nb, h->tb, h->tb_stride);
 }
 
 // cembed[block] = Wc silu(cond * mask) for every block from the condition fragments (one launch per block)
 void run_cond_embed(dsg_handle* h, int B, hipStream_t s) {
     const int tpp = cdiv(B, 32), CG = groups_of(h->d.cond_dim);
+    if (h->use_split && (CG + 1) / 2 <= kCondMaxSteps) {
+        // split path: every block in ONE launch
+        if (h->ctile_key != h->cembed || h->ctile_cap != cap_tiles_of(h)) {
+            std::vector<CondTile> tab;
+            for (const ResP& r : h->res) {
+                const int NG = groups_of(r.N);
+                for (int lt = 0; lt < cdiv(r.N, 32); ++lt) {
+                    CondTile t;
+                    t.out = h->cembed + r.ce_off * (cap_tiles_of(h) / 2) + (size_t)lt * 4 * 256;
+                    t.m = h->maxabs + r.ce.w;
+                    t.groups = NG - 4 * lt < 4 ? NG - 4 * lt : 4;
+                    t.ng_block = NG;
+                    tab.push_back(t);
+                }
+            }
+            if (!h->ctile_dev) (void)hipMalloc(&h->ctile_dev, tab.size() * sizeof(CondTile));
+            (void)hipMemcpy(h->ctile_dev, tab.data(), tab.size() * sizeof(CondTile), hipMemcpyHostToDevice);
+            h->ctile_n = (int)tab.size(); h->ctile_key = h->cembed; h->ctile_cap = cap_tiles_of(h);
+        }
+        hipLaunchKernelGGL(k_cond_embed_h, dim3(cdiv(tpp, kWavesPerBlock)), dim3(256), 0, s, h->condfrag, CG,
+                           reinterpret_cast<const uint4*>(h->arena + h->res[0].Wch), h->ctile_dev, h->ctile_n, tpp);
+        return;
+    }
     // wide blocks: one launch each; all blocks <= 32 wide: ONE launch (a wave walks the list for its tile)
     std::vector<FusedOp>& tab = h->ce_host;
     tab.clear();
@@ -1104,7 +1133,7 @@ void dsg_destroy(dsg_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev, h->maxabs,
-                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->ce_dev};
+                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->ce_dev, h->ctile_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1211,7 +1240,8 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
             };
             for (const ResP& r : h->res) {
                 if (!r.split) continue;
-                want(r.l1); want(r.l2); want(r.l3);
+                want(r.l1); want(r.l2); want(r.l3); want(r.ce);
+                pushh(r.ce, nullptr, 0, h->d.cond_dim, 0, r.Wch);
                 if (r.sclin) want(r.sc);
                 pushh(r.l1, nullptr, 0, r.in0, r.in1, r.W1h);
                 pushh(r.l2, nullptr, 0, r.N, 0, r.W2h);

@@ -689,17 +689,27 @@ __global__ __launch_bounds__(256) void k_time_table(const float* __restrict__ st
     for (int i = threadIdx.x; i < td; i += blockDim.x) sm[i] = st[(size_t)ent * td + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int b = blockIdx.y; b < nblocks; b += gridDim.y) {  // gridDim.y == nblocks: one block of the net per workgroup
-        const TimeBlockDesc d = blocks[b];
-        const int npad = (d.N + 31) / 32 * 32;
-        for (int n = wave; n < npad; n += nw) {
-            float v = 0.f;
-            if (n < d.N) {
-                float s = 0.f;
-                for (int k = lane; k < td; k += 64) s = fmaf(d.Wt[(size_t)n * td + k], sm[k], s);
-                v = wave_sum(s) + d.bt[n] + d.b1[n];
+    // gridDim.y == 8 * nblocks: an eighth of one block's rows per workgroup (the table is tiny: the kernel is bound by the
+    // length of one wave's chain of dependent dot products, so it is spread thin)
+    {
+        const int b = blockIdx.y >> 3, part = blockIdx.y & 7;
+        if (b < nblocks) {
+            const TimeBlockDesc d = blocks[b];
+            const int npad = (d.N + 31) / 32 * 32, per = npad / 8;
+            for (int n = part * per + wave; n < (part + 1) * per; n += nw) {
+                float v = 0.f;
+                if (n < d.N) {
+                    float s0 = 0.f, s1 = 0.f;
+                    int k = lane;
+                    for (; k + 64 < td; k += 128) {
+                        s0 = fmaf(d.Wt[(size_t)n * td + k], sm[k], s0);
+                        s1 = fmaf(d.Wt[(size_t)n * td + k + 64], sm[k + 64], s1);
+                    }
+                    for (; k < td; k += 64) s0 = fmaf(d.Wt[(size_t)n * td + k], sm[k], s0);
+                    v = wave_sum(s0 + s1) + d.bt[n] + d.b1[n];
+                }
+                if (lane == 0) tb[(size_t)ent * tb_stride + d.off + n] = v;
             }
-            if (lane == 0) tb[(size_t)ent * tb_stride + d.off + n] = v;
         }
     }
 }

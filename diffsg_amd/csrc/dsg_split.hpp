@@ -704,6 +704,66 @@ __global__ __launch_bounds__(256) void k_maxabs(const float* const* __restrict__
     if (threadIdx.x == 0) out[out_idx[blockIdx.x]] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Condition embeddings of ALL blocks in one launch: ce_b = Wc_b silu(cond * mask) (UNetCF.py:93), the input is the same
+// for every block, so a wave splits its tile's condition fragments once (<= 8 k16-steps, registers) and walks the list of
+// 32-wide output tiles of every block: 3 MFMAs per k16-step, unscale, store in the block's fragment region.
+// ---------------------------------------------------------------------------------------------
+struct CondTile {
+    float* out;           // block region [tile][NG_b][256] + first group of this output tile
+    const float* m;       // max|Wc_b|
+    int groups;           // groups of this output tile that exist (1..4)
+    int ng_block;         // NG_b (tile stride of the region in groups)
+};
+constexpr int kCondMaxSteps = 8;   // cond_dim <= 128
+
+__global__ __launch_bounds__(256) void k_cond_embed_h(const float* __restrict__ condfrag, int CG, const uint4* __restrict__ W,
+                                                      const CondTile* __restrict__ tiles_tab, int nout, int ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (tile >= ntiles) return;
+    const int KS = (CG + 1) >> 1;
+    h8 bhi[kCondMaxSteps], blo[kCondMaxSteps];
+#pragma unroll
+    for (int S = 0; S < kCondMaxSteps; ++S) {
+        if (S < KS) {
+            const float4 x0 = ld4(condfrag + ((size_t)tile * CG + 2 * S) * 256 + lane * 4);
+            const float4 x1 = 2 * S + 1 < CG ? ld4(condfrag + ((size_t)tile * CG + 2 * S + 1) * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float v[8] = {kActScale * x0.x, kActScale * x0.y, kActScale * x0.z, kActScale * x0.w,
+                          kActScale * x1.x, kActScale * x1.y, kActScale * x1.z, kActScale * x1.w};
+            split8(v, bhi[S], blo[S]);
+        }
+    }
+    const size_t ot_stride = (size_t)KS * 128;
+    uint4 wh[kCondMaxSteps], wl[kCondMaxSteps];
+    auto loadw = [&](int ot) {
+#pragma unroll
+        for (int S = 0; S < kCondMaxSteps; ++S)
+            if (S < KS) { wh[S] = W[ot * ot_stride + (size_t)S * 128 + lane]; wl[S] = W[ot * ot_stride + (size_t)S * 128 + 64 + lane]; }
+    };
+    loadw(0);
+    for (int ot = 0; ot < nout; ++ot) {
+        const CondTile ct = tiles_tab[ot];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int S = 0; S < kCondMaxSteps; ++S)
+            if (S < KS) {
+                const h8 whi = __builtin_bit_cast(h8, wh[S]), wlo = __builtin_bit_cast(h8, wl[S]);
+                DSG_MFMA_H(acc, whi, bhi[S]);
+                DSG_MFMA_H(acc, whi, blo[S]);
+                DSG_MFMA_H(acc, wlo, bhi[S]);
+            }
+        if (ot + 1 < nout) loadw(ot + 1);     // next tile's planes land under this tile's MFMAs and stores
+        const float inv = ldexpf(1.0f / kActScale, -scale_exp(*ct.m));
+        float* o = ct.out + (size_t)tile * ct.ng_block * 256 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < ct.groups) st4(o + (size_t)q * 256, make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv));
+    }
+}
+
 struct PackHDesc {
     const float* W;       // [N][Ktot]
     uint4* dst;
