@@ -63,13 +63,14 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 
 template <int NT>
 __device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[NT], const HFrag<NT>& w, const h8 bhi, const h8 blo) {
+    // term-major: the three products of one accumulator are NT instructions apart, so no MFMA waits on the one issued just
+    // before it (per accumulator the order hi*hi, hi*lo, lo*hi is unchanged: same bits)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const h8 whi = __builtin_bit_cast(h8, w.hi[nt]), wlo = __builtin_bit_cast(h8, w.lo[nt]);
-        DSG_MFMA_H(acc[nt], whi, bhi);
-        DSG_MFMA_H(acc[nt], whi, blo);
-        DSG_MFMA_H(acc[nt], wlo, bhi);
-    }
+    for (int nt = 0; nt < NT; ++nt) DSG_MFMA_H(acc[nt], __builtin_bit_cast(h8, w.hi[nt]), bhi);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) DSG_MFMA_H(acc[nt], __builtin_bit_cast(h8, w.hi[nt]), blo);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) DSG_MFMA_H(acc[nt], __builtin_bit_cast(h8, w.lo[nt]), bhi);
 }
 
 // kActScale * silu(u): the scale rides in the denominator (u * rcp((1 + e)/16)); exp as fast_exp_neg without the c_lo
