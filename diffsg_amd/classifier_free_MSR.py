@@ -34,7 +34,8 @@ class DDPM(DDPMCore):
     def _decode_recorded(self, i, y):
         """classifier_free_MSR.py:145-151: row softmax for the first three recorded states, the MSR decoder afterwards."""
         from .decode import msr_decode
-        return torch.softmax(y, dim=1) if i <= 2 else msr_decode(y)
+        from .decode import row_softmax
+        return row_softmax(y) if i <= 2 else msr_decode(y)
 
 
 def msr_data_load(dataset_path):

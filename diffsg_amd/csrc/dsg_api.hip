@@ -5,6 +5,7 @@
 #include "dsg_train.hpp"
 #include "dsg_split.hpp"
 #include "dsg_train_split.hpp"
+#include "dsg_eval.hpp"
 #include "../../include/diffsg.h"
 
 #include <math.h>
@@ -1577,6 +1578,93 @@ int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_deca
     if (n == 0) return 0;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_ema, dim3(blocks), dim3(256), 0, (hipStream_t)stream, avg, p, decay, one_minus_decay, (size_t)n);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- decoders / evaluators (dsg_eval.hpp)
+namespace {
+int eval_args(const void* a, const void* b, long long rows, int D, const char* who) {
+    if (!a || !b || rows < 0 || D < 1) return fail("%s: bad arguments", who);
+    return 0;
+}
+// part[0] <- (min, max) of columns [c0, c1) of the whole tensor; stream-ordered scratch, freed by the caller after its consumer
+int minmax_global(const float* y, long long rows, int D, int c0, int c1, float2** part, hipStream_t s) {
+    const int w = c1 - c0, lpr = w >= 64 ? 64 : (w >= 16 ? 16 : (w >= 4 ? 4 : 1));
+    const long long want = (rows + 4LL * (64 / lpr) - 1) / (4LL * (64 / lpr));   // one trip of k_minmax_partial per block if it fits
+    const int nparts = (int)(want < kEvalParts ? want : kEvalParts);
+    HIPCK(hipMallocAsync(reinterpret_cast<void**>(part), (size_t)(1 + nparts) * sizeof(float2), s));
+    hipLaunchKernelGGL(k_minmax_partial, dim3(nparts), dim3(256), 0, s, y, rows, D, c0, c1, *part);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, s, *part, nparts);
+    return 0;
+}
+template <int MODE>
+int softmax_rows(const float* y, float* out, long long rows, int D, hipStream_t s, int c0, int c1) {
+    if (rows == 0) return 0;
+    float2* part = nullptr;
+    if (MODE == 1 && minmax_global(y, rows, D, c0, c1, &part, s)) return 1;
+    auto blocks = [&](int lpr) { const long long rpb = 4LL * (64 / lpr); return dim3((unsigned)((rows + rpb - 1) / rpb)); };
+    if (D <= kSoftEpl) hipLaunchKernelGGL((k_row_softmax<MODE, 1>), blocks(1), dim3(256), 0, s, y, out, rows, D, part);
+    else if (D <= 4 * kSoftEpl) hipLaunchKernelGGL((k_row_softmax<MODE, 4>), blocks(4), dim3(256), 0, s, y, out, rows, D, part);
+    else if (D <= 16 * kSoftEpl) hipLaunchKernelGGL((k_row_softmax<MODE, 16>), blocks(16), dim3(256), 0, s, y, out, rows, D, part);
+    else if (D <= 64 * kSoftEpl) hipLaunchKernelGGL((k_row_softmax<MODE, 64>), blocks(64), dim3(256), 0, s, y, out, rows, D, part);
+    else hipLaunchKernelGGL((k_row_softmax_wide<MODE>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, y, out, rows, D, part);
+    if (part) HIPCK(hipFreeAsync(part, s));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int dsg_row_softmax(const float* y, float* out, long long rows, int D, void* stream) {
+    if (eval_args(y, out, rows, D, "dsg_row_softmax")) return 1;
+    return softmax_rows<0>(y, out, rows, D, (hipStream_t)stream, 0, D);
+}
+int dsg_msr_decode(const float* y, float* out, long long rows, int D, void* stream) {
+    if (eval_args(y, out, rows, D, "dsg_msr_decode")) return 1;
+    return softmax_rows<1>(y, out, rows, D, (hipStream_t)stream, 0, D);
+}
+int dsg_co_decode(const float* y, float* out, long long rows, int D, void* stream) {
+    if (eval_args(y, out, rows, D, "dsg_co_decode")) return 1;
+    return softmax_rows<2>(y, out, rows, D, (hipStream_t)stream, 0, D);
+}
+int dsg_msr_rate(const float* p, const float* gain, float* rate, long long rows, int D, void* stream) {
+    if (eval_args(p, gain, rows, D, "dsg_msr_rate") || !rate) return fail("dsg_msr_rate: bad arguments");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (D <= 8) hipLaunchKernelGGL((k_msr_rate<1>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, p, gain, rate, rows, D);
+    else if (D <= 160) hipLaunchKernelGGL((k_msr_rate<16>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, p, gain, rate, rows, D);
+    else hipLaunchKernelGGL((k_msr_rate<64>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p, gain, rate, rows, D);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+int dsg_co_cost(const float* X, const float* Y, float* cost, long long rows, int n, void* stream) {
+    if (eval_args(X, Y, rows, n, "dsg_co_cost") || !cost) return fail("dsg_co_cost: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_co_cost, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, Y, cost, rows, n);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+int dsg_nu_decode(const float* y, float* out, long long rows, int D, float width, float height, float p_sum, void* stream) {
+    if (eval_args(y, out, rows, D, "dsg_nu_decode")) return 1;
+    if (D < 3) return fail("dsg_nu_decode: D = %d (two position columns and at least one power column)", D);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    float2* part = nullptr;
+    if (minmax_global(y, rows, D, 0, 2, &part, s)) return 1;
+    hipLaunchKernelGGL(k_nu_decode, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, y, out, rows, D, width, height, p_sum, part);
+    HIPCK(hipFreeAsync(part, s));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+int dsg_nu_rate(const float* Yd, const float* X, float* rate, long long rows, int K, void* stream) {
+    if (eval_args(Yd, X, rows, K, "dsg_nu_rate") || !rate) return fail("dsg_nu_rate: bad arguments");
+    if (K > kNuMaxUsers) return fail("dsg_nu_rate: K = %d users (at most %d)", K, kNuMaxUsers);
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_nu_rate, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Yd, X, rate, rows, K);
     HIPCK(hipGetLastError());
     return 0;
 }

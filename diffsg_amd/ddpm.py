@@ -107,8 +107,8 @@ class DDPMCore(nn.Module):
         if rec is not None:
             # one device-to-host copy of the whole trajectory instead of the reference's 2T per-step copies (MSR.py:140-141);
             # then the reference's post-processing (MSR.py:143-154): decode every recorded y, lay out as (B, T*D)
-            ys = rec[0].cpu()
-            ys = torch.stack([self._decode_recorded(i, ys[i]) for i in range(T)]).numpy()
+            # (decoded on the device, MSR.py:143-154), then ONE copy
+            ys = torch.stack([self._decode_recorded(i, rec[0][i]) for i in range(T)]).cpu().numpy()
             self.y_i_record = ys.transpose(1, 0, 2).reshape(B, -1)
             self.eps_i_record = rec[1].cpu().numpy().transpose(1, 0, 2).reshape(B, -1)
         # the call only enqueues: keep its inputs alive until the next call on this object

@@ -97,6 +97,24 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
 /* avg = decay*avg + one_minus_decay*p over n floats   (ddpm_opt/ema.py:11-12). */
 int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_decay, long long n, void* stream);
 
+/* ---- Solution decoders and objective evaluators.  Row-major float32 device tensors; no handle: they do
+ * not depend on the denoiser.  Stream-ordered; scratch for the two global reductions comes from hipMallocAsync. ---- */
+/* out[r][:] = softmax(y[r][:])   (torch.softmax(dim=1); MSR.py:147 for the first recorded states) */
+int dsg_row_softmax(const float* y, float* out, long long rows, int D, void* stream);
+/* custom_decoder, classifier_free_MSR.py:239-245: min-max over the WHOLE tensor, then a row softmax. */
+int dsg_msr_decode(const float* y, float* out, long long rows, int D, void* stream);
+/* rate[r] = sum_c log2(1 + p[r][c] * gain[r][c])   (classifier_free_MSR.py:287-288). */
+int dsg_msr_rate(const float* p, const float* gain, float* rate, long long rows, int D, void* stream);
+/* customized_real_decoder, classifier_free_CO.py:281-290: row softmax; rows with every entry < -10 become zero. */
+int dsg_co_decode(const float* y, float* out, long long rows, int D, void* stream);
+/* cost_calc, classifier_free_CO.py:255-278: X [rows][3n] = (local, transition, exec) per node, Y [rows][n] decoded shares. */
+int dsg_co_cost(const float* X, const float* Y, float* cost, long long rows, int n, void* stream);
+/* custom_decoder, classifier_free_NU.py:267-276: columns 0,1 min-max scaled (global over both) to width x height,
+ * columns 2.. softmax * p_sum. */
+int dsg_nu_decode(const float* y, float* out, long long rows, int D, float width, float height, float p_sum, void* stream);
+/* rate_calc, classifier_free_NU.py:279-303: NOMA-SIC sum rate; Yd [rows][K+2] decoded, X [rows][2K] user positions; K <= 32. */
+int dsg_nu_rate(const float* Yd, const float* X, float* rate, long long rows, int K, void* stream);
+
 /* Measurement hooks for bench.py: the per-step operator list and a timed replay of one operator's kernel with HIP
  * events on `stream` (rows = B rows, both passes, as inside dsg_sample). */
 int dsg_op_count(const dsg_handle* h);

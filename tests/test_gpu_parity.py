@@ -420,3 +420,56 @@ def test_record_denoise_path(gold):
     assert rel(ddpm.y_i_record, r["y_i_record"]) <= 1e-4
     ddpm.record_denoise_path = False
     assert torch.equal(ddpm.sample(torch.from_numpy(g["cond"]).cuda(), 1.0, y_T=torch.from_numpy(g["y_T"]), noise=_z(g, T)), y0)
+
+
+# ---------------------------------------------------------------- decoders / evaluators
+def test_decoders_match_reference_goldens(gold):
+    """dsg_*_decode / dsg_*_rate / dsg_co_cost through the C ABI against the outputs of the reference's own functions
+    (tests/golden/g5_decoders.npz, made by importing the reference)."""
+    from diffsg_amd import decode as Dc
+    g = gold("g5_decoders.npz")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    close = lambda a, b, tol=2e-6: np.abs(a.cpu().numpy() - b).max() <= tol * max(np.abs(b).max(), 1e-30)
+    dec = Dc.msr_decode(t("msr_y"))
+    assert close(dec, g["msr_dec"]) and close(Dc.msr_rate(10.0 * dec, t("msr_gain")), g["msr_rate"])
+    dec = Dc.co_decode(t("co_y"))
+    assert close(dec, g["co_dec"]) and close(Dc.co_cost(t("co_X"), dec), g["co_cost"])
+    dec = Dc.nu_decode(t("nu_y"), 400, 400, 18.0)
+    assert close(dec, g["nu_dec"]) and close(Dc.nu_rate(dec, t("nu_X")), g["nu_rate"], 1e-5)
+
+
+@pytest.mark.parametrize("rows", [1, 63, 1000, 65536])
+def test_decoders_vs_oracle_random(rows):
+    """Ragged and full-size batches against the CPU restatement, incl. the CO dead-row rule, ties-free NU ordering with
+    K = 7 users, and the properties the domain offers: decoded rows sum to 1 (MSR, CO) / to P_sum (NU powers)."""
+    from diffsg_amd import decode as Dc
+    g = torch.Generator().manual_seed(rows)
+    rel_ok = lambda a, b, tol: float((a.cpu() - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-30)
+    y = torch.randn(rows, 80, generator=g) * 3.0
+    gain = torch.rand(rows, 80, generator=g) * 5.0
+    dec = Dc.msr_decode(y.cuda())
+    assert rel_ok(dec, O.msr_decode(y), 2e-6) and float((dec.sum(1) - 1).abs().max()) < 1e-5
+    assert rel_ok(Dc.msr_rate(10.0 * dec, gain.cuda()), O.msr_rate(10.0 * O.msr_decode(y), gain), 5e-6)
+    assert rel_ok(Dc.row_softmax(y.cuda()), torch.softmax(y, 1), 2e-6)
+    if rows <= 1000:                                  # every lanes-per-row variant of the softmax kernel, and the streamed one
+        for D in (1, 16, 17, 64, 65, 256, 257, 1024, 1100):
+            yw = torch.randn(rows, D, generator=g) * 4.0
+            assert rel_ok(Dc.row_softmax(yw.cuda()), torch.softmax(yw, 1), 2e-6), D
+            assert rel_ok(Dc.msr_decode(yw.cuda()), O.msr_decode(yw), 3e-6) or (rows * D == 1), D
+    yc = torch.randn(rows, 3, generator=g)
+    yc[::7] = -20.0                                   # dead rows
+    Xc = torch.rand(rows, 9, generator=g) * 10.0
+    dc = Dc.co_decode(yc.cuda())
+    assert rel_ok(dc, O.co_decode(yc), 2e-6) and float(dc[::7].abs().max()) == 0.0
+    assert rel_ok(Dc.co_cost(Xc.cuda(), dc), O.co_cost(Xc, O.co_decode(yc)), 1e-5)
+    K = 7
+    yn = torch.randn(rows, K + 2, generator=g)
+    Xn = torch.rand(rows, 2 * K, generator=g) * 400.0
+    dn = Dc.nu_decode(yn.cuda(), 400, 400, 18.0)
+    if rows > 1:                                      # one row: the global min-max of the position columns degenerates
+        assert rel_ok(dn, O.nu_decode(yn, 400, 400, 18.0), 2e-6)
+        assert float((dn[:, 2:].sum(1) - 18.0).abs().max()) < 1e-4
+        # rates here are ~1e-4 bit: each of the K terms is log2(1 + sinr) with sinr << 1, so float32 resolves it to ~1.7e-7
+        # absolute whatever the implementation; the bound is K ulps of 1.0 in log2 units, not a relative one
+        ref_rate = O.nu_rate(O.nu_decode(yn, 400, 400, 18.0), Xn)
+        assert float((Dc.nu_rate(dn, Xn.cuda()).cpu() - ref_rate).abs().max()) <= 1e-5 * float(ref_rate.abs().max()) + K * 1.8e-7
