@@ -1291,7 +1291,8 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
     if (h->mx_n) {
         // max|W| of every split-packed weight -> maxabs[param index]; the pack and the block kernels derive the same
         // power-of-two scale from it on the device (no host round trip)
-        hipLaunchKernelGGL(k_maxabs, dim3(h->mx_n), dim3(256), 0, s, h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->maxabs);
+        HIPCK(hipMemsetAsync(h->maxabs, 0, h->params.size() * sizeof(float), s));
+        hipLaunchKernelGGL(k_maxabs, dim3(h->mx_n, kMaxabsSlices), dim3(256), 0, s, h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->maxabs);
         hipLaunchKernelGGL(k_pack_h, dim3((unsigned)h->packh_blocks), dim3(256), 0, s, h->packh_dev, h->packh_n);
     }
     HIPCK(hipGetLastError());
@@ -1474,7 +1475,7 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     RunCtx c{B, 1, 0, h->tr_yt_rm, h->eps, nullptr, h->tr_ts, true, h->use_split};
     run_unet(h, c, s);
     hipLaunchKernelGGL(k_loss_grad, dim3(kRedBlocks), dim3(256), 0, s, h->eps, noise, B, D, trp(h, h->tr_deps), tiles, h->red);
-    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, s, h->red, kRedBlocks, (double)B * (double)D, loss_out);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, s, h->red, kRedBlocks, (double)B * (double)D, loss_out);
 
     // ---- backward: activation gradients in reverse operator order
     HIPCK(hipMemsetAsync(h->tr_gmax_t, 0, (size_t)h->n_gmax * h->gmax_ld * sizeof(unsigned), s));

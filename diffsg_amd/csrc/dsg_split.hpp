@@ -691,18 +691,26 @@ __global__ __launch_bounds__(256, 4) void k_fused_narrow_h(const FusedOpH* __res
 //   dst[((nt*KS + S)*2 + plane)*64 + lane] = 8 halfs: plane(W[32nt + (lane&31)][col(2S + (jj>>2), 4(lane>>5) + (jj&3))] * 2^e)
 // with every K segment padded to an EVEN number of 8-feature groups.
 // ---------------------------------------------------------------------------------------------
+// grid (tensors, kMaxabsSlices): a slice of a tensor per block, combined by atomicMax on the bit pattern (values are >= 0, so
+// the patterns order like the values); `out` is zeroed by the caller.  One block per tensor made the launch as long as the
+// serial walk over the largest weight matrix.
+constexpr int kMaxabsSlices = 8;
 __global__ __launch_bounds__(256) void k_maxabs(const float* const* __restrict__ ptrs, const long long* __restrict__ numel,
                                                 const int* __restrict__ out_idx, float* __restrict__ out) {
     __shared__ float sm[4];
     const float* p = ptrs[blockIdx.x];
     const long long n = numel[blockIdx.x];
+    const long long per = (n + kMaxabsSlices - 1) / kMaxabsSlices, lo = blockIdx.y * per, hi = lo + per < n ? lo + per : n;
     float m = 0.f;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(p[i]));
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) m = fmaxf(m, fabsf(p[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) out[out_idx[blockIdx.x]] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (threadIdx.x == 0) {
+        const float v = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        if (v > 0.f) atomicMax(reinterpret_cast<unsigned*>(out + out_idx[blockIdx.x]), __float_as_uint(v));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

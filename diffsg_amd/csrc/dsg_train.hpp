@@ -66,12 +66,12 @@ __global__ __launch_bounds__(256) void k_loss_grad(const float* __restrict__ eps
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-__global__ void k_loss_final(const double* __restrict__ part, int nparts, double denom, float* __restrict__ loss) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < nparts; ++i) t += part[i];
-        *loss = (float)(t / denom);
-    }
+__global__ __launch_bounds__(256) void k_loss_final(const double* __restrict__ part, int nparts, double denom, float* __restrict__ loss) {
+    __shared__ double sm[4];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) t += part[i];     // fixed assignment and tree: deterministic
+    t = block_sum(t, sm);
+    if (threadIdx.x == 0) *loss = (float)(t / denom);
 }
 
 // ---------------------------------------------------------------------------------------------
