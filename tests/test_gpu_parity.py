@@ -272,6 +272,30 @@ def test_training_reduces_loss_and_matches_cpu_adam():
         assert rel(v, cpu[k].detach()) <= 1e-3, k
 
 
+@pytest.mark.parametrize("name,B", [("msr80", 100), ("co3", 77)])
+def test_train_step_exact_f32_mode(name, B):
+    """precision="f32": exact f32 MFMA forward, data gradients and weight gradients (k_resblock_bwd / k_wgrad), same oracle."""
+    plan, p = synth_params(name, 11)
+    T = 20
+    ddpm = make_ddpm(name, p, T)
+    ddpm.model.set_precision("f32")
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(B)
+    y = torch.rand(B, cfg["input_dim"], generator=g)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g)
+    ts = torch.randint(0, T, (1, B), generator=g)
+    noise = torch.randn(B, cfg["input_dim"], generator=g)
+    mask = (torch.rand(B, 1, generator=g) < 0.9).float()
+    loss = ddpm(y.cuda(), cond.cuda(), ts=ts.cuda(), noise=noise.cuda(), cond_mask=mask.cuda())
+    loss.backward()
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    ref_loss, ref = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    for k, prm in ddpm.model.named_parameters():
+        assert float((prm.grad.cpu() - ref[k]).abs().max()) / gmax <= 1e-4, k
+
+
 @pytest.mark.parametrize("name,B", [("msr3", 512), ("msr80", 96)])
 def test_train_step_is_run_to_run_deterministic(name, B):
     """Same inputs -> bit-identical loss and gradients, 12 times (every reduction has a fixed order; this also guards the
