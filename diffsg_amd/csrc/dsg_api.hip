@@ -853,7 +853,7 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
     const Param* P = h->params.data();
     const int DG = groups_of(h->d.input_dim);
     const int tiles = cdiv(B, 32);
-    { const char* e = getenv("DSG_CHUNKS"); const int mc = e ? atoi(e) : 32; h->tr_chunks = tiles < mc ? tiles : mc; }
+    h->tr_chunks = tiles < 32 ? tiles : 32;
     std::vector<WgradDesc> wd;
     std::vector<int> wd_op;            // operator each descriptor belongs to
     int cur_op = 0;
