@@ -145,7 +145,8 @@ def main():
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["split_f16", "f32"], default="split_f16")
-    ap.add_argument("--train-batch", type=int, default=65536, help="training rows per GPU (the sampling workload's batch)")
+    ap.add_argument("--train-batch", type=int, default=32768,
+                    help="training rows per GPU: BASELINE config 4 is a global batch of 262144 over 8 GPUs")
     ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--no-train", action="store_true")
     a = ap.parse_args()
