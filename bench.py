@@ -97,7 +97,7 @@ def _cpu_baseline_run(nthreads, sample_rows, steps, B_ref):
             "row_steps_per_s": row_steps}
 
 
-def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=3):
+def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
     """MSR-80c training throughput (BASELINE config 5 shape): per GPU `B` rows, T=20, Adam(lr 5e-3); one step =
     DDPM.forward (q_sample + denoiser forward + backward in libdiffsg_hip) + ONE all-reduce of the flat 6.6 MB gradient
     bucket (RCCL, world > 1) + Adam.step + re-pack of the updated weights."""
@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--precision", choices=["split_f16", "f32"], default="split_f16")
     ap.add_argument("--train-batch", type=int, default=32768,
                     help="training rows per GPU: BASELINE config 4 is a global batch of 262144 over 8 GPUs")
-    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--warm-seconds", type=float, default=0.3, help="untimed clock warm-up before the timed steps")
     a = ap.parse_args()
