@@ -24,20 +24,34 @@ class UNetDesc(ctypes.Structure):
                 ("n_res", ctypes.c_int), ("dims", ctypes.c_int * MAX_RES), ("n_blocks", ctypes.c_int)]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU)."""
+def _stale() -> bool:
     deps = [p for p in SOURCES + HEADERS if os.path.exists(p)]
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(p) for p in deps)):
+    return not (os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(p) for p in deps))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU).  Serialised by a file lock: the ranks of a
+    multi-process launch must not compile the same file at once."""
+    if not force and not _stale():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -fno-slp-vectorize: with the SLP vectoriser on, the packed-f32 code it forms in k_wgrad_h gave run-to-run different
-    # results on gfx950 (DESIGN.md, "Build flags"); without it the library is deterministic and 2-5 % faster.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-fno-slp-vectorize",
-           "-o", LIB_PATH] + SOURCES
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():      # another process built it while this one waited
+                return LIB_PATH
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            # -fno-slp-vectorize: with the SLP vectoriser on, the packed-f32 code it forms in k_wgrad_h gave run-to-run
+            # different results on gfx950 (DESIGN.md, "Build flags"); without it the library is deterministic and 2-5 % faster.
+            tmp = LIB_PATH + f".{os.getpid()}.tmp"
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-fno-slp-vectorize",
+                   "-o", tmp] + SOURCES
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB_PATH)           # atomic: a reader never maps a half-written library
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB_PATH
 
 
