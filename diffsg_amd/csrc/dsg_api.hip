@@ -6,6 +6,7 @@
 #include "dsg_split.hpp"
 #include "dsg_train_split.hpp"
 #include "dsg_eval.hpp"
+#include "dsg_labelgen.hpp"
 #include "../../include/diffsg.h"
 
 #include <math.h>
@@ -1666,6 +1667,35 @@ int dsg_nu_rate(const float* Yd, const float* X, float* rate, long long rows, in
     if (K > kNuMaxUsers) return fail("dsg_nu_rate: K = %d users (at most %d)", K, kNuMaxUsers);
     if (rows == 0) return 0;
     hipLaunchKernelGGL(k_nu_rate, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Yd, X, rate, rows, K);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int dsg_sum_rate_gen(const double* gs, double* schemes, double* rates, long long rows, int M, double W, void* stream) {
+    if (!gs || !schemes || !rates || rows < 0 || M < 1) return fail("dsg_sum_rate_gen: bad arguments");
+    if (M > kSrMaxM) return fail("dsg_sum_rate_gen: M = %d channels (at most %d)", M, kSrMaxM);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int kMaxIter = 149;                       // the reference leaves its loop when k reaches 150
+    int* flags = nullptr;
+    HIPCK(hipMallocAsync(reinterpret_cast<void**>(&flags), (kMaxIter + 3) * sizeof(int), s));
+    HIPCK(hipMemsetAsync(flags, 0, (kMaxIter + 3) * sizeof(int), s));
+    HIPCK(hipMemsetAsync(flags, 1, 1, s));          // flags[0] = 1 (low byte): the dry pass always runs
+    const long long n = rows * M;
+    hipLaunchKernelGGL(k_sumrate_init, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, schemes, n, W / M);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const double eps = 0.001;
+    double beta = 0.1;
+    hipLaunchKernelGGL(k_sumrate_iter, grid, dim3(256), 0, s, gs, schemes, rows, M, 0.0, eps, flags, flags + 1, 1);
+    int k = 1;
+    for (int it = 1; it <= kMaxIter; ++it) {
+        hipLaunchKernelGGL(k_sumrate_iter, grid, dim3(256), 0, s, gs, schemes, rows, M, beta, eps, flags + it, flags + it + 1, 0);
+        ++k;
+        if (k % 20 == 0) beta *= 0.5;
+        if (k == 150) break;
+    }
+    hipLaunchKernelGGL(k_sumrate_rates, grid, dim3(256), 0, s, gs, schemes, rates, rows, M);
+    HIPCK(hipFreeAsync(flags, s));
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -115,6 +115,11 @@ int dsg_nu_decode(const float* y, float* out, long long rows, int D, float width
 /* rate_calc, classifier_free_NU.py:279-303: NOMA-SIC sum rate; Yd [rows][K+2] decoded, X [rows][2K] user positions; K <= 32. */
 int dsg_nu_rate(const float* Yd, const float* X, float* rate, long long rows, int K, void* stream);
 
+/* ---- Label generator of the MSR problem: SUM_RATE_GEN, utils/dataset_generate.py:280-313 ("LRH gradient
+ * descent", float64 like the reference).  gs [rows][M] channel gains (the reference draws them with np.random.uniform; the
+ * caller does), W total power; schemes [rows][M] and rates [rows] are written.  M <= 128.  Stream-ordered. */
+int dsg_sum_rate_gen(const double* gs, double* schemes, double* rates, long long rows, int M, double W, void* stream);
+
 /* Measurement hooks for bench.py: the per-step operator list and a timed replay of one operator's kernel with HIP
  * events on `stream` (rows = B rows, both passes, as inside dsg_sample). */
 int dsg_op_count(const dsg_handle* h);

@@ -10,7 +10,7 @@ committed.  Nothing here is imported by tests at run time except weights.py.
 Groups follow SURVEY.md section 8(c): G1 schedule, G2 denoiser forward (+ per
 module taps), G3 DDPM.forward loss/grads, G4 DDPM.sample trajectories (NU
 checkpoint + synthetic), G5 decoders/evaluators, G6 loaders on CSV slices,
-G7 state-dict layout + EMA.
+G7 state-dict layout + EMA, G8 the MSR label generator.
 """
 import json
 import os
@@ -356,7 +356,27 @@ def g7():
     save("g7_seeded_init.npz", **out)
 
 
+def g8():
+    """utils/dataset_generate.py:247-313: SUM_RATE_GEN (LRH gradient descent labels of the MSR problem), float64."""
+    import contextlib, io
+    from utils.dataset_generate import SUM_RATE_GEN, SUM_RATE_GRAD, alpha_calc
+    out = {}
+    for tag, n, M, W in (("m3", 40, 3, 10.0), ("m80", 48, 80, 20.0), ("m7", 33, 7, 5.0)):
+        np.random.seed(1000 + M)
+        with contextlib.redirect_stdout(io.StringIO()):
+            gs, rates, schemes = SUM_RATE_GEN(sample_num=n, M=M, W=W)
+        out[tag + "_gs"], out[tag + "_rates"], out[tag + "_schemes"] = gs, rates, schemes
+        out[tag + "_W"] = np.array(W)
+    # one alpha_calc step on its own (the piece with the sort)
+    np.random.seed(7)
+    gs = np.random.uniform(0.5, 2.5, size=(9, 12))
+    sch = np.random.uniform(0.1, 1.0, size=(9, 12))
+    grad = SUM_RATE_GRAD(gs, sch)
+    out["step_gs"], out["step_schemes"], out["step_grad"], out["step_alpha"] = gs, sch, grad, alpha_calc(grad)
+    save("g8_sum_rate_gen.npz", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7)
+    groups = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

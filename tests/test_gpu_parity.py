@@ -497,3 +497,39 @@ def test_decoders_vs_oracle_random(rows):
         # absolute whatever the implementation; the bound is K ulps of 1.0 in log2 units, not a relative one
         ref_rate = O.nu_rate(O.nu_decode(yn, 400, 400, 18.0), Xn)
         assert float((Dc.nu_rate(dn, Xn.cuda()).cpu() - ref_rate).abs().max()) <= 1e-5 * float(ref_rate.abs().max()) + K * 1.8e-7
+
+
+# ---------------------------------------------------------------- MSR label generator
+def test_sum_rate_gen_matches_reference_goldens(gold):
+    """dsg_sum_rate_gen (149 device iterations, float64) against the outputs of the reference's own SUM_RATE_GEN on the same
+    channel gains (tests/golden/g8_sum_rate_gen.npz), and its invariant: the total power stays W."""
+    from diffsg_amd.labelgen import SUM_RATE_GEN
+    g = gold("g8_sum_rate_gen.npz")
+    for tag in ("m3", "m7", "m80"):
+        gs, W = g[tag + "_gs"], float(g[tag + "_W"])
+        gs2, rates, schemes = SUM_RATE_GEN(sample_num=gs.shape[0], M=gs.shape[1], W=W, gs=gs)
+        assert gs2 is not None and np.array_equal(gs2, gs)
+        assert np.allclose(schemes, g[tag + "_schemes"], rtol=1e-10, atol=1e-12), (tag, np.abs(schemes - g[tag + "_schemes"]).max())
+        assert np.allclose(rates, g[tag + "_rates"], rtol=1e-12), tag
+        assert np.allclose(schemes.sum(1), W, rtol=1e-12), tag
+
+
+@pytest.mark.parametrize("rows,M", [(1, 1), (5, 2), (257, 64), (1000, 65), (300, 128)])
+def test_sum_rate_gen_vs_oracle(rows, M):
+    from diffsg_amd.labelgen import SUM_RATE_GEN
+    from oracle import sumrate_oracle as S
+    rng = np.random.default_rng(rows + M)
+    gs = rng.uniform(0.5, 2.5, size=(rows, M))
+    _, rates, schemes = SUM_RATE_GEN(sample_num=rows, M=M, W=20.0, gs=gs)
+    ref_rates, ref_schemes = S.sum_rate_gen(gs, 20.0)
+    assert np.allclose(schemes, ref_schemes, rtol=1e-10, atol=1e-12), np.abs(schemes - ref_schemes).max()
+    assert np.allclose(rates, ref_rates, rtol=1e-12)
+
+
+def test_sum_rate_gen_draws_gains_like_the_reference():
+    """Without `gs` the gains come from numpy's global generator, one uniform(size=(n, M)) call as in the reference."""
+    from diffsg_amd.labelgen import SUM_RATE_GEN
+    np.random.seed(11)
+    gs, rates, schemes = SUM_RATE_GEN(sample_num=7, M=5, W=10.0)
+    np.random.seed(11)
+    assert np.array_equal(gs, np.random.uniform(0.5, 2.5, size=(7, 5))) and rates.shape == (7,) and schemes.shape == (7, 5)

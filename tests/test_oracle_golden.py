@@ -173,3 +173,16 @@ def test_g7_state_layout_and_ema(gold):
         assert n == int(g[f"step{step}_n"])
         close(avg["feature_proj.weight"], g[f"step{step}_feature_proj.weight"])
         close(avg["norm.bias"], g[f"step{step}_norm.bias"])
+
+
+def test_g8_sum_rate_label_generator(gold):
+    """oracle/sumrate_oracle.py against the reference's SUM_RATE_GEN / alpha_calc outputs (float64, same additions)."""
+    from oracle import sumrate_oracle as S
+    g = gold("g8_sum_rate_gen.npz")
+    assert np.array_equal(S.sum_rate_grad(g["step_gs"], g["step_schemes"]), g["step_grad"])
+    assert np.allclose(S.alpha_calc(g["step_grad"]), g["step_alpha"], rtol=1e-13, atol=1e-15)
+    for tag in ("m3", "m7", "m80"):
+        rates, schemes = S.sum_rate_gen(g[tag + "_gs"], float(g[tag + "_W"]))
+        assert np.allclose(schemes, g[tag + "_schemes"], rtol=1e-11, atol=1e-13), tag
+        assert np.allclose(rates, g[tag + "_rates"], rtol=1e-12), tag
+        assert np.allclose(schemes.sum(1), float(g[tag + "_W"]), rtol=1e-12), tag     # total power is conserved
