@@ -365,7 +365,11 @@ __global__ void k_linspace_t(float* p, int T) {  // t = i / T in float32, as `to
 int ensure_workspace(dsg_handle* h, int rows, int entries) {
     if (rows <= h->cap_rows && entries <= h->cap_entries) return 0;
     const int nrows = rows > h->cap_rows ? rows : h->cap_rows;
-    const int nent = entries > h->cap_entries ? entries : h->cap_entries;
+    // the per-entry tables are a few MB: size them for 1024 schedule entries at once (T = 1000 is the longest shipped schedule), so
+    // that a longer call after a short one -- a K-step run after a W-step warm-up -- does not free and re-create the multi-GB row
+    // workspace and the captured graphs in the middle of a timed region
+    int nent = entries > h->cap_entries ? entries : h->cap_entries;
+    if (nent < 1024) nent = 1024;
     HIPCK(hipDeviceSynchronize());
     free_workspace(h);
     const size_t tiles = (size_t)cdiv(nrows, 32) * 2;  // two passes
@@ -555,9 +559,25 @@ void launch_res_h_n(bool sclin, const BlockArgsH& a, hipStream_t s) {
     if (sclin) hipLaunchKernelGGL((k_resblock_h<N, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_resblock_h<N, false>), grid, block, 0, s, a);
 }
+// launches with fewer row tiles than this leave SIMDs idle with one wave per tile: the wide blocks then run cooperatively
+// (N/32 waves per tile, k_resblock_c)
+constexpr int kCoopMaxTiles = 512;
+
 void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStream_t s) {
     BlockArgsH a;
     fill_block_args_h(h, r, b, a);
+    if ((r.N == 64 || r.N == 128) && a.b.ntiles <= kCoopMaxTiles && !getenv("DSG_NO_COOP")) {
+        const int tpw = 4 / (r.N / 32);
+        const dim3 grid(cdiv(a.b.ntiles, tpw)), block(256);
+        if (r.N == 128) {
+            if (r.sclin) hipLaunchKernelGGL((k_resblock_c<128, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_resblock_c<128, false>), grid, block, 0, s, a);
+        } else {
+            if (r.sclin) hipLaunchKernelGGL((k_resblock_c<64, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_resblock_c<64, false>), grid, block, 0, s, a);
+        }
+        return;
+    }
     switch (r.N) {
         case 4: launch_res_h_n<4>(r.sclin, a, s); break;
         case 8: launch_res_h_n<8>(r.sclin, a, s); break;
@@ -683,6 +703,7 @@ bool try_pair(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
     if (fuse && i + 1 >= h->fuse_lo && i < h->fuse_hi) return false;
     const ResP& r = h->res[a.p];
     if (r.N < 64) return false;
+    if (cdiv(c.nrows, 32) * c.npass <= kCoopMaxTiles && !getenv("DSG_NO_COOP")) return false;   // small launch: cooperative block, then the Linear
     BlockArgs ba; LinArgs la;
     fill_block_args(h, a, c, ba);
     fill_lin_args(h, b, c, la);

@@ -380,6 +380,276 @@ __global__ __launch_bounds__(256, 2) void k_resblock_h(const BlockArgsH ah) {
     resblock_body_h<N, SCLIN>(ah, tile, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cooperative form of the wide blocks for SMALL launches (fewer row tiles than SIMDs: 512-row evaluation chunks, the
+// 8 192-row BASELINE config, 32 768-row training steps).  One wave per tile leaves most of the chip idle there and a block
+// is then as slow as ONE wave walking through all of it (VALU and MFMA of a wave do not overlap).  Here the N/32 waves of
+// a tile each own one 32-feature slice of every stage: a wave transforms (LayerNorm, SiLU, hi/lo split) only its share
+// of a stage's input and publishes the operand halves in LDS, all waves read all of them (lane-contiguous b128, the MFMA
+// B-operand image as it is) and multiply by their own slice of the weights; the LayerNorm statistics of the next stage
+// are merged from the per-slice (mean, M2) with Chan's formula.  Same packed weights, same HBM layouts, same arithmetic per
+// element; only the order of the additions inside a row statistic differs from k_resblock_h.
+// Workgroup = 4 waves = one 128-wide tile or two 64-wide tiles.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCoopLdsU4 = 4096;      // 64 KiB: per tile slot the transformed image and (Linear shortcut) the raw image
+
+__device__ __forceinline__ void coop_publish(uint4* __restrict__ img, int S, int lane, const h8 hi, const h8 lo) {
+    img[(size_t)(2 * S) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+    img[(size_t)(2 * S + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+// A wave's share of a stage is 3 MFMAs per k16-step: far too little to hide an L2 round trip per step, so ALL weight planes
+// of a stage are requested up front (before the barrier that publishes the operands: the fetch overlaps the other waves'
+// transforms) and the chain then runs out of registers.  KSM = compile-time bound of the step count.
+template <int KSM>
+__device__ __forceinline__ void coop_load_w(HFrag<1> (&wf)[KSM], const uint4* __restrict__ wp, int KS) {
+#pragma unroll
+    for (int S = 0; S < KSM; ++S)
+        if (S < KS) load_hfrag<1>(wf[S], wp + (size_t)S * 128, 0);
+}
+template <int KSM>
+__device__ __forceinline__ void coop_mma(f32x16 (&acc)[1], const uint4* __restrict__ img, const HFrag<1> (&wf)[KSM], int KS, int lane) {
+#pragma unroll
+    for (int S = 0; S < KSM; ++S)
+        if (S < KS) {
+            const h8 bhi = __builtin_bit_cast(h8, img[(size_t)(2 * S) * 64 + lane]), blo = __builtin_bit_cast(h8, img[(size_t)(2 * S + 1) * 64 + lane]);
+            mfma_step_h<1>(acc, wf[S], bhi, blo);
+        }
+}
+// (mean, M2) of a row over N = 32 * NT features from the per-slice (mean, M2) in `st` (Chan, equal counts)
+template <int NT>
+__device__ __forceinline__ void coop_merge_stats(const float2* __restrict__ st /* [NT][32] of this tile slot */, int j, float& mean, float& m2) {
+    float2 p[NT];
+    float ms = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) { p[w] = st[w * 32 + j]; ms += p[w].x; }
+    mean = ms * (1.0f / NT);
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) { const float d = p[w].x - mean; q += p[w].y + 32.0f * d * d; }
+    m2 = q;
+}
+
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
+    constexpr int NG = N / 8, NT = N / 32, TPW = 4 / NT, KS = NG / 2;
+    constexpr int kSlotU4 = kCoopLdsU4 / TPW;
+    __shared__ uint4 img[kCoopLdsU4];
+    __shared__ float2 stats[4 * 32];
+    const BlockArgs& a = ah.b;
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = wave / NT, w = wave % NT;
+    const int tile_raw = blockIdx.x * TPW + slot;
+    const bool live = tile_raw < a.ntiles;            // idle slots of the last workgroup still meet the barriers
+    const int tile = live ? tile_raw : a.ntiles - 1;
+    const int ptile = tile % a.tiles_per_pass;
+    uint4* const Bimg = img + slot * kSlotU4;
+    uint4* const Rimg = Bimg + kSlotU4 / 2;
+    float2* const st = stats + slot * NT * 32;
+    const int ks0 = (a.in0.groups + 1) >> 1, ks1 = (a.in1.groups + 1) >> 1, KS1 = ks0 + ks1;
+
+    // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as k_resblock_h
+    float mean1, rstd1;
+    {
+        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
+        float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
+        if (a.in1.groups) {
+            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
+            const float n1 = (float)a.in1.width, nt_ = n + n1;
+            const float dd = s1.x - mean;
+            m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
+            mean = mean + dd * (n1 / nt_);
+            n = nt_;
+        }
+        mean1 = mean;
+        rstd1 = rsqrtf(m2 / n + kLnEps);
+    }
+    const int e1 = scale_exp(*ah.m1), e2 = scale_exp(*ah.m2);
+    const int e3 = SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3);
+    const float inv1 = ldexpf(1.0f / kActScale, -e1), inv2 = ldexpf(1.0f / kActScale, -e2), inv3 = ldexpf(1.0f / kActScale, -e3);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- stage 1 operands: this wave transforms k16-steps w, w + NT, ... of the (concatenated) input
+    constexpr int KS1M = SCLIN ? NG : NG / 2;           // concat input of an up block: 2N wide
+    HFrag<1> wf1[KS1M];
+    coop_load_w<KS1M>(wf1, ah.W1h + (size_t)w * KS1 * 128 + lane, KS1);
+    {
+        const float c = rstd1, d = -mean1 * rstd1;
+        constexpr int MY = KS1M / NT;                   // k16-steps per wave (upper bound)
+        float4 x0[MY], x1[MY], g0[MY], b0[MY], g1[MY], b1[MY];
+#pragma unroll
+        for (int i = 0; i < MY; ++i) {                  // every load of the stage first
+            const int S = w + i * NT;
+            x0[i] = z4; x1[i] = z4; g0[i] = z4; b0[i] = z4; g1[i] = z4; b1[i] = z4;
+            if (S < KS1) {
+                const bool first = S < ks0;
+                const Seg& sg = first ? a.in0 : a.in1;
+                const int Sl = first ? S : S - ks0;
+                const float* xp = sg.data + (size_t)tile * sg.groups * 256 + lane * 4;
+                x0[i] = ld4(xp + (size_t)(2 * Sl) * 256);
+                if (2 * Sl + 1 < sg.groups) x1[i] = ld4(xp + (size_t)(2 * Sl + 1) * 256);
+                const int gbase = (first ? 0 : 8 * a.in0.groups) + 16 * Sl + 4 * h;
+                g0[i] = ld4(a.gamma1 + gbase); b0[i] = ld4(a.beta1 + gbase); g1[i] = ld4(a.gamma1 + gbase + 8); b1[i] = ld4(a.beta1 + gbase + 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MY; ++i) {
+            const int S = w + i * NT;
+            if (S < KS1) {
+                float v[8];
+                act8(v, x0[i], x1[i], c, d, g0[i], b0[i], g1[i], b1[i]);
+                h8 hi, lo;
+                split8(v, hi, lo);
+                coop_publish(Bimg, S, lane, hi, lo);
+                if (SCLIN) {
+                    const float r[8] = {kRawScale * x0[i].x, kRawScale * x0[i].y, kRawScale * x0[i].z, kRawScale * x0[i].w,
+                                        kRawScale * x1[i].x, kRawScale * x1[i].y, kRawScale * x1[i].z, kRawScale * x1[i].w};
+                    split8(r, hi, lo);
+                    coop_publish(Rimg, S, lane, hi, lo);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 1: this wave's 32 output features
+    f32x16 acc1[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+    coop_mma<KS1M>(acc1, Bimg, wf1, KS1, lane);
+    HFrag<1> wf2[KS];                                   // next stage's planes: requested now, used after two barriers
+    coop_load_w<KS>(wf2, ah.W2h + (size_t)w * KS * 128 + lane, KS);
+    {
+        int entry = 0;
+        if (a.ts) {
+            int row = ptile * 32 + j;
+            row = row < a.nrows ? row : a.nrows - 1;
+            entry = a.ts[row];
+        } else if (a.step_ptr) {
+            entry = *a.step_ptr;
+        }
+        acc_unscale_add<1>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride + 32 * w, h);
+    }
+    if (a.save_h1 && live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            st4(a.save_h1 + ((size_t)tile * NG + 4 * w + q) * 256 + lane * 4,
+                make_float4(acc1[0][4 * q], acc1[0][4 * q + 1], acc1[0][4 * q + 2], acc1[0][4 * q + 3]));
+    }
+    {
+        float m, q;
+        acc_stats<32, 1>(acc1, h, m, q);
+        if (h == 0) st[w * 32 + j] = make_float2(m, q);
+    }
+    __syncthreads();                 // statistics published; every wave is also done reading the stage-1 image
+
+    // ---- stage 2
+    f32x16 acc2[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[0][r] = 0.f;
+    {
+        float mean, m2;
+        coop_merge_stats<NT>(st, j, mean, m2);
+        const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+        const float c = rstd, d = -mean * rstd;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int S = 2 * w + half, r0 = 8 * half;
+            const float4 g0 = ld4(a.gamma2 + 16 * S + 4 * h), b0 = ld4(a.beta2 + 16 * S + 4 * h);
+            const float4 g1 = ld4(a.gamma2 + 16 * S + 8 + 4 * h), b1 = ld4(a.beta2 + 16 * S + 8 + 4 * h);
+            float v[8];
+            act8(v, make_float4(acc1[0][r0], acc1[0][r0 + 1], acc1[0][r0 + 2], acc1[0][r0 + 3]),
+                 make_float4(acc1[0][r0 + 4], acc1[0][r0 + 5], acc1[0][r0 + 6], acc1[0][r0 + 7]), c, d, g0, b0, g1, b1);
+            h8 hi, lo;
+            split8(v, hi, lo);
+            coop_publish(Bimg, S, lane, hi, lo);
+        }
+    }
+    __syncthreads();
+    coop_mma<KS>(acc2, Bimg, wf2, KS, lane);
+    HFrag<1> wf3[KS];
+    coop_load_w<KS>(wf3, ah.W3h + (size_t)w * KS * 128 + lane, KS);
+    HFrag<1> wfs[SCLIN ? KS1M : 1];
+    if (SCLIN) coop_load_w<(SCLIN ? KS1M : 1)>(wfs, ah.Wsch + (size_t)w * KS1 * 128 + lane, KS1);
+    acc_unscale_add<1>(acc2, inv2, a.c2 + 32 * w, h);
+    if (tile >= a.uncond_tiles) {
+        const float* cp = a.cond_pre + ((size_t)ptile * NG + 4 * w) * 256 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 cv = ld4(cp + (size_t)q * 256);
+            acc2[0][4 * q + 0] += cv.x; acc2[0][4 * q + 1] += cv.y; acc2[0][4 * q + 2] += cv.z; acc2[0][4 * q + 3] += cv.w;
+        }
+    }
+    if (a.save_h2 && live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            st4(a.save_h2 + ((size_t)tile * NG + 4 * w + q) * 256 + lane * 4,
+                make_float4(acc2[0][4 * q], acc2[0][4 * q + 1], acc2[0][4 * q + 2], acc2[0][4 * q + 3]));
+    }
+    {
+        float m, q;
+        acc_stats<32, 1>(acc2, h, m, q);
+        if (h == 0) st[w * 32 + j] = make_float2(m, q);
+    }
+    __syncthreads();
+
+    // ---- stage 3 (+ shortcut in the same scaled accumulator)
+    f32x16 (&acc3)[1] = acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc3[0][r] = 0.f;
+    {
+        float mean, m2;
+        coop_merge_stats<NT>(st, j, mean, m2);
+        const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+        const float c = rstd, d = -mean * rstd;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int S = 2 * w + half, r0 = 8 * half;
+            const float4 g0 = ld4(a.gamma3 + 16 * S + 4 * h), b0 = ld4(a.beta3 + 16 * S + 4 * h);
+            const float4 g1 = ld4(a.gamma3 + 16 * S + 8 + 4 * h), b1 = ld4(a.beta3 + 16 * S + 8 + 4 * h);
+            float v[8];
+            act8(v, make_float4(acc2[0][r0], acc2[0][r0 + 1], acc2[0][r0 + 2], acc2[0][r0 + 3]),
+                 make_float4(acc2[0][r0 + 4], acc2[0][r0 + 5], acc2[0][r0 + 6], acc2[0][r0 + 7]), c, d, g0, b0, g1, b1);
+            h8 hi, lo;
+            split8(v, hi, lo);
+            coop_publish(Bimg, S, lane, hi, lo);
+        }
+    }
+    __syncthreads();
+    coop_mma<KS>(acc3, Bimg, wf3, KS, lane);
+    if (SCLIN) {
+        coop_mma<(SCLIN ? KS1M : 1)>(acc3, Rimg, wfs, KS1, lane);
+        acc_unscale_add<1>(acc3, inv3, a.c3 + 32 * w, h);
+    } else {
+        acc_unscale_add<1>(acc3, inv3, a.c3 + 32 * w, h);
+        const float* xp = a.in0.data + ((size_t)tile * NG + 4 * w) * 256 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 xv = ld4(xp + (size_t)q * 256);
+            acc3[0][4 * q + 0] += xv.x; acc3[0][4 * q + 1] += xv.y; acc3[0][4 * q + 2] += xv.z; acc3[0][4 * q + 3] += xv.w;
+        }
+    }
+    // ---- output statistics (merged by the first wave of the tile) + store
+    {
+        float m, q;
+        acc_stats<32, 1>(acc3, h, m, q);
+        __syncthreads();             // the stage-3 statistics in `st` have been read by everyone
+        if (h == 0) st[w * 32 + j] = make_float2(m, q);
+    }
+    __syncthreads();
+    if (live) {
+        if (w == 0 && h == 0) {
+            float mean, m2;
+            coop_merge_stats<NT>(st, j, mean, m2);
+            reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            st4(a.out + ((size_t)tile * NG + 4 * w + q) * 256 + lane * 4,
+                make_float4(acc3[0][4 * q], acc3[0][4 * q + 1], acc3[0][4 * q + 2], acc3[0][4 * q + 3]));
+    }
+}
+
 // A wide block followed by the Linear that consumes it (Down/Upsample: raw; final: LayerNorm + SiLU, row-major out),
 // fused: the block's output stays in registers, which saves one launch, one store (unless it is a skip) and one reload.
 struct LinArgsH;
