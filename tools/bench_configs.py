@@ -23,12 +23,12 @@ for name, B, T, omega in (("msr3", 8192, 1000, 1.0), ("msr3", 512, 20, 500.0), (
     cond = torch.rand(B, cfg["cond_dim"], device=dev)
     d.sample(cond, omega, seed=1)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reps = 3 if T <= 20 else 1
-    for _ in range(reps):
+    dt = 1e9
+    for _ in range(3):                       # best of 3 calls
+        torch.cuda.synchronize(); t0 = time.perf_counter()
         y = d.sample(cond, omega, seed=2)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+        torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
     out.append(dict(config=name, B=B, T=T, omega=omega, ms_per_call=dt * 1e3, steps_per_s=T / dt, row_steps_per_s=B * T / dt,
                     finite=bool(torch.isfinite(y).all())))
     print(out[-1])
