@@ -689,7 +689,11 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
 void launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     const int ntiles = cdiv(c.nrows, 32) * c.npass;
     const dim3 grid(cdiv(ntiles, kWavesPerBlock)), block(256);
-    if (split_ctx(h, c)) hipLaunchKernelGGL(k_fused_narrow_h, grid, block, 0, s, h->fusedh_dev, h->fuse_hi - h->fuse_lo, ntiles);
+    if (split_ctx(h, c)) {
+        // small launches: the latency of one wave is the kernel time -> first-step weight planes requested a stage ahead
+        if (ntiles <= 2 * kCoopMaxTiles) hipLaunchKernelGGL(k_fused_narrow_h<true>, grid, block, 0, s, h->fusedh_dev, h->fuse_hi - h->fuse_lo, ntiles);
+        else hipLaunchKernelGGL(k_fused_narrow_h<false>, grid, block, 0, s, h->fusedh_dev, h->fuse_hi - h->fuse_lo, ntiles);
+    }
     else hipLaunchKernelGGL(k_fused_narrow, grid, block, 0, s, h->fused_dev, h->fuse_hi - h->fuse_lo, ntiles);
 }
 

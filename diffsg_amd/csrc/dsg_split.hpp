@@ -97,13 +97,14 @@ __device__ __forceinline__ void act8(float (&v)[8], const float4 x0, const float
 template <int N, int NT, int NTI = NT>
 __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16 (&in)[NTI], const uint4* __restrict__ wp,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float mean, float rstd,
-                                                 int lane, int h, size_t nt_stride_override = 0) {
+                                                 int lane, int h, size_t nt_stride_override = 0, const HFrag<NT>* w0 = nullptr) {
     constexpr int KS = ((N + 7) / 8 + 1) / 2;
     const size_t nt_stride = nt_stride_override ? nt_stride_override : (size_t)KS * 128;
     const float c = rstd, d = -mean * rstd;
     HFrag<NT> wn;
     float4 gn0, bn0, gn1, bn1;
-    load_hfrag<NT>(wn, wp + lane, nt_stride);
+    if (w0) wn = *w0;                 // the first step's planes were requested earlier (narrow run)
+    else load_hfrag<NT>(wn, wp + lane, nt_stride);
     gn0 = ld4(gamma + 4 * h); bn0 = ld4(beta + 4 * h); gn1 = ld4(gamma + 8 + 4 * h); bn1 = ld4(beta + 8 + 4 * h);
 #pragma unroll
     for (int S = 0; S < KS; ++S) {
@@ -129,13 +130,14 @@ __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16
 // lives in registers.  `groups` (runtime, <= 4*NT) real groups; the missing group of an odd count is accumulator padding.
 template <int NT, int NTI = NT>
 __device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f32x16 (&in)[NTI], int groups, const uint4* __restrict__ wp,
-                                                     size_t nt_stride, int lane) {
+                                                     size_t nt_stride, int lane, const HFrag<NT>* w0 = nullptr) {
     const int steps = (groups + 1) >> 1;
 #pragma unroll
     for (int S = 0; S < 2 * NTI; ++S) {
         if (S < steps) {
             HFrag<NT> w;
-            load_hfrag<NT>(w, wp + (size_t)S * 128 + lane, nt_stride);
+            if (S == 0 && w0) w = *w0;
+            else load_hfrag<NT>(w, wp + (size_t)S * 128 + lane, nt_stride);
             const int t = S >> 1, r0 = 8 * (S & 1);
             float v[8];
 #pragma unroll
@@ -152,14 +154,15 @@ __device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f3
 template <int NT, bool LNACT>
 __device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float* __restrict__ xp, int groups, const uint4* __restrict__ wp,
                                                  size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                 float mean, float rstd) {
+                                                 float mean, float rstd, const HFrag<NT>* w0 = nullptr) {
     const int steps = (groups + 1) >> 1;
     if (steps <= 0) return;
     const float c = rstd, d = -mean * rstd;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     HFrag<NT> wn;
     float4 xn0, xn1, gn0 = z4, bn0 = z4, gn1 = z4, bn1 = z4;
-    load_hfrag<NT>(wn, wp, nt_stride);
+    if (w0) wn = *w0;
+    else load_hfrag<NT>(wn, wp, nt_stride);
     xn0 = ld4(xp);
     xn1 = groups > 1 ? ld4(xp + 256) : z4;
     if (LNACT) { gn0 = ld4(gamma); bn0 = ld4(beta); gn1 = ld4(gamma + 8); bn1 = ld4(beta + 8); }
@@ -218,7 +221,7 @@ struct BlockArgsH {
 // and added here, never multiplied.
 // XIN: in0 is not read from memory but handed over in registers `xr` with its row statistics (narrow run).
 // XOUT: the output goes (back) into `xr`; it is stored only when `store_out` (something outside this wave reads it).
-template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN>
+template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN, bool PRE = false>
 __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane, f32x16 (*xr)[(N + 31) / 32] = nullptr,
                                                 float* xr_mean = nullptr, float* xr_m2 = nullptr, bool store_out = true) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
@@ -247,6 +250,21 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     const int e1 = scale_exp(*ah.m1), e2 = scale_exp(*ah.m2);
     const int e3 = SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3);
     const float inv1 = ldexpf(1.0f / kActScale, -e1), inv2 = ldexpf(1.0f / kActScale, -e2), inv3 = ldexpf(1.0f / kActScale, -e3);
+    // Narrow run, small launches (PRE): a stage is one or two k16-steps, so the first step of every chain is an exposed L2
+    // round trip unless its planes are requested before the previous stage's arithmetic: request all six of them now.  (Costs
+    // ~40 VGPRs: the large-launch form of the narrow kernel keeps four waves per SIMD instead.)
+    HFrag<NT> p1a, p1b, p2, p3, psa, psb;
+    if (PRE) {
+        const size_t s1 = (size_t)KS1 * 128, s2 = (size_t)(((N + 7) / 8 + 1) / 2) * 128;
+        load_hfrag<NT>(p1a, ah.W1h + lane, s1);
+        if (a.in1.groups) load_hfrag<NT>(p1b, ah.W1h + (size_t)ks0 * 128 + lane, s1);
+        load_hfrag<NT>(p2, ah.W2h + lane, s2);
+        load_hfrag<NT>(p3, ah.W3h + lane, s2);
+        if (SCLIN) {
+            load_hfrag<NT>(psa, ah.Wsch + lane, s1);
+            if (a.in1.groups) load_hfrag<NT>(psb, ah.Wsch + (size_t)ks0 * 128 + lane, s1);
+        }
+    }
 
     // ---- stage 1
     f32x16 acc1[NT];
@@ -257,14 +275,14 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     {
         const size_t nt_stride = (size_t)KS1 * 128;
         if (XIN)    // in0 has the block's own width N here (down / middle: in = N; up: cat(N, N))
-            chain_from_acc_h<N, NT>(acc1, *xr, ah.W1h, a.gamma1, a.beta1, mean1, rstd1, lane, h, nt_stride);
+            chain_from_acc_h<N, NT>(acc1, *xr, ah.W1h, a.gamma1, a.beta1, mean1, rstd1, lane, h, nt_stride, PRE ? &p1a : nullptr);
         else
             chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
                                        a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
         if (a.in1.groups)
             chain_from_mem_h<NT, true>(acc1, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                        ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, a.gamma1 + 8 * a.in0.groups + 4 * h,
-                                       a.beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1);
+                                       a.beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr);
         int entry = 0;
         if (a.ts) {
             int row = ptile * 32 + j;
@@ -293,7 +311,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         float mean, m2;
         acc_stats<N, NT>(acc1, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
-        chain_from_acc_h<N, NT>(acc2, acc1, ah.W2h, a.gamma2, a.beta2, mean, rstd, lane, h);
+        chain_from_acc_h<N, NT>(acc2, acc1, ah.W2h, a.gamma2, a.beta2, mean, rstd, lane, h, 0, PRE ? &p2 : nullptr);
         acc_unscale_add<NT>(acc2, inv2, a.c2, h);
     }
     if (tile >= a.uncond_tiles) {
@@ -323,18 +341,18 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         float mean, m2;
         acc_stats<N, NT>(acc2, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
-        chain_from_acc_h<N, NT>(acc3, acc2, ah.W3h, a.gamma3, a.beta3, mean, rstd, lane, h);
+        chain_from_acc_h<N, NT>(acc3, acc2, ah.W3h, a.gamma3, a.beta3, mean, rstd, lane, h, 0, PRE ? &p3 : nullptr);
     }
     if (SCLIN) {
         const size_t nt_stride = (size_t)KS1 * 128;
         if (XIN)
-            chain_raw_from_reg_h<NT>(acc3, *xr, a.in0.groups, ah.Wsch, nt_stride, lane);
+            chain_raw_from_reg_h<NT>(acc3, *xr, a.in0.groups, ah.Wsch, nt_stride, lane, PRE ? &psa : nullptr);
         else
             chain_from_mem_h<NT, false>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
                                         nullptr, nullptr, 0.f, 1.f);
         if (a.in1.groups)
             chain_from_mem_h<NT, false>(acc3, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
-                                        ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f);
+                                        ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f, PRE ? &psb : nullptr);
         acc_unscale_add<NT>(acc3, inv3, a.c3, h);
     } else {
         acc_unscale_add<NT>(acc3, inv3, a.c3, h);
@@ -894,7 +912,8 @@ __device__ __forceinline__ void linear_reg_h(const LinArgsH& ah, const int tile,
     }
 }
 
-__global__ __launch_bounds__(256, 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles) {
+template <bool PRE>
+__global__ __launch_bounds__(256, PRE ? 3 : 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles) {
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (tile >= ntiles) return;
@@ -922,17 +941,17 @@ __global__ __launch_bounds__(256, 4) void k_fused_narrow_h(const FusedOpH* __res
             const bool st = op.store_out != 0;
             if (op.sclin) {
                 switch (op.N) {
-                    case 4: resblock_body_h<4, true, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    case 8: resblock_body_h<8, true, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    case 16: resblock_body_h<16, true, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    default: resblock_body_h<32, true, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 4: resblock_body_h<4, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 8: resblock_body_h<8, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 16: resblock_body_h<16, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    default: resblock_body_h<32, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
                 }
             } else {
                 switch (op.N) {
-                    case 4: resblock_body_h<4, false, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    case 8: resblock_body_h<8, false, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    case 16: resblock_body_h<16, false, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    default: resblock_body_h<32, false, true>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 4: resblock_body_h<4, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 8: resblock_body_h<8, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 16: resblock_body_h<16, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    default: resblock_body_h<32, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
                 }
             }
         } else if (!have_x || op.l.l.in_groups > 4) {
