@@ -163,6 +163,8 @@ struct dsg_handle {
     FusedOp* fused_dev = nullptr;
     std::vector<FusedOp> fused_host;
     FusedOpH* fusedh_dev = nullptr;
+    FusedOpH* fusedh_train_dev = nullptr;   // the same run for the training forward (every output stored, h1/h2 saved)
+    const void* fusedh_train_key[4] = {nullptr, nullptr, nullptr, nullptr}; int fusedh_train_rows = 0;
     FusedOp* ce_dev = nullptr;          // condition-embedding Linear table (narrow blocks, one launch)
     std::vector<FusedOp> ce_host;
     CondTile* ctile_dev = nullptr; int ctile_n = 0; const float* ctile_key = nullptr; size_t ctile_cap = 0;
@@ -657,9 +659,18 @@ bool fusable(const dsg_handle* h, const Op& op) {
 // Upload the operator descriptors of the fused narrow run for this context (stream ordered; replayed graphs read them).
 int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
     const int n = h->fuse_hi - h->fuse_lo;
-    if (n < 2 || c.train) return 0;
-    HIPCK(hipStreamSynchronize(s));  // the host tables may still be the source of an earlier async copy
+    if (n < 2) return 0;
     const bool sp = split_ctx(h, c);
+    if (c.train) {
+        // training forward: split path only; the table depends on the workspaces and the batch, not on the step -> cached
+        if (!sp) return 0;
+        const void* key[4] = {h->ws, h->tr_ws, h->cembed, h->tb};
+        if (h->fusedh_train_dev && h->fusedh_train_rows == c.nrows && !memcmp(key, h->fusedh_train_key, sizeof key)) return 0;
+        if (!h->fusedh_train_dev) HIPCK(hipMalloc(&h->fusedh_train_dev, (h->ops.size() + 1) * sizeof(FusedOpH)));
+        memcpy(h->fusedh_train_key, key, sizeof key);
+        h->fusedh_train_rows = c.nrows;
+    }
+    HIPCK(hipStreamSynchronize(s));  // the host tables may still be the source of an earlier async copy
     if (sp) h->fusedh_host.resize(n); else h->fused_host.resize(n);
     for (int i = 0; i < n; ++i) {
         const Op& op = h->ops[h->fuse_lo + i];
@@ -673,7 +684,7 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
             FusedOpH& f = h->fusedh_host[i];
             memset(&f, 0, sizeof f);
             f.kind = kind; f.N = N; f.sclin = sclin;
-            f.store_out = (h->tensors[op.out].is_skip || i == n - 1) ? 1 : 0;
+            f.store_out = (c.train || h->tensors[op.out].is_skip || i == n - 1) ? 1 : 0;   // training: the backward reads every tensor
             if (kind == 0) fill_block_args_h(h, h->res[op.p], b, f.b); else fill_lin_args_h(h, h->lin[op.p], l, f.l);
         } else {
             FusedOp& f = h->fused_host[i];
@@ -681,7 +692,7 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
             f.kind = kind; f.N = N; f.sclin = sclin; f.b = b; f.l = l;
         }
     }
-    if (sp) HIPCK(hipMemcpyAsync(h->fusedh_dev, h->fusedh_host.data(), n * sizeof(FusedOpH), hipMemcpyHostToDevice, s));
+    if (sp) HIPCK(hipMemcpyAsync(c.train ? h->fusedh_train_dev : h->fusedh_dev, h->fusedh_host.data(), n * sizeof(FusedOpH), hipMemcpyHostToDevice, s));
     else HIPCK(hipMemcpyAsync(h->fused_dev, h->fused_host.data(), n * sizeof(FusedOp), hipMemcpyHostToDevice, s));
     return 0;
 }
@@ -691,8 +702,9 @@ void launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     const dim3 grid(cdiv(ntiles, kWavesPerBlock)), block(256);
     if (split_ctx(h, c)) {
         // small launches: the latency of one wave is the kernel time -> first-step weight planes requested a stage ahead
-        if (ntiles <= 2 * kCoopMaxTiles) hipLaunchKernelGGL(k_fused_narrow_h<true>, grid, block, 0, s, h->fusedh_dev, h->fuse_hi - h->fuse_lo, ntiles);
-        else hipLaunchKernelGGL(k_fused_narrow_h<false>, grid, block, 0, s, h->fusedh_dev, h->fuse_hi - h->fuse_lo, ntiles);
+        const FusedOpH* tab = c.train ? h->fusedh_train_dev : h->fusedh_dev;
+        if (ntiles <= 2 * kCoopMaxTiles) hipLaunchKernelGGL(k_fused_narrow_h<true>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
+        else hipLaunchKernelGGL(k_fused_narrow_h<false>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
     }
     else hipLaunchKernelGGL(k_fused_narrow, grid, block, 0, s, h->fused_dev, h->fuse_hi - h->fuse_lo, ntiles);
 }
@@ -715,7 +727,7 @@ bool try_pair(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
 }
 
 void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
-    const bool fuse = !c.train && h->fuse_hi - h->fuse_lo >= 2;
+    const bool fuse = (!c.train || split_ctx(h, c)) && h->fuse_hi - h->fuse_lo >= 2;
     for (int i = 0; i < (int)h->ops.size(); ++i) {
         if (fuse && i == h->fuse_lo) {
             launch_fused(h, c, s);
@@ -1160,7 +1172,7 @@ void dsg_destroy(dsg_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev, h->maxabs,
-                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->ce_dev, h->ctile_dev};
+                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev, h->fusedh_train_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->ce_dev, h->ctile_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1499,6 +1511,7 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     // the forward may run on the split-f16 kernels (they need the condition embeddings as an additive term)
     if (h->use_split) run_cond_embed(h, B, s);
     RunCtx c{B, 1, 0, h->tr_yt_rm, h->eps, nullptr, h->tr_ts, true, h->use_split};
+    if (prepare_fused(h, c, s)) return 1;
     run_unet(h, c, s);
     hipLaunchKernelGGL(k_loss_grad, dim3(kRedBlocks), dim3(256), 0, s, h->eps, noise, B, D, trp(h, h->tr_deps), tiles, h->red);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, s, h->red, kRedBlocks, (double)B * (double)D, loss_out);
