@@ -48,6 +48,8 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
  *   DSG_PRECISION_SPLIT_F16 (default)  float32-accurate GEMMs as hi/lo fp16 splits on the f16 matrix cores, f32 accumulate
  *                                      (22 significant bits per operand);
  *   DSG_PRECISION_F32_MFMA             exact float32 v_mfma_f32_32x32x2_f32 (also selected by env DSG_PRECISION=f32).
+ * Launches with at most 512 row tiles run the 64- and 128-wide blocks cooperatively (one tile per workgroup, N/32 waves);
+ * env DSG_NO_COOP=1 keeps the one-wave-per-tile kernels there (A/B measurements).
  * Training and dsg_unet_forward always use the exact float32 kernels. */
 #define DSG_PRECISION_SPLIT_F16 0
 #define DSG_PRECISION_F32_MFMA 1
