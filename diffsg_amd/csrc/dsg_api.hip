@@ -779,7 +779,9 @@ void run_cond_embed(dsg_handle* h, int B, hipStream_t s) {
             (void)hipMemcpy(h->ctile_dev, tab.data(), tab.size() * sizeof(CondTile), hipMemcpyHostToDevice);
             h->ctile_n = (int)tab.size(); h->ctile_key = h->cembed; h->ctile_cap = cap_tiles_of(h);
         }
-        hipLaunchKernelGGL(k_cond_embed_h, dim3(cdiv(tpp, kWavesPerBlock)), dim3(256), 0, s, h->condfrag, CG,
+        // enough waves for ~2 per SIMD: row tiles x parts
+        const int parts = tpp >= 2048 ? 1 : (tpp >= 1024 ? 2 : (tpp >= 512 ? 4 : 8));
+        hipLaunchKernelGGL(k_cond_embed_h, dim3(cdiv(tpp, kWavesPerBlock), parts), dim3(256), 0, s, h->condfrag, CG,
                            reinterpret_cast<const uint4*>(h->arena + h->res[0].Wch), h->ctile_dev, h->ctile_n, tpp);
         return;
     }

@@ -1032,6 +1032,9 @@ __global__ __launch_bounds__(256) void k_cond_embed_h(const float* __restrict__ 
             split8(v, bhi[S], blo[S]);
         }
     }
+    // gridDim.y waves share one row tile: each takes every gridDim.y-th output tile (the operand split above is repeated per
+    // wave: 10 k-groups, cheap), so that small launches still fill the SIMDs
+    const int part = blockIdx.y, nparts = gridDim.y;
     const size_t ot_stride = (size_t)KS * 128;
     uint4 wh[kCondMaxSteps], wl[kCondMaxSteps];
     auto loadw = [&](int ot) {
@@ -1039,8 +1042,8 @@ __global__ __launch_bounds__(256) void k_cond_embed_h(const float* __restrict__ 
         for (int S = 0; S < kCondMaxSteps; ++S)
             if (S < KS) { wh[S] = W[ot * ot_stride + (size_t)S * 128 + lane]; wl[S] = W[ot * ot_stride + (size_t)S * 128 + 64 + lane]; }
     };
-    loadw(0);
-    for (int ot = 0; ot < nout; ++ot) {
+    if (part < nout) loadw(part);
+    for (int ot = part; ot < nout; ot += nparts) {
         const CondTile ct = tiles_tab[ot];
         f32x16 acc;
 #pragma unroll
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_cond_embed_h(const float* __restrict__ 
                 DSG_MFMA_H(acc, whi, blo[S]);
                 DSG_MFMA_H(acc, wlo, bhi[S]);
             }
-        if (ot + 1 < nout) loadw(ot + 1);     // next tile's planes land under this tile's MFMAs and stores
+        if (ot + nparts < nout) loadw(ot + nparts);     // next tile's planes land under this tile's MFMAs and stores
         const float inv = ldexpf(1.0f / kActScale, -scale_exp(*ct.m));
         float* o = ct.out + (size_t)tile * ct.ng_block * 256 + lane * 4;
 #pragma unroll
