@@ -56,13 +56,20 @@ class DDPMCore(nn.Module):
     def _coef_table(self):
         """[T][4] float32 on the model's device: the per-step scalars of MSR.py:133-134, evaluated with the same
         float32 tensor ops on the registered buffers, plus the `i > 1` noise switch (MSR.py:129)."""
+        key = tuple((b.data_ptr(), b._version) for b in (self.betas, self.sqrt_one_minus_alphas_cumprod, self.reciprocal_sqrt_alphas,
+                                                         self.alphas_cumprod))
+        cached = getattr(self, "_coef_cache", None)
+        if cached is not None and cached[0] == key:      # a dozen tiny kernels per call otherwise: the buffers rarely change
+            return cached[1]
         i = torch.arange(self.T, device=self.betas.device)
         prev = torch.clamp(i - 1, min=0)
         c1 = self.betas / self.sqrt_one_minus_alphas_cumprod
         c2 = self.reciprocal_sqrt_alphas
         c3 = (1.0 - self.alphas_cumprod[prev]) / (1.0 - self.alphas_cumprod)
         c4 = (i > 1).to(torch.float32)
-        return torch.stack((c1, c2, c3, c4), dim=1).contiguous()
+        tab = torch.stack((c1, c2, c3, c4), dim=1).contiguous()
+        self._coef_cache = (key, tab)
+        return tab
 
     @torch.no_grad()
     def sample(self, cond, omega=1.0, *, y_T=None, noise=None, seed=None, host_rng=False, use_graph=True,
