@@ -563,7 +563,12 @@ void launch_res_h_n(bool sclin, const BlockArgsH& a, hipStream_t s) {
 }
 // launches with fewer row tiles than this leave SIMDs idle with one wave per tile: the wide blocks then run cooperatively
 // (N/32 waves per tile, k_resblock_c)
-constexpr int kCoopMaxTiles = 512;
+constexpr int kCoopMaxTilesDefault = 512;
+int coop_max_tiles() {
+    static const int v = [] { const char* e = getenv("DSG_COOP_MAX"); return e ? atoi(e) : kCoopMaxTilesDefault; }();
+    return v;
+}
+#define kCoopMaxTiles coop_max_tiles()
 
 void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStream_t s) {
     BlockArgsH a;

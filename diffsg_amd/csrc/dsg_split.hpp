@@ -419,17 +419,17 @@ __device__ __forceinline__ void coop_publish(uint4* __restrict__ img, int S, int
 // of a stage are requested up front (before the barrier that publishes the operands: the fetch overlaps the other waves'
 // transforms) and the chain then runs out of registers.  KSM = compile-time bound of the step count.
 template <int KSM>
-__device__ __forceinline__ void coop_load_w(HFrag<1> (&wf)[KSM], const uint4* __restrict__ wp, int KS) {
+__device__ __forceinline__ void coop_load_w(HFrag<1> (&wf)[KSM], const uint4* __restrict__ wp, int KS, int S0 = 0) {
 #pragma unroll
     for (int S = 0; S < KSM; ++S)
-        if (S < KS) load_hfrag<1>(wf[S], wp + (size_t)S * 128, 0);
+        if (S0 + S < KS) load_hfrag<1>(wf[S], wp + (size_t)(S0 + S) * 128, 0);
 }
 template <int KSM>
-__device__ __forceinline__ void coop_mma(f32x16 (&acc)[1], const uint4* __restrict__ img, const HFrag<1> (&wf)[KSM], int KS, int lane) {
+__device__ __forceinline__ void coop_mma(f32x16 (&acc)[1], const uint4* __restrict__ img, const HFrag<1> (&wf)[KSM], int KS, int lane, int S0 = 0) {
 #pragma unroll
     for (int S = 0; S < KSM; ++S)
-        if (S < KS) {
-            const h8 bhi = __builtin_bit_cast(h8, img[(size_t)(2 * S) * 64 + lane]), blo = __builtin_bit_cast(h8, img[(size_t)(2 * S + 1) * 64 + lane]);
+        if (S0 + S < KS) {
+            const h8 bhi = __builtin_bit_cast(h8, img[(size_t)(2 * (S0 + S)) * 64 + lane]), blo = __builtin_bit_cast(h8, img[(size_t)(2 * (S0 + S) + 1) * 64 + lane]);
             mfma_step_h<1>(acc, wf[S], bhi, blo);
         }
 }
@@ -489,8 +489,9 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
 
     // ---- stage 1 operands: this wave transforms k16-steps w, w + NT, ... of the (concatenated) input
     constexpr int KS1M = SCLIN ? NG : NG / 2;           // concat input of an up block: 2N wide
-    HFrag<1> wf1[KS1M];
-    coop_load_w<KS1M>(wf1, ah.W1h + (size_t)w * KS1 * 128 + lane, KS1);
+    constexpr int KSB = KS1M < 8 ? KS1M : 8;            // planes in flight per batch (8 steps = 64 VGPRs)
+    HFrag<1> wf1[KSB];
+    coop_load_w<KSB>(wf1, ah.W1h + (size_t)w * KS1 * 128 + lane, KS1);
     {
         const float c = rstd1, d = -mean1 * rstd1;
         constexpr int MY = KS1M / NT;                   // k16-steps per wave (upper bound)
@@ -534,7 +535,11 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
     f32x16 acc1[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-    coop_mma<KS1M>(acc1, Bimg, wf1, KS1, lane);
+    coop_mma<KSB>(acc1, Bimg, wf1, KS1, lane);
+    if (KS1M > KSB) {                                   // second batch of a 2N-wide input
+        coop_load_w<KSB>(wf1, ah.W1h + (size_t)w * KS1 * 128 + lane, KS1, KSB);
+        coop_mma<KSB>(acc1, Bimg, wf1, KS1, lane, KSB);
+    }
     HFrag<1> wf2[KS];                                   // next stage's planes: requested now, used after two barriers
     coop_load_w<KS>(wf2, ah.W2h + (size_t)w * KS * 128 + lane, KS);
     {
@@ -587,8 +592,8 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
     coop_mma<KS>(acc2, Bimg, wf2, KS, lane);
     HFrag<1> wf3[KS];
     coop_load_w<KS>(wf3, ah.W3h + (size_t)w * KS * 128 + lane, KS);
-    HFrag<1> wfs[SCLIN ? KS1M : 1];
-    if (SCLIN) coop_load_w<(SCLIN ? KS1M : 1)>(wfs, ah.Wsch + (size_t)w * KS1 * 128 + lane, KS1);
+    HFrag<1> wfs[SCLIN ? KSB : 1];
+    if (SCLIN) coop_load_w<(SCLIN ? KSB : 1)>(wfs, ah.Wsch + (size_t)w * KS1 * 128 + lane, KS1);
     acc_unscale_add<1>(acc2, inv2, a.c2 + 32 * w, h);
     if (tile >= a.uncond_tiles) {
         const float* cp = a.cond_pre + ((size_t)ptile * NG + 4 * w) * 256 + lane * 4;
@@ -636,7 +641,11 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
     __syncthreads();
     coop_mma<KS>(acc3, Bimg, wf3, KS, lane);
     if (SCLIN) {
-        coop_mma<(SCLIN ? KS1M : 1)>(acc3, Rimg, wfs, KS1, lane);
+        coop_mma<(SCLIN ? KSB : 1)>(acc3, Rimg, wfs, KS1, lane);
+        if (KS1M > KSB) {
+            coop_load_w<(SCLIN ? KSB : 1)>(wfs, ah.Wsch + (size_t)w * KS1 * 128 + lane, KS1, KSB);
+            coop_mma<(SCLIN ? KSB : 1)>(acc3, Rimg, wfs, KS1, lane, KSB);
+        }
         acc_unscale_add<1>(acc3, inv3, a.c3 + 32 * w, h);
     } else {
         acc_unscale_add<1>(acc3, inv3, a.c3 + 32 * w, h);

@@ -49,7 +49,7 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
  *                                      (22 significant bits per operand);
  *   DSG_PRECISION_F32_MFMA             exact float32 v_mfma_f32_32x32x2_f32 (also selected by env DSG_PRECISION=f32).
  * Launches with at most 512 row tiles run the 64- and 128-wide blocks cooperatively (one tile per workgroup, N/32 waves);
- * env DSG_NO_COOP=1 keeps the one-wave-per-tile kernels there (A/B measurements).
+ * env DSG_NO_COOP=1 keeps the one-wave-per-tile kernels there, DSG_COOP_MAX=<tiles> moves the threshold (A/B measurements).
  * Training and dsg_unet_forward always use the exact float32 kernels. */
 #define DSG_PRECISION_SPLIT_F16 0
 #define DSG_PRECISION_F32_MFMA 1
