@@ -573,7 +573,9 @@ int coop_max_tiles() {
 void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStream_t s) {
     BlockArgsH a;
     fill_block_args_h(h, r, b, a);
-    if ((r.N == 64 || r.N == 128) && a.b.ntiles <= kCoopMaxTiles && !getenv("DSG_NO_COOP")) {
+    const int ks1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2;
+    const bool coop_fits = ks1 * 128 <= kCoopLdsU4 / (4 / (r.N / 32 > 0 ? r.N / 32 : 1)) / 2 && ks1 <= (r.sclin ? r.N / 8 : r.N / 16);   // LDS images, register bound
+    if ((r.N == 64 || r.N == 128) && coop_fits && a.b.ntiles <= kCoopMaxTiles && !getenv("DSG_NO_COOP")) {
         const int tpw = 4 / (r.N / 32);
         const dim3 grid(cdiv(a.b.ntiles, tpw)), block(256);
         if (r.N == 128) {
