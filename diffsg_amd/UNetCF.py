@@ -239,6 +239,8 @@ class UNet1D(nn.Module):
         if x.shape[1] != self.cfg["input_dim"] or cond.shape[1] != self.cfg["cond_dim"]:
             raise ValueError("x / cond feature size does not match the model")
         out = torch.empty_like(x)
+        if B == 0:
+            return out                     # no rows, nothing to launch (the reference returns an empty tensor too)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().dsg_unet_forward(hd, _lib.ptr(x), _lib.ptr(tv), _lib.ptr(cond), _lib.ptr(mk),
                                                    _lib.ptr(out), B, _lib.stream_ptr()))

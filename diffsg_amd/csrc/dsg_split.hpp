@@ -219,12 +219,23 @@ struct BlockArgsH {
 // and added here, never multiplied.
 // XIN: in0 is not read from memory but handed over in registers `xr` with its row statistics (narrow run).
 // XOUT: the output goes (back) into `xr`; it is stored only when `store_out` (something outside this wave reads it).
-template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN, bool PRE = false>
+constexpr int kLnLdsW1 = 272, kLnLdsN = 128;   // LDS copy of the LayerNorm vectors: stage-1 width (<= 256 + pad), block width
+
+template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN, bool PRE = false, bool LDSLN = false>
 __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane, f32x16 (*xr)[(N + 31) / 32] = nullptr,
-                                                float* xr_mean = nullptr, float* xr_m2 = nullptr, bool store_out = true) {
+                                                float* xr_mean = nullptr, float* xr_m2 = nullptr, bool store_out = true,
+                                                const float* lnp = nullptr) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
     const BlockArgs& a = ah.b;
     const int h = lane >> 5, j = lane & 31;
+    // LayerNorm affine vectors: global, or the block's LDS copy (stage_ln_params) - a third of the wide kernels' vector
+    // memory instructions are these broadcast reads
+    const float* const gamma1 = LDSLN ? lnp : a.gamma1;
+    const float* const beta1 = LDSLN ? lnp + kLnLdsW1 : a.beta1;
+    const float* const gamma2 = LDSLN ? lnp + 2 * kLnLdsW1 : a.gamma2;
+    const float* const beta2 = LDSLN ? lnp + 2 * kLnLdsW1 + kLnLdsN : a.beta2;
+    const float* const gamma3 = LDSLN ? lnp + 2 * kLnLdsW1 + 2 * kLnLdsN : a.gamma3;
+    const float* const beta3 = LDSLN ? lnp + 2 * kLnLdsW1 + 3 * kLnLdsN : a.beta3;
     const int ptile = tile % a.tiles_per_pass;
     const int ks0 = (a.in0.groups + 1) >> 1, ks1 = (a.in1.groups + 1) >> 1, KS1 = ks0 + ks1;
 
@@ -273,14 +284,14 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     {
         const size_t nt_stride = (size_t)KS1 * 128;
         if (XIN)    // in0 has the block's own width N here (down / middle: in = N; up: cat(N, N))
-            chain_from_acc_h<N, NT>(acc1, *xr, ah.W1h, a.gamma1, a.beta1, mean1, rstd1, lane, h, nt_stride, PRE ? &p1a : nullptr);
+            chain_from_acc_h<N, NT>(acc1, *xr, ah.W1h, gamma1, beta1, mean1, rstd1, lane, h, nt_stride, PRE ? &p1a : nullptr);
         else
             chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
-                                       a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
+                                       gamma1 + 4 * h, beta1 + 4 * h, mean1, rstd1);
         if (a.in1.groups)
             chain_from_mem_h<NT, true>(acc1, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
-                                       ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, a.gamma1 + 8 * a.in0.groups + 4 * h,
-                                       a.beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr);
+                                       ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, gamma1 + 8 * a.in0.groups + 4 * h,
+                                       beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr);
         int entry = 0;
         if (a.ts) {
             int row = ptile * 32 + j;
@@ -309,7 +320,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         float mean, m2;
         acc_stats<N, NT>(acc1, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
-        chain_from_acc_h<N, NT>(acc2, acc1, ah.W2h, a.gamma2, a.beta2, mean, rstd, lane, h, 0, PRE ? &p2 : nullptr);
+        chain_from_acc_h<N, NT>(acc2, acc1, ah.W2h, gamma2, beta2, mean, rstd, lane, h, 0, PRE ? &p2 : nullptr);
         acc_unscale_add<NT>(acc2, inv2, a.c2, h);
     }
     if (tile >= a.uncond_tiles) {
@@ -339,7 +350,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         float mean, m2;
         acc_stats<N, NT>(acc2, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
-        chain_from_acc_h<N, NT>(acc3, acc2, ah.W3h, a.gamma3, a.beta3, mean, rstd, lane, h, 0, PRE ? &p3 : nullptr);
+        chain_from_acc_h<N, NT>(acc3, acc2, ah.W3h, gamma3, beta3, mean, rstd, lane, h, 0, PRE ? &p3 : nullptr);
     }
     if (SCLIN) {
         const size_t nt_stride = (size_t)KS1 * 128;
@@ -388,12 +399,26 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     }
 }
 
+// Copy the block's three (gamma, beta) pairs into LDS: [gamma1 | beta1] kLnLdsW1 floats each, then [gamma2 | beta2 |
+// gamma3 | beta3] kLnLdsN each.  n1 = the floats stage 1 can touch (8 * groups of in0 + 16 * steps of in1).
+__device__ __forceinline__ void stage_ln_params(float* __restrict__ lds, const BlockArgs& a, int N) {
+    const int n1 = 8 * a.in0.groups + 16 * ((a.in1.groups + 1) >> 1), n2 = 16 * (((N + 7) / 8 + 1) / 2);
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) { lds[i] = a.gamma1[i]; lds[kLnLdsW1 + i] = a.beta1[i]; }
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        float* q = lds + 2 * kLnLdsW1;
+        q[i] = a.gamma2[i]; q[kLnLdsN + i] = a.beta2[i]; q[2 * kLnLdsN + i] = a.gamma3[i]; q[3 * kLnLdsN + i] = a.beta3[i];
+    }
+    __syncthreads();
+}
+
 template <int N, bool SCLIN>
 __global__ __launch_bounds__(256, 2) void k_resblock_h(const BlockArgsH ah) {
+    __shared__ float lnp[2 * kLnLdsW1 + 4 * kLnLdsN];
+    stage_ln_params(lnp, ah.b, N);
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= ah.b.ntiles) return;
-    resblock_body_h<N, SCLIN>(ah, tile, lane);
+    resblock_body_h<N, SCLIN, false, false, false, true>(ah, tile, lane, nullptr, nullptr, nullptr, true, lnp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -757,12 +782,14 @@ struct BlockLinArgsH { BlockArgsH b; LinArgsH l; int store_block_out; };
 template <int N, bool SCLIN, int NTO, bool FINAL>
 __global__ __launch_bounds__(256, 2) void k_resblock_lin_h(const BlockLinArgsH a) {
     constexpr int NT = (N + 31) / 32;
+    __shared__ float lnp[2 * kLnLdsW1 + 4 * kLnLdsN];
+    stage_ln_params(lnp, a.b.b, N);
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (tile >= a.b.b.ntiles) return;
     f32x16 x[NT];
     float xmean = 0.f, xm2 = 0.f;
-    resblock_body_h<N, SCLIN, false, true>(a.b, tile, lane, &x, &xmean, &xm2, a.store_block_out != 0);
+    resblock_body_h<N, SCLIN, false, true, false, true>(a.b, tile, lane, &x, &xmean, &xm2, a.store_block_out != 0, lnp);
     linear_epilogue_h<NTO, NT, FINAL>(a.l, tile, lane, x, xmean, xm2);
 }
 

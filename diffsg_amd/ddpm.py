@@ -104,6 +104,8 @@ class DDPMCore(nn.Module):
         coef = self._coef_table()
         out = torch.empty(B, D, device=dev, dtype=torch.float32)
         rec = torch.empty(2, T, B, D, device=dev, dtype=torch.float32) if self.record_denoise_path else None
+        if B == 0:
+            return out                     # no rows, nothing to launch (the reference's loop runs on empty tensors)
         flags = 2 if profile else (0 if use_graph else 1)
         # T <= 2 has no noisy step (MSR.py:129): a null pointer (= device Philox) is then never dereferenced
         zptr = _lib.ptr(noise) if (noise is not None and noise.numel()) else _lib.ptr(None)

@@ -75,6 +75,17 @@ def _z(g, T):
     return torch.from_numpy(g["z"]) if T > 2 else None
 
 
+def test_empty_batch_gives_empty_results():
+    """Zero rows: the reference's torch ops return empty tensors; here nothing is launched."""
+    plan, p = synth_params("msr3", 1)
+    ddpm = make_ddpm("msr3", p, 5)
+    e = lambda w: torch.empty(0, w, device="cuda")
+    assert tuple(ddpm.model(e(3), torch.empty(1, 0, device="cuda"), e(3), e(1)).shape) == (0, 3)
+    assert tuple(ddpm.sample(e(3), 1.0).shape) == (0, 3)
+    with pytest.raises(RuntimeError):          # a mean over zero rows has no value: the C-ABI refuses B < 1
+        ddpm(e(3), e(3))
+
+
 @pytest.mark.parametrize("name,T", [("tiny", 8), ("msr80", 6), ("msr3", 6), ("co3", 6), ("tiny", 3)])
 @pytest.mark.parametrize("graph", [True, False])
 def test_sample_vs_golden_synth(gold, name, T, graph):
