@@ -1,6 +1,7 @@
 """Classifier-free-guidance DDPM for Computation Offloading (reference: ddpm_opt/classifier_free_CO.py).
 
-Entry points kept: `DDPM`, `co_data_load`, `train_ddpm_co`, `cost_calc`, `customized_real_decoder`, `load_test_co`;
+Entry points kept: `DDPM`, `co_data_load`, `train_ddpm_co`, `cost_calc`, `customized_real_decoder`, `load_test_co`, and
+the self-check harness `validation_data_gen` / `validate_ddpm_co` / `test_ddpm`;
 constants of the reference as defaults (UNet1D(proj 64, dims (64,32,16,8), n_blocks 3), lr 5e-3,
 MultiStepLR [15,80,150], omega 500).
 """
@@ -144,3 +145,71 @@ def load_test_co(ckpt_path, dataset_path=DEFAULT_DATASET, T=20, omega=500.0, bat
     log(f"terrible samples num: {out['terrible']}/{out['n']}.")
     log(f"accuracy: {out['accuracy']}/{out['n']}")
     return out
+
+
+# ------------------------------------------------------------------ self-check harness (classifier_free_CO.py:416-558)
+def validation_data_gen():
+    """classifier_free_CO.py:416-449: 3 x 1000 rows whose label is the one-hot index of the node block that got +1; same
+    numpy draws in the same order (random((1000, 3)), then permutation(3000)), 70/30 split."""
+    X_base = np.random.random((1000, 3))
+    blocks = []
+    for k in range(3):
+        X = np.concatenate([X_base + 1 if i == k else X_base for i in range(3)], axis=1)
+        Y = np.zeros((1000, 3))
+        Y[:, k] = 1
+        blocks.append(np.concatenate((Y, X), axis=1))
+    src = np.concatenate(blocks, axis=0)
+    src = src[np.random.permutation(src.shape[0])]
+    X, Y = src[:, 3:], src[:, :3]
+    n_tr, n_te = int(src.shape[0] * 0.7), int(src.shape[0] * 0.3)
+    return X[:n_tr], Y[:n_tr], X[-n_te:], Y[-n_te:], {'sfn': 3, 'cfn': 0}
+
+
+def _validation_model(node_num, cond_dim, device, T, custom_config, uncond_prob):
+    """UNet1D(proj 64, dims (32,16,8), n_blocks 2) of classifier_free_CO.py:468-476 / :521-528."""
+    alphas = 1.0 - generate_cosine_schedule(T)
+    model = UNet1D(input_dim=node_num, proj_dim=64, cond_dim=cond_dim, dims=(32, 16, 8), is_attn=(False, False, False),
+                   middle_attn=False, n_blocks=2)
+    return DDPM(T, model, node_num, alphas, device, (1, 3), custom_config, uncond_prob, 0.9999, 10, 5, False)
+
+
+def validate_ddpm_co(epochs=500, T=500, use_ema=False, warmup_epoch=5, batch_size=512, lr=0.005,
+                     milestones=(30, 150, 350), data_split=None, log=print):
+    """classifier_free_CO.py:451-502: train on the validation set (uncond_prob 0.0, MultiStepLR [30,150,350])."""
+    X_train, Y_train, _, _, custom_config = data_split if data_split is not None else validation_data_gen()
+    dataset = data.TensorDataset(torch.tensor(X_train, dtype=torch.float32), torch.tensor(Y_train, dtype=torch.float32))
+    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True)
+    node_num = Y_train.shape[1]
+    device = _device()
+    diffusion_model = _validation_model(node_num, custom_config['sfn'] * node_num, device, T, custom_config, 0.0)
+    diffusion_model.apply(init_weights)
+    diffusion_model.to(device)
+    from .train import FlatAdam, run_epochs
+    optimizer = FlatAdam(diffusion_model, lr=lr)
+    scheduler = optim.lr_scheduler.MultiStepLR(optimizer, list(milestones))
+    run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log)
+    return diffusion_model
+
+
+@torch.no_grad()
+def test_ddpm(ckpt_path=None, T=500, omega=30.0, batch_size=512, diffusion_model=None, data_split=None, log=print):
+    """classifier_free_CO.py:504-558: sample the validation test split, softmax, threshold 0.1, compare the decision
+    pattern (as a binary number over the nodes) with the label's; returns and prints `accuracy: k/n`."""
+    _, Y_train, X_test, Y_test, custom_config = data_split if data_split is not None else validation_data_gen()
+    node_num = Y_train.shape[1]
+    device = _device()
+    if diffusion_model is None:
+        diffusion_model = _validation_model(node_num, custom_config['sfn'] * node_num, device, T, custom_config, 0.1)
+        diffusion_model.load_state_dict(torch.load(ckpt_path, map_location="cpu"))
+    diffusion_model.to(device)
+    X = torch.tensor(X_test, dtype=torch.float32)
+    Y_pred = torch.cat([diffusion_model.sample(X[i:i + batch_size].to(device), omega) for i in range(0, len(X), batch_size)])
+    from .decode import row_softmax
+    Y_pred = row_softmax(Y_pred)
+    Yt = torch.tensor(Y_test, dtype=torch.float32, device=device)
+    weights = 2 ** torch.arange(node_num - 1, -1, -1, device=device)
+    pred_cls = ((Y_pred > 0.1).long() * weights).sum(dim=1)
+    true_cls = ((Yt > 0.1).long() * weights).sum(dim=1)
+    hits = int((pred_cls == true_cls).sum())
+    log(f"accuracy: {hits}/{X.shape[0]}")
+    return {"accuracy": hits, "n": int(X.shape[0]), "Y_pred": Y_pred}

@@ -125,3 +125,10 @@ def load_test_nu(ckpt_path, dataset_path=DEFAULT_DATASET, T=20, omega=500, batch
     log(f"less ratio: {out['less_ratio']}")
     log(f"avg rate diff:\n {out['avg_rate_diff']}")
     return out
+
+
+def load_test_nu_debug(*args, **kw):
+    """classifier_free_NU.py:365-394: record the de-noising trajectory of the test split and write
+    `../results/nu_denoise_path.csv` (see trajectory.nu_trajectory_gen_store)."""
+    from .trajectory import nu_trajectory_gen_store
+    return nu_trajectory_gen_store(*args, **kw)

@@ -10,7 +10,7 @@ committed.  Nothing here is imported by tests at run time except weights.py.
 Groups follow SURVEY.md section 8(c): G1 schedule, G2 denoiser forward (+ per
 module taps), G3 DDPM.forward loss/grads, G4 DDPM.sample trajectories (NU
 checkpoint + synthetic), G5 decoders/evaluators, G6 loaders on CSV slices,
-G7 state-dict layout + EMA, G8 the MSR label generator.
+G7 state-dict layout + EMA, G8 the MSR label generator, G9 the CO self-check harness.
 """
 import json
 import os
@@ -376,7 +376,29 @@ def g8():
     save("g8_sum_rate_gen.npz", **out)
 
 
+def g9():
+    """classifier_free_CO.py:416-449 validation_data_gen (numpy draw order, split), and the decision-pattern accuracy rule
+    of test_ddpm (:542-552) evaluated on fixed raw samples."""
+    np.random.seed(321)
+    Xtr, Ytr, Xte, Yte, cfg = RCO.validation_data_gen()
+    out = dict(Xtr_head=Xtr[:16], Ytr_head=Ytr[:16], Xte_tail=Xte[-16:], Yte_tail=Yte[-16:],
+               shapes=np.array([Xtr.shape, Ytr.shape, Xte.shape, Yte.shape]), sums=np.array([Xtr.sum(), Ytr.sum(), Xte.sum(), Yte.sum()]),
+               sfn=np.array(cfg['sfn']), cfn=np.array(cfg['cfn']))
+    g = torch.Generator().manual_seed(5)
+    raw = torch.randn(200, 3, generator=g) * 3.0
+    lab = torch.zeros(200, 3)
+    lab[torch.arange(200), torch.randint(0, 3, (200,), generator=g)] = 1
+    Y_pred = torch.softmax(raw, dim=1)
+    pd_, td_ = torch.where(Y_pred > 0.1, 1, 0), torch.where(lab > 0.1, 1, 0)
+    pc, tc = np.zeros(200, dtype=int), np.zeros(200, dtype=int)
+    for i in range(3):
+        pc = pc + (pd_[:, i] * (2 ** (3 - i - 1))).numpy()
+        tc = tc + (td_[:, i] * (2 ** (3 - i - 1))).numpy()
+    out.update(acc_raw=raw.numpy(), acc_lab=lab.numpy(), acc_hits=np.array(int(np.sum(np.where(tc == pc, 1, 0)))))
+    save("g9_co_validation.npz", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8)
+    groups = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

@@ -458,6 +458,78 @@ def test_record_denoise_path(gold):
 
 
 # ---------------------------------------------------------------- decoders / evaluators
+def test_trajectory_files_and_dataset_file(tmp_path, gold):
+    """the (rows, T*D) de-noising trajectory CSVs of datasets/*_trajectory_gen.py and
+    classifier_free_NU.py:365-394, written from the device-side ring; row 4: the sum-rate dataset file of
+    datasets/sum_rate_gen.py, read back by msr_data_load."""
+    import os
+    import pandas as pd
+    from _util import GOLD
+    from diffsg_amd import classifier_free_CO as CO, classifier_free_MSR as MSR, classifier_free_NU as NU, trajectory
+    dd = os.path.join(GOLD, "data")
+    quiet = lambda *_: None
+    # NU with the reference's checkpoint weights
+    g = gold("g4_sample_nu_ckpt.npz")
+    p = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    T = int(g["T"])
+    base = make_ddpm("nu3", p, T)
+    ddpm = NU.DDPM(T, base.model, 3, 18.0, 1.0 - O.cosine_betas(T), torch.device("cuda"), (1, 5),
+                   {'K': 3, 'P_sum': 18.0, 'cdim': 1, 'width': 400, 'height': 400}).to("cuda")
+    out = str(tmp_path / "nu_denoise_path.csv")
+    torch.manual_seed(3)
+    traj = NU.load_test_nu_debug(None, os.path.join(dd, "3u_18mW_200samples.csv"), out, T=T, omega=1.0, diffusion_model=ddpm,
+                                 log=quiet)
+    back = np.array(pd.read_csv(out, header=None))
+    assert back.shape == (60, T * 5) and np.allclose(back, traj, rtol=1e-6)
+    assert np.all(np.isfinite(back)) and np.all(back[:, -3:] >= 0.0)          # decoded powers of the final step
+    # CO in 32-row chunks (the last one ragged): every recorded step is a decoded simplex point
+    plan, pc = synth_params("co3", 2)
+    dco = CO.DDPM(5, make_model("co3", pc), 3, 1.0 - O.cosine_betas(5), torch.device("cuda"), (1, 3), None).to("cuda")
+    out = str(tmp_path / "co_denoise_path.csv")
+    tr = trajectory.co_trajectory_gen_store(None, os.path.join(dd, "3nodes_200samples_ood.csv"), out, T=5, omega=1.0,
+                                            batch_size=32, diffusion_model=dco, log=quiet)
+    back = np.array(pd.read_csv(out, header=None))
+    assert back.shape == tr.shape and back.shape[1] == 15 and back.shape[0] > 32 and np.allclose(back, tr, rtol=1e-6)
+    assert np.allclose(back.reshape(-1, 5, 3).sum(-1), 1.0, atol=1e-5)
+    # MSR: whole test split in one call
+    plan, pm = synth_params("msr3", 2)
+    dm = make_ddpm("msr3", pm, 4)
+    out = str(tmp_path / "msr_denoise_path.csv")
+    trajectory.msr_trajectory_gen_store(None, os.path.join(dd, "3c_10w_200samples.csv"), out, T=4, omega=1.0,
+                                        diffusion_model=dm, log=quiet)
+    assert np.array(pd.read_csv(out, header=None)).shape == (60, 12)
+    # dataset file: [gs | rate | schemes], accepted by the loader, labels feasible (sum = W) and consistent with the rate
+    ds = str(tmp_path / "5c_8w_40samples.csv")
+    np.random.seed(4)
+    tab = trajectory.sum_rate_dataset_store(ds, sample_num=40, M=5, W=8.0, log=quiet)
+    assert tab.shape == (40, 11)
+    np.testing.assert_allclose(tab[:, 6:].sum(1), 8.0, rtol=1e-9)
+    np.testing.assert_allclose(np.log2(1.0 + tab[:, :5] * tab[:, 6:]).sum(1), tab[:, 5], rtol=1e-9)
+    Xtr, Ytr, Xte, Yte, cfg = MSR.msr_data_load(ds)
+    assert Xtr.shape == (28, 5) and Yte.shape == (12, 5) and cfg["M"] == 5
+
+
+def test_co_self_check_harness(gold):
+    """classifier_free_CO.py:451-558: validate_ddpm_co trains on the one-hot validation set, test_ddpm scores the decision
+    pattern; the scoring rule is pinned by the reference's own arithmetic on fixed raw samples (G9)."""
+    from diffsg_amd import classifier_free_CO as CO
+    from diffsg_amd.decode import row_softmax
+    g = gold("g9_co_validation.npz")
+    raw, lab = torch.from_numpy(g["acc_raw"]).cuda(), torch.from_numpy(g["acc_lab"]).cuda()
+    w = 2 ** torch.arange(2, -1, -1, device="cuda")
+    hits = int((((row_softmax(raw) > 0.1).long() * w).sum(1) == ((lab > 0.1).long() * w).sum(1)).sum())
+    assert hits == int(g["acc_hits"])
+    np.random.seed(0); torch.manual_seed(0)
+    split = CO.validation_data_gen()
+    logs = []
+    model = CO.validate_ddpm_co(epochs=12, T=20, data_split=split, log=logs.append)
+    losses = [float(l.split("Loss:")[1]) for l in logs]
+    assert len(losses) == 12 and losses[-1] < 0.5 * losses[0]
+    res = CO.test_ddpm(T=20, omega=3.0, diffusion_model=model, data_split=split, log=logs.append)
+    assert res["n"] == 900 and logs[-1] == f"accuracy: {res['accuracy']}/900"
+    assert res["accuracy"] > 450            # far above the 1/3 of an untrained model's constant guess
+
+
 def test_decoders_match_reference_goldens(gold):
     """dsg_*_decode / dsg_*_rate / dsg_co_cost through the C ABI against the outputs of the reference's own functions
     (tests/golden/g5_decoders.npz, made by importing the reference)."""

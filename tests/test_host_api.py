@@ -149,3 +149,24 @@ def test_flatten_parameters_keeps_state_dict_and_aliases_one_buffer():
         off += v.numel()
     flat.mul_(2.0)
     assert torch.equal(net.state_dict()[list(before)[0]], 2.0 * before[list(before)[0]])
+
+
+def test_co_validation_data_gen_matches_reference(gold):
+    """classifier_free_CO.py:416-449: same numpy draws in the same order, same split."""
+    from diffsg_amd import classifier_free_CO as CO
+    g = gold("g9_co_validation.npz")
+    np.random.seed(321)
+    Xtr, Ytr, Xte, Yte, cfg = CO.validation_data_gen()
+    assert [list(a.shape) for a in (Xtr, Ytr, Xte, Yte)] == g["shapes"].tolist()
+    assert cfg == {'sfn': int(g["sfn"]), 'cfn': int(g["cfn"])}
+    np.testing.assert_array_equal(Xtr[:16], g["Xtr_head"]); np.testing.assert_array_equal(Ytr[:16], g["Ytr_head"])
+    np.testing.assert_array_equal(Xte[-16:], g["Xte_tail"]); np.testing.assert_array_equal(Yte[-16:], g["Yte_tail"])
+    np.testing.assert_allclose([Xtr.sum(), Ytr.sum(), Xte.sum(), Yte.sum()], g["sums"], rtol=1e-13)
+
+
+def test_trajectory_writers_fail_loudly_without_gpu(tmp_path):
+    from diffsg_amd import trajectory
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        trajectory.nu_trajectory_gen_store(None, os.path.join(GOLD, "data", "3u_18mW_200samples.csv"), str(tmp_path / "t.csv"))
