@@ -793,16 +793,36 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a) {
     const float omega = cp.omega, w1 = 1.0f + cp.omega;
     const size_t n4 = (a.n + 3) / 4;
     const float* zrow = (cp.z && noisy) ? cp.z + (size_t)(cp.T - 1 - step) * a.n : nullptr;
+    float* rec = cp.rec_eps ? cp.rec_eps + (size_t)(cp.T - 1 - step) * a.n : nullptr;
+    // whole quads, 16-byte aligned everywhere: one dwordx4 per stream and thread (same arithmetic per element)
+    const bool quads = (a.n & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(a.eps) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(zrow) |
+                         reinterpret_cast<uintptr_t>(rec)) & 15) == 0;
     for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
         float zz[4] = {0.f, 0.f, 0.f, 0.f};
         if (noisy && !zrow) normal4(cp.seed, (uint32_t)step, i4, zz);
+        if (quads) {
+            const float4 e0 = ld4(a.eps + i4 * 4), e1 = ld4(a.eps + a.n + i4 * 4), yv = ld4(a.y + i4 * 4);
+            if (zrow) { const float4 zv = ld4(zrow + i4 * 4); zz[0] = zv.x; zz[1] = zv.y; zz[2] = zv.z; zz[3] = zv.w; }
+            const float e0a[4] = {e0.x, e0.y, e0.z, e0.w}, e1a[4] = {e1.x, e1.y, e1.z, e1.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+            float ea[4], out[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ea[p] = __fsub_rn(__fmul_rn(w1, e1a[p]), __fmul_rn(omega, e0a[p]));
+                const float v = __fmul_rn(__fsub_rn(ya[p], __fmul_rn(c1, ea[p])), c2);
+                out[p] = noisy ? __fadd_rn(v, __fmul_rn(c3, zz[p])) : v;
+            }
+            if (rec) st4(rec + i4 * 4, make_float4(ea[0], ea[1], ea[2], ea[3]));
+            st4(a.y + i4 * 4, make_float4(out[0], out[1], out[2], out[3]));
+            continue;
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const size_t i = i4 * 4 + p;
             if (i < a.n) {
                 if (zrow) zz[p] = zrow[i];
                 const float e = __fsub_rn(__fmul_rn(w1, a.eps[a.n + i]), __fmul_rn(omega, a.eps[i]));
-                if (cp.rec_eps) cp.rec_eps[(size_t)(cp.T - 1 - step) * a.n + i] = e;
+                if (rec) rec[i] = e;
                 const float v = __fmul_rn(__fsub_rn(a.y[i], __fmul_rn(c1, e)), c2);
                 a.y[i] = noisy ? __fadd_rn(v, __fmul_rn(c3, zz[p])) : v;
             }

@@ -341,10 +341,24 @@ struct BwdGemmSplit {
 
 template <int N, bool SCLIN>
 __global__ __launch_bounds__(256, 2) void k_resblock_bwd_h(const BlockBwdArgsH a) {
+    // LayerNorm affine vectors from LDS (as in k_resblock_h): a quarter of this kernel's vector memory instructions
+    __shared__ float lnp[2 * kLnLdsW1 + 4 * kLnLdsN];
+    {
+        const int n1 = 8 * (a.b.in0.groups + a.b.in1.groups), n2 = 8 * ((N + 7) / 8);
+        for (int i = threadIdx.x; i < n1; i += blockDim.x) { lnp[i] = a.b.gamma1[i]; lnp[kLnLdsW1 + i] = a.b.beta1[i]; }
+        float* q = lnp + 2 * kLnLdsW1;
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+            q[i] = a.b.gamma2[i]; q[kLnLdsN + i] = a.b.beta2[i]; q[2 * kLnLdsN + i] = a.b.gamma3[i]; q[3 * kLnLdsN + i] = a.b.beta3[i];
+        }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (tile >= a.b.ntiles) return;
-    resblock_bwd_body<N, SCLIN>(a.b, BwdGemmSplit{a, lane, SCLIN, tile}, tile, lane);
+    BlockBwdArgs b = a.b;
+    b.gamma1 = lnp; b.beta1 = lnp + kLnLdsW1;
+    b.gamma2 = lnp + 2 * kLnLdsW1; b.beta2 = b.gamma2 + kLnLdsN; b.gamma3 = b.gamma2 + 2 * kLnLdsN; b.beta3 = b.gamma2 + 3 * kLnLdsN;
+    resblock_bwd_body<N, SCLIN>(b, BwdGemmSplit{a, lane, SCLIN, tile}, tile, lane);
 }
 
 }  // namespace dsg
