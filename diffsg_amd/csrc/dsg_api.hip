@@ -486,6 +486,7 @@ struct RunCtx {
     const int* ts;       // or null
     bool train;          // save h1/h2 for the backward pass
     bool cond_pre;       // condition embeddings precomputed for this call (dsg_sample)
+    int* advance_step = nullptr;   // reverse loop: feature_proj decrements the step index (LinArgs::advance_step)
 };
 
 size_t cap_tiles_of(const dsg_handle* h) { return (size_t)cdiv(h->cap_rows, 32) * 2; }
@@ -532,7 +533,7 @@ void fill_lin_args(const dsg_handle* h, const Op& op, const RunCtx& c, LinArgs& 
     a.in_width = l.l.K; a.in_groups = groups_of(l.l.K);
     a.out_width = l.l.N;
     a.ntiles = tpp * c.npass; a.tiles_per_pass = tpp; a.nrows = c.nrows;
-    if (op.kind == OP_PROJ) a.in_rm = c.y;
+    if (op.kind == OP_PROJ) { a.in_rm = c.y; a.advance_step = c.advance_step; }
     else a.in = seg_of(h, op.in0);
     if (op.kind == OP_FINAL) {
         a.gamma = A + l.gp; a.beta = A + l.betap; a.out_rm = c.eps_out;
@@ -1397,14 +1398,15 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
         run_unet(h, c, s);
     }
     const unsigned ublocks = (unsigned)(((u.n + 3) / 4 + 255) / 256 < 2048 ? ((u.n + 3) / 4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_update, dim3(ublocks), dim3(256), 0, s, u);
-    if (renorm) {
+    UpdateArgs ua = u;
+    ua.record_y = renorm ? 0 : 1;
+    hipLaunchKernelGGL(k_update, dim3(ublocks), dim3(256), 0, s, ua);
+    if (renorm) {   // the record is of the renormalised y (MSR.py:136-141): separate launches on these (at most 4) steps
         hipLaunchKernelGGL(k_renorm_sum, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red);
         hipLaunchKernelGGL(k_renorm_sqdiff, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
         hipLaunchKernelGGL(k_renorm_apply, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
+        hipLaunchKernelGGL(k_record, dim3(ublocks), dim3(256), 0, s, u.y, u.n, u.cp, u.step_ptr);
     }
-    hipLaunchKernelGGL(k_record, dim3(ublocks), dim3(256), 0, s, u.y, u.n, u.cp, u.step_ptr);
-    hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, s, h->step_dev);
     HIPCK(hipGetLastError());
     if (ev) {
         HIPCK(hipStreamSynchronize(s));
@@ -1445,16 +1447,17 @@ int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const flo
     run_cond_embed(h, B, s);
     if (y_T) HIPCK(hipMemcpyAsync(h->ywork, y_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     else hipLaunchKernelGGL(k_randn, dim3(2048), dim3(256), 0, s, h->ywork, n, seed, 0xFFFFFFFFu);
-    const int start = T - 1;
+    const int start = T;   // every step's first operator decrements it before anything reads it: step T-1 first
     HIPCK(hipMemcpyAsync(h->step_dev, &start, sizeof(int), hipMemcpyHostToDevice, s));
     const CallParams cp{noise, coef, omega, T, seed, rec_y, rec_eps};
     HIPCK(hipMemcpyAsync(h->call_dev, &cp, sizeof cp, hipMemcpyHostToDevice, s));
     HIPCK(hipStreamSynchronize(s));  // `start` and `cp` are host temporaries
 
     RunCtx c{B, 2, tpp, h->ywork, h->eps, h->step_dev, nullptr, false, true};
+    c.advance_step = h->step_dev;
     if (prepare_fused(h, c, s)) return 1;
     UpdateArgs u;
-    u.eps = h->eps; u.y = h->ywork; u.cp = h->call_dev; u.step_ptr = h->step_dev; u.n = n;
+    u.eps = h->eps; u.y = h->ywork; u.cp = h->call_dev; u.step_ptr = h->step_dev; u.n = n; u.record_y = 0;
 
     const int n_renorm = T < 4 ? T : 4;  // steps i > T-5 (MSR.py:136)
     if (flags & DSG_SAMPLE_PROFILE) {

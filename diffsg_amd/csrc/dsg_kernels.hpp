@@ -411,6 +411,8 @@ struct LinArgs {
     float* out_rm;          // row-major out [npass][nrows][out_width]
     int out_width;
     int ntiles, tiles_per_pass, nrows;
+    int* advance_step;      // reverse loop: the step's first operator (feature_proj, which does not read the step index)
+                            // moves it on - no kernel of its own, and nothing else is running that could read it
 };
 
 enum { IN_FRAG = 0, IN_ROWMAJOR = 1 };
@@ -494,6 +496,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, const int tile, co
 
 template <int NT, int INMODE, int OUTMODE, bool LNACT>
 __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
+    if (INMODE == IN_ROWMAJOR && a.advance_step && blockIdx.x == 0 && threadIdx.x == 0) *a.advance_step -= 1;
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.ntiles) return;
@@ -783,6 +786,7 @@ struct UpdateArgs {
     const CallParams* cp;
     const int* step_ptr;
     size_t n;
+    int record_y;             // steps without the renorm: this launch also records y (otherwise k_record after the renorm)
 };
 
 __global__ __launch_bounds__(256) void k_update(const UpdateArgs a) {
@@ -794,10 +798,11 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a) {
     const size_t n4 = (a.n + 3) / 4;
     const float* zrow = (cp.z && noisy) ? cp.z + (size_t)(cp.T - 1 - step) * a.n : nullptr;
     float* rec = cp.rec_eps ? cp.rec_eps + (size_t)(cp.T - 1 - step) * a.n : nullptr;
+    float* recy = (a.record_y && cp.rec_y) ? cp.rec_y + (size_t)(cp.T - 1 - step) * a.n : nullptr;
     // whole quads, 16-byte aligned everywhere: one dwordx4 per stream and thread (same arithmetic per element)
     const bool quads = (a.n & 3) == 0 &&
                        ((reinterpret_cast<uintptr_t>(a.eps) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(zrow) |
-                         reinterpret_cast<uintptr_t>(rec)) & 15) == 0;
+                         reinterpret_cast<uintptr_t>(rec) | reinterpret_cast<uintptr_t>(recy)) & 15) == 0;
     for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
         float zz[4] = {0.f, 0.f, 0.f, 0.f};
         if (noisy && !zrow) normal4(cp.seed, (uint32_t)step, i4, zz);
@@ -814,6 +819,7 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a) {
             }
             if (rec) st4(rec + i4 * 4, make_float4(ea[0], ea[1], ea[2], ea[3]));
             st4(a.y + i4 * 4, make_float4(out[0], out[1], out[2], out[3]));
+            if (recy) st4(recy + i4 * 4, make_float4(out[0], out[1], out[2], out[3]));
             continue;
         }
 #pragma unroll
@@ -824,7 +830,9 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a) {
                 const float e = __fsub_rn(__fmul_rn(w1, a.eps[a.n + i]), __fmul_rn(omega, a.eps[i]));
                 if (rec) rec[i] = e;
                 const float v = __fmul_rn(__fsub_rn(a.y[i], __fmul_rn(c1, e)), c2);
-                a.y[i] = noisy ? __fadd_rn(v, __fmul_rn(c3, zz[p])) : v;
+                const float o = noisy ? __fadd_rn(v, __fmul_rn(c3, zz[p])) : v;
+                a.y[i] = o;
+                if (recy) recy[i] = o;
             }
         }
     }
@@ -849,7 +857,6 @@ __global__ void k_record(const float* __restrict__ y, size_t n, const CallParams
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = y[i];
 }
 
-__global__ void k_step_advance(int* step_ptr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr -= 1; }
 
 // ---------------------------------------------------------------------------------------------
 // Early-step renormalisation (MSR.py:136-137): y <- (y - mean(y)) / sqrt(var(y)), unbiased var over ALL B*D

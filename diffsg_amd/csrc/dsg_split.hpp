@@ -896,6 +896,7 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
 
 template <int NT, int INMODE, int OUTMODE, bool LNACT>
 __global__ __launch_bounds__(256) void k_linear_h(const LinArgsH a) {
+    if (INMODE == IN_ROWMAJOR && a.l.advance_step && blockIdx.x == 0 && threadIdx.x == 0) *a.l.advance_step -= 1;
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.l.ntiles) return;
