@@ -110,6 +110,7 @@ class _Native:
         self.handle = None
         self.bound_key = None
         self.epoch = 0
+        self.named_params = None
 
     def __deepcopy__(self, memo):
         return _Native()
@@ -176,7 +177,7 @@ class UNet1D(nn.Module):
         """Create (once) the dsg handle and (re)bind the current parameter tensors; returns the raw handle."""
         L = _lib.lib()
         nat = self._native
-        params = list(self.state_dict(keep_vars=True).items())
+        params = self._named_param_list()
         if not params[0][1].is_cuda:
             raise RuntimeError("UNet1D: parameters are not on a HIP device; libdiffsg_hip has no CPU path "
                                "(move the model with .to('cuda'))")
@@ -210,9 +211,30 @@ class UNet1D(nn.Module):
             nat.bound_key = key
         return nat.handle
 
-    def mark_weights_changed(self):
-        """Parameters were updated in place through an aliasing tensor (train.FlatAdam): re-pack on the next call."""
+    def _named_param_list(self):
+        """[(state-dict key, Parameter)] in state-dict order, cached: walking the module tree costs more host time per
+        training step than the whole launch sequence.  The Parameter OBJECTS are stable under .to(), load_state_dict and
+        train.flatten_parameters (they swap `.data`); `_apply` drops the cache anyway, and code that assigns new Parameter
+        objects into sub-modules must call `mark_weights_changed()`."""
+        nat = self._native
+        if getattr(nat, 'named_params', None) is None:
+            nat.named_params = list(self.state_dict(keep_vars=True).items())
+        return nat.named_params
+
+    def param_list(self):
+        """The parameter tensors in state-dict order (cached, see `_named_param_list`)."""
+        return [v for _, v in self._named_param_list()]
+
+    def _apply(self, fn, *a, **k):
+        self._native.named_params = None
+        return super()._apply(fn, *a, **k)
+
+    def mark_weights_changed(self, rebuild=False):
+        """Parameters were updated in place through an aliasing tensor (train.FlatAdam): re-pack on the next call.
+        rebuild=True also drops the cached parameter list (new Parameter objects were assigned into sub-modules)."""
         self._native.epoch += 1
+        if rebuild:
+            self._native.named_params = None
 
     def set_precision(self, mode):
         """Arithmetic of the >= 64-wide blocks inside DDPM.sample: "split_f16" (default; float32-accurate hi/lo fp16

@@ -191,17 +191,23 @@ class DDPMCore(nn.Module):
     def _publish(self, grad_out):
         work, bucket = self._grad_work, self._grad_bucket
         work.mul_(grad_out.to(work.dtype))
-        params = list(self.model.parameters())
-        installed = all(p.grad is not None for p in params) and params[0].grad.data_ptr() == bucket.data_ptr()
+        params = self.model.param_list()
+        installed = params[0].grad is not None and params[-1].grad is not None and params[0].grad.data_ptr() == bucket.data_ptr()
         if installed:
             bucket.add_(work)          # gradient accumulation across calls, as autograd would
         else:
             bucket.copy_(work)
-            off = 0
-            for p in params:
-                n = p.numel()
-                p.grad = bucket[off:off + n].view_as(p)
-                off += n
+            views = getattr(self, "_grad_views", None)
+            if views is None or views[0] is not bucket or len(views[1]) != len(params):
+                off, vs = 0, []
+                for p in params:
+                    n = p.numel()
+                    vs.append(bucket[off:off + n].view_as(p))
+                    off += n
+                views = self._grad_views = (bucket, vs)
+            for p, v in zip(params, views[1]):
+                p.grad = v
+        self._grads_ready = True
 
     def allreduce_grads(self):
         """Data parallel: ONE all-reduce of the flat bucket, mean over ranks (mse_loss is a mean over local rows)."""
