@@ -407,6 +407,20 @@ def test_flat_adam_is_adam_bit_for_bit():
         assert float(la) == float(lb), step
     for (k, va), vb in zip(a.model.state_dict().items(), b.model.state_dict().values()):
         assert torch.equal(va, vb), k
+    # zero_grad(): the .grad views stay installed and read zero; a step() without a backward changes nothing
+    w = b.model.final.weight
+    assert w.grad is not None and not w.grad.any() and w.grad.data_ptr() != 0
+    before = w.detach().clone()
+    assert opt_b.step() is None and torch.equal(w.detach(), before)
+    # gradient accumulation over two backward calls, as autograd does it
+    lb = b(y, cond, ts=ts, noise=noise, cond_mask=mask); lb.backward()
+    g1 = w.grad.clone()
+    lb = b(y, cond, ts=ts, noise=noise, cond_mask=mask); lb.backward()
+    assert torch.allclose(w.grad, 2 * g1, rtol=1e-6, atol=0)
+    opt_b.zero_grad(set_to_none=True)
+    assert all(q.grad is None for q in b.model.parameters())
+    lb = b(y, cond, ts=ts, noise=noise, cond_mask=mask); lb.backward()
+    assert torch.equal(w.grad, g1)
 
 
 def test_entry_points_train_save_load_eval(tmp_path):
