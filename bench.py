@@ -131,7 +131,7 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
     f_train = 3 * 2 * (566_400 + 100_480)
     sps = world * B * steps / dt
     return {"samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": B, "global_batch": world * B,
-            "steps": steps, "T": 20, "final_loss": float(loss), "achieved_tflops": sps / world * f_train / 1e12,
+            "steps": steps, "T": 20, "final_loss": float(loss.detach()), "achieved_tflops": sps / world * f_train / 1e12,
             "frac_f32_mfma": sps / world * f_train / 1e12 / PEAK_F32_TFLOPS, "grad_bucket_bytes": int(ddpm.grad_bucket.numel()) * 4,
             "collective": "one all_reduce(SUM)/world per step over the flat bucket" if world > 1 else "none (1 GPU)"}
 
