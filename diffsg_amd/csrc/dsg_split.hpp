@@ -399,10 +399,16 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     }
 }
 
+// Floats of gamma1 / beta1 a block's stage 1 can touch: whole k16-steps of each input segment (the odd group of in0 reads
+// on into in1's vector, or - without in1 - into the zero padding of the packed buffer; both finite, both times zero weights)
+__device__ __forceinline__ int ln1_extent(const BlockArgs& a) {
+    return a.in1.groups ? 8 * a.in0.groups + 16 * ((a.in1.groups + 1) >> 1) : 16 * ((a.in0.groups + 1) >> 1);
+}
+
 // Copy the block's three (gamma, beta) pairs into LDS: [gamma1 | beta1] kLnLdsW1 floats each, then [gamma2 | beta2 |
 // gamma3 | beta3] kLnLdsN each.  n1 = the floats stage 1 can touch (8 * groups of in0 + 16 * steps of in1).
 __device__ __forceinline__ void stage_ln_params(float* __restrict__ lds, const BlockArgs& a, int N) {
-    const int n1 = 8 * a.in0.groups + 16 * ((a.in1.groups + 1) >> 1), n2 = 16 * (((N + 7) / 8 + 1) / 2);
+    const int n1 = ln1_extent(a), n2 = 16 * (((N + 7) / 8 + 1) / 2);
     for (int i = threadIdx.x; i < n1; i += blockDim.x) { lds[i] = a.gamma1[i]; lds[kLnLdsW1 + i] = a.beta1[i]; }
     for (int i = threadIdx.x; i < n2; i += blockDim.x) {
         float* q = lds + 2 * kLnLdsW1;
