@@ -780,6 +780,10 @@ struct CallParams {
     float* rec_eps;       // [T][n] guided eps of each step, or null
 };
 
+__global__ void k_set_call(int* step, CallParams* dst, const CallParams cp, int start) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { *step = start; *dst = cp; }
+}
+
 struct UpdateArgs {
     const float* eps;     // [2][n] : eps0 then eps1
     float* y;             // [n] in/out
