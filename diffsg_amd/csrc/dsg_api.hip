@@ -166,7 +166,7 @@ struct dsg_handle {
     FusedOpH* fusedh_train_dev = nullptr;   // the same run for the training forward (every output stored, h1/h2 saved)
     const void* fusedh_train_key[4] = {nullptr, nullptr, nullptr, nullptr}; int fusedh_train_rows = 0;
     // inference tables (dsg_sample / dsg_unet_forward / dsg_time_op share them): what the device copy was built for
-    struct FusedSig { bool valid = false, sp = false; int nrows = 0, npass = 0, uncond_tiles = 0; const void* p[8] = {}; } fused_sig;
+    struct FusedSig { bool valid = false, sp = false, share = false; int nrows = 0, npass = 0, uncond_tiles = 0; const void* p[8] = {}; } fused_sig;
     FusedOp* ce_dev = nullptr;          // condition-embedding Linear table (narrow blocks, one launch)
     std::vector<FusedOp> ce_host;
     CondTile* ctile_dev = nullptr; int ctile_n = 0; const float* ctile_key = nullptr; size_t ctile_cap = 0;
@@ -493,6 +493,7 @@ struct RunCtx {
     bool train;          // save h1/h2 for the backward pass
     bool cond_pre;       // condition embeddings precomputed for this call (dsg_sample)
     int* advance_step = nullptr;   // reverse loop: feature_proj decrements the step index (LinArgs::advance_step)
+    bool share_proj = false;       // reverse loop, split path: feature_proj(y) computed for ONE pass, read by both (Seg::wrap)
 };
 
 size_t cap_tiles_of(const dsg_handle* h) { return (size_t)cdiv(h->cap_rows, 32) * 2; }
@@ -506,6 +507,7 @@ Seg seg_of(const dsg_handle* h, int tid) {
     s.stats = h->ws + t.stats_off * cap;
     s.groups = groups_of(t.width);
     s.width = t.width;
+    s.wrap = 0;
     return s;
 }
 float* trp(const dsg_handle* h, size_t off) { return h->tr_ws + off * tr_tiles_of(h); }
@@ -517,6 +519,11 @@ void fill_block_args(const dsg_handle* h, const Op& op, const RunCtx& c, BlockAr
     memset(&a, 0, sizeof a);
     a.in0 = seg_of(h, op.in0);
     if (op.in1 >= 0) a.in1 = seg_of(h, op.in1);
+    if (c.share_proj) {
+        const int pt = h->ops[0].out;
+        if (op.in0 == pt) a.in0.wrap = tpp;
+        if (op.in1 == pt) a.in1.wrap = tpp;
+    }
     a.W1 = A + r.W1p; a.gamma1 = A + r.g1p; a.beta1 = A + r.b1p;
     a.tbias = h->tb + r.tb_off; a.step_ptr = c.step_ptr; a.ts = c.ts; a.tb_stride = h->tb_stride;
     a.W2 = A + r.W2p; a.gamma2 = A + r.g2p; a.beta2 = A + r.b2p; a.c2 = A + r.c2p;
@@ -539,8 +546,13 @@ void fill_lin_args(const dsg_handle* h, const Op& op, const RunCtx& c, LinArgs& 
     a.in_width = l.l.K; a.in_groups = groups_of(l.l.K);
     a.out_width = l.l.N;
     a.ntiles = tpp * c.npass; a.tiles_per_pass = tpp; a.nrows = c.nrows;
-    if (op.kind == OP_PROJ) { a.in_rm = c.y; a.advance_step = c.advance_step; }
-    else a.in = seg_of(h, op.in0);
+    if (op.kind == OP_PROJ) {
+        a.in_rm = c.y; a.advance_step = c.advance_step;
+        if (c.share_proj) a.ntiles = tpp;            // one pass: the second pass's consumers wrap onto these tiles
+    } else {
+        a.in = seg_of(h, op.in0);
+        if (c.share_proj && op.in0 == h->ops[0].out) a.in.wrap = tpp;
+    }
     if (op.kind == OP_FINAL) {
         a.gamma = A + l.gp; a.beta = A + l.betap; a.out_rm = c.eps_out;
     } else {
@@ -688,12 +700,12 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
         // same context as the table already on the device (consecutive dsg_sample calls of one batch size): nothing to do - and
         // no stream synchronise between calls, so the host can enqueue the next call while this one runs
         dsg_handle::FusedSig sig;
-        sig.valid = true; sig.sp = sp; sig.nrows = c.nrows; sig.npass = c.npass; sig.uncond_tiles = c.uncond_tiles;
+        sig.valid = true; sig.sp = sp; sig.share = c.share_proj; sig.nrows = c.nrows; sig.npass = c.npass; sig.uncond_tiles = c.uncond_tiles;
         const void* ptrs[8] = {c.y, c.eps_out, c.step_ptr, c.ts, h->ws, h->cembed, h->tb,
                                reinterpret_cast<const void*>((size_t)h->cap_rows * 2 + (c.cond_pre ? 1 : 0))};
         memcpy(sig.p, ptrs, sizeof ptrs);
         const dsg_handle::FusedSig& o = h->fused_sig;
-        if (o.valid && o.sp == sig.sp && o.nrows == sig.nrows && o.npass == sig.npass && o.uncond_tiles == sig.uncond_tiles &&
+        if (o.valid && o.sp == sig.sp && o.share == sig.share && o.nrows == sig.nrows && o.npass == sig.npass && o.uncond_tiles == sig.uncond_tiles &&
             !memcmp(o.p, sig.p, sizeof sig.p))
             return 0;
         h->fused_sig = sig;
@@ -940,8 +952,8 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
         gsrc.push_back(g);
         return (int)gsrc.size() - 1;
     };
-    auto gseg = [&](const float* data, int width) { Seg sg; sg.data = data; sg.stats = nullptr; sg.groups = groups_of(width); sg.width = width; return sg; };
-    auto none = [&]() { Seg sg; sg.data = nullptr; sg.stats = nullptr; sg.groups = 0; sg.width = 0; return sg; };
+    auto gseg = [&](const float* data, int width) { Seg sg; sg.data = data; sg.stats = nullptr; sg.groups = groups_of(width); sg.width = width; sg.wrap = 0; return sg; };
+    auto none = [&]() { Seg sg; sg.data = nullptr; sg.stats = nullptr; sg.groups = 0; sg.width = 0; sg.wrap = 0; return sg; };
     auto wgrad = [&](const float* G0, const float* G1, int N, int amode, Seg a0, Seg a1, const float* rs, const float* gm,
                      const float* bt, long long out_off, int ld) {
         WgradDesc d;
@@ -1483,6 +1495,7 @@ int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const flo
 
     RunCtx c{B, 2, tpp, h->ywork, h->eps, h->step_dev, nullptr, false, true};
     c.advance_step = h->step_dev;
+    c.share_proj = split_ctx(h, c);
     if (prepare_fused(h, c, s)) return 1;
     UpdateArgs u;
     u.eps = h->eps; u.y = h->ywork; u.cp = h->call_dev; u.step_ptr = h->step_dev; u.n = n; u.record_y = 0;

@@ -209,7 +209,10 @@ struct Seg {
     const float* stats;  // [tiles*32][2] = (mean, M2) per row, may be null when unused
     int groups;          // ceil(width/8)
     int width;           // true feature count
+    int wrap;            // 0, or tiles per pass: both CFG passes read the first pass's tiles (feature_proj(y) is the same
+                         // tensor for the unconditional and the conditional pass; split path, reverse loop only)
 };
+__device__ __forceinline__ int seg_tile(const Seg& s, int tile) { return (s.wrap && tile >= s.wrap) ? tile - s.wrap : tile; }
 
 // ---------------------------------------------------------------------------------------------
 // ResidualBlock forward (UNetCF.py:83-95), one wave per 32-row tile:

@@ -244,9 +244,9 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     {
         float mean, m2, n = (float)a.in0.width;
         if (XIN) { mean = *xr_mean; m2 = *xr_m2; }
-        else { const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j]; mean = s0.x; m2 = s0.y; }
+        else { const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)seg_tile(a.in0, tile) * 32 + j]; mean = s0.x; m2 = s0.y; }
         if (a.in1.groups) {
-            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
+            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)seg_tile(a.in1, tile) * 32 + j];
             const float n1 = (float)a.in1.width, nt_ = n + n1;
             const float dd = s1.x - mean;
             m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
@@ -286,10 +286,10 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         if (XIN)    // in0 has the block's own width N here (down / middle: in = N; up: cat(N, N))
             chain_from_acc_h<N, NT>(acc1, *xr, ah.W1h, gamma1, beta1, mean1, rstd1, lane, h, nt_stride, PRE ? &p1a : nullptr);
         else
-            chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
+            chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
                                        gamma1 + 4 * h, beta1 + 4 * h, mean1, rstd1);
         if (a.in1.groups)
-            chain_from_mem_h<NT, true>(acc1, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
+            chain_from_mem_h<NT, true>(acc1, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                        ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, gamma1 + 8 * a.in0.groups + 4 * h,
                                        beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr);
         int entry = 0;
@@ -357,10 +357,10 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         if (XIN)
             chain_raw_from_reg_h<NT>(acc3, *xr, a.in0.groups, ah.Wsch, nt_stride, lane, PRE ? &psa : nullptr);
         else
-            chain_from_mem_h<NT, false>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
+            chain_from_mem_h<NT, false>(acc3, a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
                                         nullptr, nullptr, 0.f, 1.f);
         if (a.in1.groups)
-            chain_from_mem_h<NT, false>(acc3, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
+            chain_from_mem_h<NT, false>(acc3, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                         ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f, PRE ? &psb : nullptr);
         acc_unscale_add<NT>(acc3, inv3, a.c3, h);
     } else {
@@ -369,7 +369,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc3[nt] += (*xr)[nt];
         } else {
-            const float* xp = a.in0.data + (size_t)tile * NG * 256 + lane * 4;
+            const float* xp = a.in0.data + (size_t)seg_tile(a.in0, tile) * NG * 256 + lane * 4;
 #pragma unroll
             for (int G = 0; G < NG; ++G) {
                 const float4 xv = ld4(xp + (size_t)G * 256);
@@ -498,10 +498,10 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
     // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as k_resblock_h
     float mean1, rstd1;
     {
-        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
+        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)seg_tile(a.in0, tile) * 32 + j];
         float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
         if (a.in1.groups) {
-            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
+            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)seg_tile(a.in1, tile) * 32 + j];
             const float n1 = (float)a.in1.width, nt_ = n + n1;
             const float dd = s1.x - mean;
             m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
                 const bool first = S < ks0;
                 const Seg& sg = first ? a.in0 : a.in1;
                 const int Sl = first ? S : S - ks0;
-                const float* xp = sg.data + (size_t)tile * sg.groups * 256 + lane * 4;
+                const float* xp = sg.data + (size_t)seg_tile(sg, tile) * sg.groups * 256 + lane * 4;
                 x0[i] = ld4(xp + (size_t)(2 * Sl) * 256);
                 if (2 * Sl + 1 < sg.groups) x1[i] = ld4(xp + (size_t)(2 * Sl + 1) * 256);
                 const int gbase = (first ? 0 : 8 * a.in0.groups) + 16 * Sl + 4 * h;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
         acc_unscale_add<1>(acc3, inv3, a.c3 + 32 * w, h);
     } else {
         acc_unscale_add<1>(acc3, inv3, a.c3 + 32 * w, h);
-        const float* xp = a.in0.data + ((size_t)tile * NG + 4 * w) * 256 + lane * 4;
+        const float* xp = a.in0.data + ((size_t)seg_tile(a.in0, tile) * NG + 4 * w) * 256 + lane * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 xv = ld4(xp + (size_t)q * 256);
@@ -815,12 +815,12 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
     float mean = 0.f, rstd = 1.f;
     if (LNACT) {
-        const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)tile * 32 + j];
+        const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)seg_tile(a.in, tile) * 32 + j];
         mean = s.x;
         rstd = rsqrtf(s.y / (float)a.in.width + kLnEps);
     }
     if (INMODE == IN_FRAG) {
-        chain_from_mem_h<NT, LNACT>(acc, a.in.data + (size_t)tile * KG * 256 + lane * 4, KG, ah.Wh + lane, nt_stride,
+        chain_from_mem_h<NT, LNACT>(acc, a.in.data + (size_t)seg_tile(a.in, tile) * KG * 256 + lane * 4, KG, ah.Wh + lane, nt_stride,
                                     LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
     } else {
         for (int S = 0; S < KS; ++S) {
@@ -967,12 +967,12 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void k_fused_narrow_h(const Fused
         if (op.kind == 0) {
             if (!have_x) {  // first operator of the run: bring its (<= 32 wide) input into registers once
                 const Seg& s0 = op.b.b.in0;
-                const float2 st = reinterpret_cast<const float2*>(s0.stats)[(size_t)tile * 32 + j];
+                const float2 st = reinterpret_cast<const float2*>(s0.stats)[(size_t)seg_tile(s0, tile) * 32 + j];
                 xmean = st.x; xm2 = st.y;
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (G < s0.groups) v = ld4(s0.data + ((size_t)tile * s0.groups + G) * 256 + lane * 4);
+                    if (G < s0.groups) v = ld4(s0.data + ((size_t)seg_tile(s0, tile) * s0.groups + G) * 256 + lane * 4);
                     x[0][4 * G] = v.x; x[0][4 * G + 1] = v.y; x[0][4 * G + 2] = v.z; x[0][4 * G + 3] = v.w;
                 }
                 have_x = true;
