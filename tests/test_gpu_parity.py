@@ -141,6 +141,35 @@ def test_sample_nu_checkpoint_known_answer(gold):
     assert abs(ratio - 0.91359) < 2e-3, ratio
 
 
+@pytest.mark.parametrize("name,B", [("msr80", 16384 + 33), ("co3", 16384 + 7)])
+def test_sample_large_launch_split_vs_exact_f32(name, B):
+    """Above the cooperative-kernel threshold (> 512 row tiles per launch) the wide blocks run one wave per tile, the pair
+    kernels are used and feature_proj is computed for one CFG pass only (the other pass's consumers wrap their tile index).
+    The exact-f32 path shares none of that (full launches for both passes, f32 MFMA kernels): same injected noise, ragged
+    batch, the two must agree to the float32-accuracy bar."""
+    plan, p = synth_params(name, 5)
+    cfg = CONFIGS[name]
+    T = 5
+    ddpm = make_ddpm(name, p, T)
+    g = torch.Generator().manual_seed(9)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    out = {}
+    for mode in ("split_f16", "f32"):
+        ddpm.model.set_precision(mode)
+        out[mode] = ddpm.sample(cond, 2.0, y_T=y_T, noise=z)
+    ddpm.model.set_precision("split_f16")
+    assert torch.isfinite(out["f32"]).all()
+    assert rel(out["split_f16"], out["f32"]) <= 1e-4
+    # and the small oracle check on a slice that spans the pass boundary tile: rows are independent after step T-5, but the
+    # first steps couple them through the global renorm - so compare the full batch's statistics-free invariant instead:
+    # duplicating the batch must reproduce the outputs row for row
+    y2 = ddpm.sample(torch.cat((cond, cond)), 2.0, y_T=torch.cat((y_T, y_T)), noise=torch.cat((z, z), dim=1))
+    assert torch.equal(y2[:B], y2[B:])
+    assert rel(y2[:B], out["split_f16"]) <= 1e-4
+
+
 def test_sample_full_size_properties():
     """A BASELINE-size call (B=8192, D=C=80) checked through size-independent properties:
     duplicated rows give duplicated outputs (rows only couple through the global renorm statistics, which a
