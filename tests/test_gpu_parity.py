@@ -312,6 +312,35 @@ def test_training_reduces_loss_and_matches_cpu_adam():
         assert rel(v, cpu[k].detach()) <= 1e-3, k
 
 
+def test_train_step_large_launch_split_vs_exact_f32():
+    """BASELINE training shape (32 768 rows + a ragged tail: 1 025 row tiles, above the cooperative threshold): loss and
+    every gradient of the split path (one-wave-per-tile forward, k_resblock_bwd_h, k_wgrad_h) against the exact-f32 path
+    (k_resblock / k_resblock_bwd / k_wgrad) on the same draws."""
+    name, B, T = "msr80", 32768 + 17, 20
+    plan, p = synth_params(name, 13)
+    ddpm = make_ddpm(name, p, T)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(3)
+    y = (torch.rand(B, cfg["input_dim"], generator=g) * 0.25).cuda()
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    ts = torch.randint(0, T, (1, B), generator=g).cuda()
+    noise = torch.randn(B, cfg["input_dim"], generator=g).cuda()
+    mask = (torch.rand(B, 1, generator=g) < 0.9).float().cuda()
+    res = {}
+    for mode in ("split_f16", "f32"):
+        ddpm.model.set_precision(mode)
+        for q in ddpm.model.parameters():
+            q.grad = None
+        loss = ddpm(y, cond, ts=ts, noise=noise, cond_mask=mask)
+        loss.backward()
+        res[mode] = (float(loss.detach()), {k: q.grad.detach().clone() for k, q in ddpm.model.named_parameters()})
+    ddpm.model.set_precision("split_f16")
+    assert abs(res["split_f16"][0] - res["f32"][0]) <= 1e-5 * abs(res["f32"][0])
+    gmax = max(float(v.abs().max()) for v in res["f32"][1].values())
+    for k, v in res["f32"][1].items():
+        assert float((res["split_f16"][1][k] - v).abs().max()) / gmax <= 1e-4, k
+
+
 @pytest.mark.parametrize("name,B", [("msr80", 100), ("co3", 77)])
 def test_train_step_exact_f32_mode(name, B):
     """precision="f32": exact f32 MFMA forward, data gradients and weight gradients (k_resblock_bwd / k_wgrad), same oracle."""
