@@ -190,13 +190,16 @@ __device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float*
     }
 }
 
-// acc <- acc * inv + vec  (un-scale and add the per-feature vector, padded to NT*32)
-template <int NT>
+// acc <- acc * inv + vec  (un-scale and add the per-feature vector, padded to NT*32).  NQ = real 8-feature groups: the padded
+// groups of a narrow block (N < 32) hold exact zeros (zero weight rows, zero vector padding) and are left alone - a quarter
+// of the vector reads and FMAs of an 8-wide block's three stages
+template <int NT, int NQ = NT * 4>
 __device__ __forceinline__ void acc_unscale_add(f32x16 (&acc)[NT], float inv, const float* __restrict__ vec, int h) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (4 * nt + q >= NQ) continue;
             const float4 b = ld4(vec + 32 * nt + 8 * q + 4 * h);
             acc[nt][4 * q + 0] = fmaf(acc[nt][4 * q + 0], inv, b.x); acc[nt][4 * q + 1] = fmaf(acc[nt][4 * q + 1], inv, b.y);
             acc[nt][4 * q + 2] = fmaf(acc[nt][4 * q + 2], inv, b.z); acc[nt][4 * q + 3] = fmaf(acc[nt][4 * q + 3], inv, b.w);
@@ -300,7 +303,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         } else if (a.step_ptr) {
             entry = *a.step_ptr;
         }
-        acc_unscale_add<NT>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
+        acc_unscale_add<NT, NG>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
     }
     if (a.save_h1) {
 #pragma unroll
@@ -321,7 +324,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         acc_stats<N, NT>(acc1, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
         chain_from_acc_h<N, NT>(acc2, acc1, ah.W2h, gamma2, beta2, mean, rstd, lane, h, 0, PRE ? &p2 : nullptr);
-        acc_unscale_add<NT>(acc2, inv2, a.c2, h);
+        acc_unscale_add<NT, NG>(acc2, inv2, a.c2, h);
     }
     if (tile >= a.uncond_tiles) {
         const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
@@ -362,9 +365,9 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         if (a.in1.groups)
             chain_from_mem_h<NT, false>(acc3, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                         ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f, PRE ? &psb : nullptr);
-        acc_unscale_add<NT>(acc3, inv3, a.c3, h);
+        acc_unscale_add<NT, NG>(acc3, inv3, a.c3, h);
     } else {
-        acc_unscale_add<NT>(acc3, inv3, a.c3, h);
+        acc_unscale_add<NT, NG>(acc3, inv3, a.c3, h);
         if (XIN) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc3[nt] += (*xr)[nt];
