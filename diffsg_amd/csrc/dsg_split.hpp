@@ -100,10 +100,14 @@ __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16
     const size_t nt_stride = nt_stride_override ? nt_stride_override : (size_t)KS * 128;
     const float c = rstd, d = -mean * rstd;
     HFrag<NT> wn;
-    float4 gn0, bn0, gn1, bn1;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gn0, bn0, gn1 = z4, bn1 = z4;
     if (w0) wn = *w0;                 // the first step's planes were requested earlier (narrow run)
     else load_hfrag<NT>(wn, wp + lane, nt_stride);
-    gn0 = ld4(gamma + 4 * h); bn0 = ld4(beta + 4 * h); gn1 = ld4(gamma + 8 + 4 * h); bn1 = ld4(beta + 8 + 4 * h);
+    gn0 = ld4(gamma + 4 * h); bn0 = ld4(beta + 4 * h);
+    // the second quad of a step is padding when 16 S + 8 >= N (N = 8, 24, ...): x = 0, gamma = beta = 0 there, so the operand
+    // is exactly 0 - neither loaded nor transformed
+    if (8 < N) { gn1 = ld4(gamma + 8 + 4 * h); bn1 = ld4(beta + 8 + 4 * h); }
 #pragma unroll
     for (int S = 0; S < KS; ++S) {
         const HFrag<NT> wc = wn;
@@ -111,13 +115,19 @@ __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16
         if (S + 1 < KS) {
             load_hfrag<NT>(wn, wp + (size_t)(S + 1) * 128 + lane, nt_stride);
             gn0 = ld4(gamma + 16 * (S + 1) + 4 * h); bn0 = ld4(beta + 16 * (S + 1) + 4 * h);
-            gn1 = ld4(gamma + 16 * (S + 1) + 8 + 4 * h); bn1 = ld4(beta + 16 * (S + 1) + 8 + 4 * h);
+            if (16 * (S + 1) + 8 < N) { gn1 = ld4(gamma + 16 * (S + 1) + 8 + 4 * h); bn1 = ld4(beta + 16 * (S + 1) + 8 + 4 * h); }
         }
         __builtin_amdgcn_sched_barrier(0);
         const int t = S >> 1, r0 = 8 * (S & 1);
         float v[8];
-        act8(v, make_float4(in[t][r0], in[t][r0 + 1], in[t][r0 + 2], in[t][r0 + 3]),
-             make_float4(in[t][r0 + 4], in[t][r0 + 5], in[t][r0 + 6], in[t][r0 + 7]), c, d, g0, b0, g1, b1);
+        if (16 * S + 8 < N) {
+            act8(v, make_float4(in[t][r0], in[t][r0 + 1], in[t][r0 + 2], in[t][r0 + 3]),
+                 make_float4(in[t][r0 + 4], in[t][r0 + 5], in[t][r0 + 6], in[t][r0 + 7]), c, d, g0, b0, g1, b1);
+        } else {
+            v[0] = silu_scaled(fmaf(fmaf(in[t][r0], c, d), g0.x, b0.x)); v[1] = silu_scaled(fmaf(fmaf(in[t][r0 + 1], c, d), g0.y, b0.y));
+            v[2] = silu_scaled(fmaf(fmaf(in[t][r0 + 2], c, d), g0.z, b0.z)); v[3] = silu_scaled(fmaf(fmaf(in[t][r0 + 3], c, d), g0.w, b0.w));
+            v[4] = v[5] = v[6] = v[7] = 0.f;
+        }
         h8 bhi, blo;
         split8(v, bhi, blo);
         mfma_step_h<NT>(out, wc, bhi, blo);
