@@ -90,12 +90,31 @@ class Downsample(_LinHolder):
 
 # In-place parameter updates that PyTorch's tensor version counters do not see (fused optimizers -- torch._fused_adam_ leaves
 # `_version` untouched -- and anything that writes through raw pointers) would leave the library's packed weights stale.
-# Every optimizer step in the process therefore bumps this counter, and every UNet1D re-packs on its next call.
-_OPT_EPOCH = [0]
+# A step of an optimizer that OWNS parameters of a UNet1D (its own tensors, or storage they alias: train.FlatAdam) bumps
+# that model's epoch, and the model re-packs on its next call; optimizers over unrelated parameters leave it alone.
+import weakref  # noqa: E402
+
+_NATIVES = weakref.WeakSet()
+_OPT_OWNERS = weakref.WeakKeyDictionary()   # optimizer -> (signature of its param groups, [weakref to _Native])
 
 
-def _on_optimizer_step(*_args, **_kw):
-    _OPT_EPOCH[0] += 1
+def _on_optimizer_step(optimizer, *_args, **_kw):
+    groups = optimizer.param_groups
+    sig = tuple(len(g["params"]) for g in groups) + (len(_NATIVES),)
+    hit = _OPT_OWNERS.get(optimizer)
+    if hit is None or hit[0] != sig:
+        ptrs = set()
+        for g in groups:
+            for p in g["params"]:
+                st = p.untyped_storage()
+                ptrs.add((st.data_ptr(), p.device))
+        owners = [weakref.ref(n) for n in list(_NATIVES) if n.storage_keys & ptrs]
+        hit = (sig, owners)
+        _OPT_OWNERS[optimizer] = hit
+    for r in hit[1]:
+        n = r()
+        if n is not None:
+            n.epoch += 1
 
 
 from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook  # noqa: E402
@@ -111,6 +130,8 @@ class _Native:
         self.bound_key = None
         self.epoch = 0
         self.named_params = None
+        self.storage_keys = frozenset()   # (storage pointer, device) of every parameter: what an optimizer must own to matter
+        _NATIVES.add(self)
 
     def __deepcopy__(self, memo):
         return _Native()
@@ -122,6 +143,9 @@ class _Native:
         self.handle = None
         self.bound_key = None
         self.epoch = 0
+        self.named_params = None
+        self.storage_keys = frozenset()
+        _NATIVES.add(self)
 
     def __del__(self):
         try:
@@ -200,7 +224,7 @@ class UNet1D(nn.Module):
             for i, (k, v) in enumerate(params):
                 if v.numel() != L.dsg_param_numel(hd, i):
                     raise RuntimeError(f"size mismatch for {k}")
-        key = (nat.epoch, _OPT_EPOCH[0]) + tuple((v.data_ptr(), v._version) for _, v in params)
+        key = (nat.epoch,) + tuple((v.data_ptr(), v._version) for _, v in params)
         if key != nat.bound_key:
             for k, v in params:
                 if v.dtype != torch.float32 or not v.is_contiguous():
@@ -219,6 +243,8 @@ class UNet1D(nn.Module):
         nat = self._native
         if getattr(nat, 'named_params', None) is None:
             nat.named_params = list(self.state_dict(keep_vars=True).items())
+            nat.storage_keys = frozenset((v.untyped_storage().data_ptr(), v.device) for _, v in nat.named_params)
+            _OPT_OWNERS.clear()            # ownership is decided per (optimizer, parameter storage): recompute
         return nat.named_params
 
     def param_list(self):
@@ -241,6 +267,12 @@ class UNet1D(nn.Module):
         split on the f16 matrix cores, f32 accumulate) or "f32" (exact v_mfma_f32_32x32x2_f32)."""
         code = {"split_f16": 0, "f32": 1}[mode]
         _lib.check(_lib.lib().dsg_set_precision(self.native_handle(), code))
+
+    def set_launch_policy(self, coop_max_tiles=-1, narrow_small_max_tiles=-1):
+        """Kernel forms by launch size (dsg_set_launch_policy): launches of at most `coop_max_tiles` 32-row tiles run
+        the wide blocks cooperatively, at most `narrow_small_max_tiles` the small-launch narrow run; -1 = default,
+        0 = always the large-launch forms (what a 65 536-row call uses)."""
+        _lib.check(_lib.lib().dsg_set_launch_policy(self.native_handle(), int(coop_max_tiles), int(narrow_small_max_tiles)))
 
     def forward(self, x, t, cond, cond_mask):
         """

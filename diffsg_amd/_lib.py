@@ -13,8 +13,35 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiffsg_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "dsg_api.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "dsg_kernels.hpp"), os.path.join(_HERE, "csrc", "dsg_train.hpp"), os.path.join(_HERE, "csrc", "dsg_split.hpp"),
-           os.path.join(os.path.dirname(_HERE), "include", "diffsg.h")]
+
+
+def _headers():
+    """Everything dsg_api.hip includes: every header under csrc/ and the C-ABI declaration."""
+    import glob
+    return sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp"))) + [os.path.join(os.path.dirname(_HERE), "include", "diffsg.h")]
+
+_ID_MARK = b"DSG_BUILD_ID="
+
+
+def source_id() -> str:
+    """sha256 over the sources the library is built from (file names + contents): compiled into the library as its build id."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in SOURCES + _headers():
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def built_id():
+    """The build id compiled into libdiffsg_hip.so (read from the file, nothing is loaded), or None."""
+    if not os.path.exists(LIB_PATH):
+        return None
+    with open(LIB_PATH, "rb") as f:
+        blob = f.read()
+    i = blob.find(_ID_MARK)
+    return blob[i + len(_ID_MARK): i + len(_ID_MARK) + 64].decode("ascii", "replace") if i >= 0 else None
 
 MAX_RES = 8
 
@@ -25,8 +52,9 @@ class UNetDesc(ctypes.Structure):
 
 
 def _stale() -> bool:
-    deps = [p for p in SOURCES + HEADERS if os.path.exists(p)]
-    return not (os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(p) for p in deps))
+    """The library is missing, or was built from other sources than the ones in the tree (content hash, not mtimes: the
+    binary travels to the GPU box as a file copy)."""
+    return built_id() != source_id()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -45,7 +73,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             # different results on gfx950 ("Build flags"); without it the library is deterministic and 2-5 % faster.
             tmp = LIB_PATH + f".{os.getpid()}.tmp"
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-fno-slp-vectorize",
-                   "-o", tmp] + SOURCES
+                   f'-DDSG_BUILD_ID_STR="{source_id()}"', "-o", tmp] + SOURCES
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
@@ -70,6 +98,8 @@ _SIGS = {
                                       ctypes.c_int, ctypes.c_void_p]),
     "dsg_bind_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
     "dsg_set_precision": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "dsg_set_launch_policy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "dsg_build_id": (ctypes.c_char_p, []),
     "dsg_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "dsg_unet_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
     "dsg_row_softmax": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
@@ -112,6 +142,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback for this path")
+        if _stale():
+            # never compile here: this process may already have touched the GPU, and a silent rebuild would hide the mismatch
+            raise RuntimeError(f"{LIB_PATH} was built from other sources than the ones in the tree (build id {built_id()} != "
+                               f"{source_id()}): run `python -c 'import __graft_entry__ as g; g.build()'` first")
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export what diffsg.h declares

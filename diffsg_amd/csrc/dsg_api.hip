@@ -4,6 +4,7 @@
 #include "dsg_kernels.hpp"
 #include "dsg_train.hpp"
 #include "dsg_split.hpp"
+#include "dsg_wide.hpp"
 #include "dsg_train_split.hpp"
 #include "dsg_eval.hpp"
 #include "dsg_labelgen.hpp"
@@ -103,6 +104,9 @@ struct Op {
     std::string name;
 };
 
+// launches with fewer row tiles than this leave SIMDs idle with one wave per tile (dsg_set_launch_policy)
+constexpr int kCoopMaxTilesDefault = 512, kNarrowSmallMaxTilesDefault = 1024;
+
 }  // namespace
 
 struct dsg_handle {
@@ -130,6 +134,9 @@ struct dsg_handle {
 
     // fp16-split path (dsg_split.hpp): wide blocks of the sampling loop
     bool use_split = true;
+    // launch policy (dsg_set_launch_policy): launches of at most this many row tiles take the small-launch kernel forms
+    int coop_max_tiles = kCoopMaxTilesDefault;          // wide blocks: k_resblock_c (N/32 waves per tile) and no pair kernels
+    int narrow_small_max_tiles = kNarrowSmallMaxTilesDefault; // narrow run: k_fused_narrow_h<true> (first-step planes requested a stage ahead)
     float* maxabs = nullptr;           // [params]: max|W| per tensor, refreshed at every bind
     const float** mx_ptrs_dev = nullptr; long long* mx_numel_dev = nullptr; int* mx_idx_dev = nullptr; int mx_n = 0;
     std::vector<int> mx_param;         // param index of each k_maxabs block
@@ -582,19 +589,18 @@ void launch_res_h_n(bool sclin, const BlockArgsH& a, hipStream_t s) {
 }
 // launches with fewer row tiles than this leave SIMDs idle with one wave per tile: the wide blocks then run cooperatively
 // (N/32 waves per tile, k_resblock_c)
-constexpr int kCoopMaxTilesDefault = 512;
-int coop_max_tiles() {
-    static const int v = [] { const char* e = getenv("DSG_COOP_MAX"); return e ? atoi(e) : kCoopMaxTilesDefault; }();
-    return v;
+
+// k_wide128_h: 128-wide block whose inputs are one or two 128-wide tensors, condition embedding precomputed
+bool wide128_ok(const ResP& r, const BlockArgs& b) {
+    return r.N == 128 && b.in0.groups == 16 && (b.in1.groups == 0 || b.in1.groups == 16) && (b.in1.groups != 0) == r.sclin && b.cond_pre;
 }
-#define kCoopMaxTiles coop_max_tiles()
 
 void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStream_t s) {
     BlockArgsH a;
     fill_block_args_h(h, r, b, a);
     const int ks1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2;
     const bool coop_fits = ks1 * 128 <= kCoopLdsU4 / (4 / (r.N / 32 > 0 ? r.N / 32 : 1)) / 2 && ks1 <= (r.sclin ? r.N / 8 : r.N / 16);   // LDS images, register bound
-    if ((r.N == 64 || r.N == 128) && coop_fits && a.b.ntiles <= kCoopMaxTiles && !getenv("DSG_NO_COOP")) {
+    if ((r.N == 64 || r.N == 128) && coop_fits && a.b.ntiles <= h->coop_max_tiles) {
         const int tpw = 4 / (r.N / 32);
         const dim3 grid(cdiv(a.b.ntiles, tpw)), block(256);
         if (r.N == 128) {
@@ -604,6 +610,16 @@ void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStr
             if (r.sclin) hipLaunchKernelGGL((k_resblock_c<64, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_resblock_c<64, false>), grid, block, 0, s, a);
         }
+        return;
+    }
+    if (wide128_ok(r, a.b)) {
+        // large launch, 128 wide: 4 tiles per workgroup, weight planes shared through an LDS ring (dsg_wide.hpp)
+        BlockLinArgsH w;
+        memset(&w, 0, sizeof w);
+        w.b = a; w.store_block_out = 1;
+        const dim3 grid(cdiv(a.b.ntiles, 4)), block(256);
+        if (r.sclin) hipLaunchKernelGGL((k_wide128_h<true, 0, 1>), grid, block, 0, s, w);
+        else hipLaunchKernelGGL((k_wide128_h<false, 0, 1>), grid, block, 0, s, w);
         return;
     }
     switch (r.N) {
@@ -640,6 +656,15 @@ bool launch_res_lin_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, co
     a.store_block_out = store_block_out ? 1 : 0;
     const dim3 grid(cdiv(b.ntiles, kWavesPerBlock)), block(256);
     const int NTO = cdiv(l.l.N, 32);
+    if (wide128_ok(r, b) && l.l.K == 128) {
+#define DSG_TRYW(SC_, EPI_, NTO_)                                                                            \
+    if (r.sclin == SC_ && (final_op ? 2 : 1) == EPI_ && NTO == NTO_) {                                       \
+        hipLaunchKernelGGL((k_wide128_h<SC_, EPI_, NTO_>), grid, block, 0, s, a);                            \
+        return true;                                                                                         \
+    }
+        DSG_TRYW(false, 1, 2) DSG_TRYW(false, 1, 1) DSG_TRYW(true, 2, 1) DSG_TRYW(true, 2, 3)
+#undef DSG_TRYW
+    }
 #define DSG_TRY(N_, SC_, NTO_, FIN_)                                                                         \
     if (r.N == N_ && r.sclin == SC_ && NTO == NTO_ && final_op == FIN_) {                                    \
         hipLaunchKernelGGL((k_resblock_lin_h<N_, SC_, NTO_, FIN_>), grid, block, 0, s, a);                   \
@@ -743,7 +768,7 @@ void launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     if (split_ctx(h, c)) {
         // small launches: the latency of one wave is the kernel time -> first-step weight planes requested a stage ahead
         const FusedOpH* tab = c.train ? h->fusedh_train_dev : h->fusedh_dev;
-        if (ntiles <= 2 * kCoopMaxTiles) hipLaunchKernelGGL(k_fused_narrow_h<true>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
+        if (ntiles <= h->narrow_small_max_tiles) hipLaunchKernelGGL(k_fused_narrow_h<true>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
         else hipLaunchKernelGGL(k_fused_narrow_h<false>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
     }
     else hipLaunchKernelGGL(k_fused_narrow, grid, block, 0, s, h->fused_dev, h->fuse_hi - h->fuse_lo, ntiles);
@@ -759,7 +784,7 @@ bool try_pair(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
     if (fuse && i + 1 >= h->fuse_lo && i < h->fuse_hi) return false;
     const ResP& r = h->res[a.p];
     if (r.N < 64) return false;
-    if (cdiv(c.nrows, 32) * c.npass <= kCoopMaxTiles && !getenv("DSG_NO_COOP")) return false;   // small launch: cooperative block, then the Linear
+    if (cdiv(c.nrows, 32) * c.npass <= h->coop_max_tiles) return false;   // small launch: cooperative block, then the Linear
     BlockArgs ba; LinArgs la;
     fill_block_args(h, a, c, ba);
     fill_lin_args(h, b, c, la);
@@ -1092,6 +1117,15 @@ extern "C" {
 
 const char* dsg_last_error(void) { return g_err.c_str(); }
 
+#ifndef DSG_BUILD_ID_STR
+#define DSG_BUILD_ID_STR "unknown"
+#endif
+// "DSG_BUILD_ID=<sha256 of the sources>": _lib.py compares it with the tree before loading (a stale binary must not pass tests)
+const char* dsg_build_id(void) {
+    static const char id[] = "DSG_BUILD_ID=" DSG_BUILD_ID_STR;
+    return id + 13;
+}
+
 dsg_handle* dsg_create(const dsg_unet_desc* desc) {
     if (!desc) { fail("null desc"); return nullptr; }
     const dsg_unet_desc d = *desc;
@@ -1247,7 +1281,10 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
     hipStream_t s = (hipStream_t)stream;
     const bool same = h->bound && h->bound_ptrs.size() == (size_t)n && memcmp(h->bound_ptrs.data(), ptrs, n * sizeof(float*)) == 0;
     if (!same) {
-        // (re)build the pack descriptor table: ONE grouped launch re-packs everything after each optimizer step
+        // (re)build the pack descriptor table: ONE grouped launch re-packs everything after each optimizer step.
+        // The tables below are rewritten with synchronous copies: kernels of an earlier call on `s` (a non-blocking stream
+        // does not order with them) may still be reading the old ones
+        HIPCK(hipStreamSynchronize(s));
         for (int i = 0; i < n; ++i) h->params[i].ptr = ptrs[i];
         h->bound_ptrs.assign(ptrs, ptrs + n);
         const Param* P = h->params.data();
@@ -1394,6 +1431,18 @@ int dsg_set_precision(dsg_handle* h, int mode) {
     if (mode != DSG_PRECISION_SPLIT_F16 && mode != DSG_PRECISION_F32_MFMA) return fail("unknown precision mode %d", mode);
     const bool split = mode == DSG_PRECISION_SPLIT_F16;
     if (split != h->use_split) { (void)hipDeviceSynchronize(); free_graphs(h); h->use_split = split; }
+    return 0;
+}
+
+int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_max_tiles) {
+    if (!h) return fail("null handle");
+    const int c = coop_max_tiles < 0 ? kCoopMaxTilesDefault : coop_max_tiles;
+    const int n = narrow_small_max_tiles < 0 ? kNarrowSmallMaxTilesDefault : narrow_small_max_tiles;
+    if (c != h->coop_max_tiles || n != h->narrow_small_max_tiles) {
+        (void)hipDeviceSynchronize();
+        free_graphs(h);                 // the captured step graphs hold the kernel forms chosen at capture time
+        h->coop_max_tiles = c; h->narrow_small_max_tiles = n;
+    }
     return 0;
 }
 

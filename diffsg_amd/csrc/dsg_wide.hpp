@@ -1,0 +1,452 @@
+// 128-wide ResidualBlocks for LARGE launches: the four waves of a workgroup share every weight plane through LDS.
+//
+// Why (profiles/r01i_pmc_summary.txt): with one wave per 32-row tile fetching its own weight planes
+// (k_resblock_h), a 256 -> 128 up block moves 384 KiB of packed planes from L2 per tile -- 8 of a wave's 10 vector loads per
+// k16-step, every wave of a workgroup fetching the same bytes: 1.5 GB of L2 -> CU traffic per launch, ~64 GB/s per CU, which
+// is what a CU can pull out of its XCD's L2 (MI355X guide: 66-73 GB/s per CU for L2-served rows).  The kernel was bound by
+// that, not by its MFMA (27 % busy) or VALU issue.  Here a workgroup = 4 waves = 4 row tiles streams each plane ONCE into
+// an LDS ring with LDS-DMA (`global_load_lds_dwordx4`: no staging registers, no register rotation of prefetched
+// operands) and all four waves read it with ds_read_b128: 4x less L2 traffic, 256 B/clk of LDS bandwidth instead of
+// 64 B/clk of vector-L1 return path.  The private operands of a wave (its tile of the input tensors, the precomputed
+// condition embedding) travel through the same ring, so that no compiler-visible vector load sits between two stages
+// (hipcc's own s_waitcnt for such a load would drain the DMA queue: guide, "three .s-level traps").
+//
+// Ring: kRingChunks slots of 8 KiB; a chunk = 8 pieces of 1 KiB (= one wave-wide b128 access); wave w issues pieces 2w and
+// 2w+1 of every chunk (one asm statement: two DMAs, the second through the instruction offset, which moves the global AND the
+// LDS address).  The producer runs kRingDist chunks ahead of the consumer, across stage boundaries.  An EVENT consumes 1-3
+// chunks: counted `s_waitcnt vmcnt(2 * chunks still in flight)`, raw s_barrier (every wave's pieces have landed; every wave
+// is done with the previous event's slots), issue as many chunks as the event consumes, read.  A shared (weight) chunk holds
+// the hi/lo planes of ONE k16-step for the 4 out tiles; a private chunk holds two 8-feature groups per wave.
+//
+// Arithmetic per element is that of resblock_body_h (same packed planes, same scales, same accumulation order per
+// accumulator), except that -log2(e) is folded into the staged LayerNorm vectors (one VALU less per element: the SiLU's
+// exponent argument is the LayerNorm output itself).
+#pragma once
+#include "dsg_split.hpp"
+
+namespace dsg {
+
+constexpr int kRingChunks = 9;     // 72 KiB; two workgroups per CU
+constexpr int kRingDist = 6;       // chunks in flight ahead of the consumer
+constexpr int kChunkU4 = 512;      // uint4 per chunk
+constexpr int kWideVec = 2 * kLnLdsW1 + 10 * 128;   // floats: LN1 | LN2 | LN3 (gamma', beta'), time bias, c2, c3, epilogue LN + bias
+
+// two 1 KiB pieces: global (wave-uniform base + per-lane byte offset) -> LDS (wave-uniform address, lane-linear)
+__device__ __forceinline__ void glds_pair(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void wide_wait_vm(int n) {   // n = DMAs of this wave that may stay in flight (wave-uniform)
+    switch (n) {
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// The chunk program of one block (+ optional Linear epilogue), as seen by ONE wave: where chunk c comes from.
+struct WideProg {
+    int cA, cB, cC, cD, cE, cF;   // cumulative ends of: stage 1 (x, W1 per step) | stage 2 (W2) | condition embedding (private) |
+                                  // stage 3 (W3) | shortcut (x, Wsc per step) or residual re-read (private) | epilogue Linear
+    int ks0;                      // k16-steps of in0 (the rest of stage 1 reads in1)
+    const float *x0, *x1, *cp;    // this wave's tile of in0 / in1 / cond_pre
+    const uint4 *w1, *w2, *w3, *wsc, *wl;   // this wave's out tile of each packed matrix (step 0, hi plane)
+    int lin_spc;                  // epilogue Linear: k16-steps per chunk (4 / pow2(NTO))
+    bool sclin;
+    unsigned voff;                // lane * 16
+    unsigned lds_w;               // LDS byte address of this wave's first piece of slot 0
+
+    __device__ __forceinline__ void issue(int c, int slot) const {
+        const void* src;
+        if (c < cA) {
+            const int S = c >> 1;
+            if (c & 1) src = w1 + (size_t)S * 128;
+            else src = S < ks0 ? (const void*)(x0 + (size_t)S * 512) : (const void*)(x1 + (size_t)(S - ks0) * 512);
+        } else if (c < cB) {
+            src = w2 + (size_t)(c - cA) * 128;
+        } else if (c < cC) {
+            src = cp + (size_t)(c - cB) * 512;
+        } else if (c < cD) {
+            src = w3 + (size_t)(c - cC) * 128;
+        } else if (c < cE) {
+            const int i = c - cD;
+            if (sclin) {
+                const int S = i >> 1;
+                if (i & 1) src = wsc + (size_t)S * 128;
+                else src = S < ks0 ? (const void*)(x0 + (size_t)S * 512) : (const void*)(x1 + (size_t)(S - ks0) * 512);
+            } else {
+                src = x0 + (size_t)i * 512;
+            }
+        } else {
+            src = wl + (size_t)(c - cE) * lin_spc * 128;
+        }
+        glds_pair(voff, src, lds_w + (unsigned)slot * 8192u);
+    }
+};
+
+struct WideRing {
+    const uint4* rd;   // the ring as ordinary LDS (+ lane)
+    int gc, pi;        // chunks consumed / issued so far
+    int sc, sp;        // slot of chunk gc / of chunk pi
+    int total;
+};
+
+__device__ __forceinline__ int ring_next(int s, int n = 1) { return s + n >= kRingChunks ? s + n - kRingChunks : s + n; }
+
+// Consume NEV chunks: returns the slot of the first one (the others follow, modulo the ring).
+template <int NEV>
+__device__ __forceinline__ int wide_event(WideRing& r, const WideProg& p) {
+    wide_wait_vm(2 * (r.pi - r.gc - NEV));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < NEV; ++i)
+        if (r.pi < r.total) { p.issue(r.pi, r.sp); ++r.pi; r.sp = ring_next(r.sp); }
+    const int s = r.sc;
+    r.gc += NEV;
+    r.sc = ring_next(r.sc, NEV);
+    return s;
+}
+
+// 16 * silu(u) from u' = -log2(e) * u:  p = 2^u' = e^-u;  16 u / (1 + p) = u' / ((1 + p) * (-log2(e) / 16))
+__device__ __forceinline__ float silu_scaled_l2(float up) {
+    constexpr float k = -1.44269504088896341f / kActScale;
+    const float p = __builtin_amdgcn_exp2f(up);
+    return up * __builtin_amdgcn_rcpf(fmaf(p, k, k));
+}
+// gv / bv: gamma' and beta' of the 8 features (already times -log2 e)
+__device__ __forceinline__ void act8_l2(float (&v)[8], const float (&x)[8], float c, float d, const float4 g0, const float4 b0, const float4 g1,
+                                        const float4 b1) {
+    v[0] = silu_scaled_l2(fmaf(fmaf(x[0], c, d), g0.x, b0.x)); v[1] = silu_scaled_l2(fmaf(fmaf(x[1], c, d), g0.y, b0.y));
+    v[2] = silu_scaled_l2(fmaf(fmaf(x[2], c, d), g0.z, b0.z)); v[3] = silu_scaled_l2(fmaf(fmaf(x[3], c, d), g0.w, b0.w));
+    v[4] = silu_scaled_l2(fmaf(fmaf(x[4], c, d), g1.x, b1.x)); v[5] = silu_scaled_l2(fmaf(fmaf(x[5], c, d), g1.y, b1.y));
+    v[6] = silu_scaled_l2(fmaf(fmaf(x[6], c, d), g1.z, b1.z)); v[7] = silu_scaled_l2(fmaf(fmaf(x[7], c, d), g1.w, b1.w));
+}
+
+template <int NT>
+__device__ __forceinline__ void ring_wfrag(HFrag<NT>& w, const uint4* slot /* + lane */) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { w.hi[nt] = slot[(2 * nt) * 64]; w.lo[nt] = slot[(2 * nt + 1) * 64]; }
+}
+
+template <int NT>
+__device__ __forceinline__ void wacc_zero(f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+}
+
+// register-fed stage over the ring: out += W * split(16 silu(LN(in))), one chunk (= one k16-step, 4 out tiles) per event
+__device__ __forceinline__ void wide_stage_reg(f32x16 (&out)[4], const f32x16 (&in)[4], WideRing& r, const WideProg& p, const float* gamma,
+                                               const float* beta, float mean, float rstd, int h) {
+    const float c = rstd, d = -mean * rstd;
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+        const int s = wide_event<1>(r, p);
+        HFrag<4> w;
+        ring_wfrag<4>(w, r.rd + s * kChunkU4);
+        const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
+        const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
+        const int t = S >> 1, r0 = 8 * (S & 1);
+        const float x[8] = {in[t][r0], in[t][r0 + 1], in[t][r0 + 2], in[t][r0 + 3], in[t][r0 + 4], in[t][r0 + 5], in[t][r0 + 6], in[t][r0 + 7]};
+        float v[8];
+        act8_l2(v, x, c, d, g0, b0, g1, b1);
+        h8 bhi, blo;
+        split8(v, bhi, blo);
+        mfma_step_h<4>(out, w, bhi, blo);
+    }
+}
+
+// memory-fed stage over the ring: per k16-step one private chunk (this wave's two groups of x) and one weight chunk
+template <bool LNACT>
+__device__ __forceinline__ void wide_stage_mem(f32x16 (&acc)[4], int steps, WideRing& r, const WideProg& p, int wave, const float* gamma,
+                                               const float* beta, float mean, float rstd, int h) {
+    const float c = rstd, d = -mean * rstd;
+    for (int S = 0; S < steps; ++S) {
+        const int s0 = wide_event<2>(r, p), s1 = ring_next(s0);
+        const uint4* xs = r.rd + s0 * kChunkU4 + (2 * wave) * 64;
+        const float4 xa = __builtin_bit_cast(float4, xs[0]), xb = __builtin_bit_cast(float4, xs[64]);
+        HFrag<4> w;
+        ring_wfrag<4>(w, r.rd + s1 * kChunkU4);
+        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        float v[8];
+        if (LNACT) {
+            const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
+            const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
+            act8_l2(v, x, c, d, g0, b0, g1, b1);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = kRawScale * x[q];
+        }
+        h8 bhi, blo;
+        split8(v, bhi, blo);
+        mfma_step_h<4>(acc, w, bhi, blo);
+    }
+}
+
+// acc += private tensor (16 groups of this wave's tile), two chunks (4 groups = one accumulator tile) per event
+__device__ __forceinline__ void wide_add_private(f32x16 (&acc)[4], WideRing& r, const WideProg& p, int wave, bool take) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int s0 = wide_event<2>(r, p), s1 = ring_next(s0);
+        if (take) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4* src = r.rd + (q < 2 ? s0 : s1) * kChunkU4 + (2 * wave + (q & 1)) * 64;
+                const float4 cv = __builtin_bit_cast(float4, src[0]);
+                acc[e][4 * q + 0] += cv.x; acc[e][4 * q + 1] += cv.y; acc[e][4 * q + 2] += cv.z; acc[e][4 * q + 3] += cv.w;
+            }
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_unscale_add_lds(f32x16 (&acc)[NT], float inv, const float* vec, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = ld4(vec + 32 * nt + 8 * q + 4 * h);
+            acc[nt][4 * q + 0] = fmaf(acc[nt][4 * q + 0], inv, b.x); acc[nt][4 * q + 1] = fmaf(acc[nt][4 * q + 1], inv, b.y);
+            acc[nt][4 * q + 2] = fmaf(acc[nt][4 * q + 2], inv, b.z); acc[nt][4 * q + 3] = fmaf(acc[nt][4 * q + 3], inv, b.w);
+        }
+}
+
+// EPI: 0 = block only, 1 = + raw Linear (Down/Upsample), 2 = + final (LayerNorm + SiLU + Linear, row-major out)
+template <bool SCLIN, int EPI, int NTO>
+__global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
+    constexpr int N = 128, NT = 4, NG = 16;
+    constexpr int NTOP = NTO <= 1 ? 1 : (NTO == 2 ? 2 : 4), SPC = 4 / NTOP;       // epilogue Linear: k16-steps per chunk
+    __shared__ uint4 lds[kRingChunks * kChunkU4 + kWideVec / 4];
+    float* const vec = reinterpret_cast<float*>(lds + kRingChunks * kChunkU4);
+    float* const g1v = vec, * const b1v = vec + kLnLdsW1, * const v2 = vec + 2 * kLnLdsW1;
+    float* const g2v = v2, * const b2v = v2 + 128, * const g3v = v2 + 256, * const b3v = v2 + 384, * const tbv = v2 + 512, * const c2v = v2 + 640,
+         * const c3v = v2 + 768, * const gLv = v2 + 896, * const bLv = v2 + 1024, * const biasLv = v2 + 1152;
+    const BlockArgsH& ah = A.b;
+    const BlockArgs& a = ah.b;
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_raw = blockIdx.x * 4 + wave;
+    const bool live = tile_raw < a.ntiles;                 // idle waves of the last workgroup still move their pieces and meet the barriers
+    const int tile = live ? tile_raw : a.ntiles - 1;
+    const int ptile = tile % a.tiles_per_pass;
+    const int ks0 = a.in0.groups >> 1, ks1 = a.in1.groups >> 1, KS1 = ks0 + ks1;
+    const int last_tile = blockIdx.x * 4 + 3 < a.ntiles ? blockIdx.x * 4 + 3 : a.ntiles - 1;
+    const bool wg_cond = last_tile >= a.uncond_tiles, my_cond = tile >= a.uncond_tiles;
+    constexpr float kL2 = -1.44269504088896341f;
+
+    // ---- per-feature vectors -> LDS (LayerNorm vectors times -log2 e)
+    {
+        const int n1 = ln1_extent(a);
+        for (int i = threadIdx.x; i < n1; i += 256) { g1v[i] = a.gamma1[i] * kL2; b1v[i] = a.beta1[i] * kL2; }
+        if (threadIdx.x < 128) {
+            const int i = threadIdx.x;
+            g2v[i] = a.gamma2[i] * kL2; b2v[i] = a.beta2[i] * kL2; g3v[i] = a.gamma3[i] * kL2; b3v[i] = a.beta3[i] * kL2;
+            c2v[i] = a.c2[i]; c3v[i] = a.c3[i];
+            if (!a.ts) tbv[i] = a.tbias[(size_t)(a.step_ptr ? *a.step_ptr : 0) * a.tb_stride + i];
+            if (EPI == 2) { gLv[i] = A.l.l.gamma[i] * kL2; bLv[i] = A.l.l.beta[i] * kL2; }
+            if (EPI != 0) biasLv[i] = i < NTO * 32 ? A.l.l.bias[i] : 0.f;
+        }
+    }
+    // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as resblock_body_h
+    float mean1, rstd1;
+    {
+        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)seg_tile(a.in0, tile) * 32 + j];
+        float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
+        if (a.in1.groups) {
+            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)seg_tile(a.in1, tile) * 32 + j];
+            const float n1 = (float)a.in1.width, nt_ = n + n1;
+            const float dd = s1.x - mean;
+            m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
+            mean = mean + dd * (n1 / nt_);
+            n = nt_;
+        }
+        mean1 = mean;
+        rstd1 = rsqrtf(m2 / n + kLnEps);
+    }
+    const int e1 = scale_exp(*ah.m1), e2 = scale_exp(*ah.m2);
+    const int e3 = SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3);
+    const float inv1 = ldexpf(1.0f / kActScale, -e1), inv2 = ldexpf(1.0f / kActScale, -e2), inv3 = ldexpf(1.0f / kActScale, -e3);
+    int entry = 0;
+    if (a.ts) {
+        int row = ptile * 32 + j;
+        row = row < a.nrows ? row : a.nrows - 1;
+        entry = a.ts[row];
+    }
+
+    // ---- chunk program
+    WideProg p;
+    p.ks0 = ks0; p.sclin = SCLIN; p.lin_spc = SPC;
+    p.cA = 2 * KS1; p.cB = p.cA + 8; p.cC = p.cB + (wg_cond ? 8 : 0); p.cD = p.cC + 8; p.cE = p.cD + (SCLIN ? 2 * KS1 : 8);
+    p.cF = p.cE + (EPI != 0 ? 8 / SPC : 0);
+    p.x0 = a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256;
+    p.x1 = a.in1.groups ? a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 : p.x0;
+    p.cp = a.cond_pre + (size_t)ptile * NG * 256;
+    p.w1 = ah.W1h + (size_t)wave * KS1 * 128; p.w2 = ah.W2h + (size_t)wave * 8 * 128; p.w3 = ah.W3h + (size_t)wave * 8 * 128;
+    p.wsc = SCLIN ? ah.Wsch + (size_t)wave * KS1 * 128 : p.w1;
+    if (EPI != 0) {
+        const int nt = wave % NTOP, sl = wave / NTOP;                     // wave -> (out tile, step within the chunk); tiles >= NTO: reload tile 0
+        p.wl = A.l.Wh + (size_t)(nt < NTO ? nt : 0) * 8 * 128 + (size_t)sl * 128;
+    } else {
+        p.wl = p.w1;
+    }
+    p.voff = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds;
+    p.lds_w = lds0 + (unsigned)wave * 2048u;
+    WideRing r;
+    r.rd = lds + lane; r.gc = 0; r.pi = 0; r.sc = 0; r.sp = 0; r.total = p.cF;
+    __syncthreads();                                        // the staged vectors are visible; no DMA is in flight yet
+#pragma unroll
+    for (int i = 0; i < kRingDist; ++i) { p.issue(r.pi, r.sp); ++r.pi; r.sp = ring_next(r.sp); }
+
+    // ---- stage 1
+    f32x16 acc1[NT];
+    wacc_zero<NT>(acc1);
+    wide_stage_mem<true>(acc1, KS1, r, p, wave, g1v, b1v, mean1, rstd1, h);
+    if (a.ts) acc_unscale_add<NT>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
+    else acc_unscale_add_lds<NT>(acc1, inv1, tbv, h);
+    if (a.save_h1 && live) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+            st4(a.save_h1 + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc1[G >> 2][4 * (G & 3)], acc1[G >> 2][4 * (G & 3) + 1], acc1[G >> 2][4 * (G & 3) + 2], acc1[G >> 2][4 * (G & 3) + 3]));
+    }
+
+    // ---- stage 2
+    f32x16 acc2[NT];
+    wacc_zero<NT>(acc2);
+    {
+        float mean, m2;
+        acc_stats<N, NT>(acc1, h, mean, m2);
+        wide_stage_reg(acc2, acc1, r, p, g2v, b2v, mean, rsqrtf(m2 * (1.0f / N) + kLnEps), h);
+        acc_unscale_add_lds<NT>(acc2, inv2, c2v, h);
+    }
+    if (wg_cond) wide_add_private(acc2, r, p, wave, my_cond);
+    if (a.save_h2 && live) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+            st4(a.save_h2 + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc2[G >> 2][4 * (G & 3)], acc2[G >> 2][4 * (G & 3) + 1], acc2[G >> 2][4 * (G & 3) + 2], acc2[G >> 2][4 * (G & 3) + 3]));
+    }
+
+    // ---- stage 3 (+ shortcut in the same scaled accumulator)
+    f32x16 (&acc3)[NT] = acc1;
+    wacc_zero<NT>(acc3);
+    {
+        float mean, m2;
+        acc_stats<N, NT>(acc2, h, mean, m2);
+        wide_stage_reg(acc3, acc2, r, p, g3v, b3v, mean, rsqrtf(m2 * (1.0f / N) + kLnEps), h);
+    }
+    if (SCLIN) {
+        wide_stage_mem<false>(acc3, KS1, r, p, wave, nullptr, nullptr, 0.f, 1.f, h);
+        acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
+    } else {
+        acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
+        wide_add_private(acc3, r, p, wave, true);
+    }
+
+    // ---- statistics + store
+    float xmean, xm2;
+    acc_stats<N, NT>(acc3, h, xmean, xm2);
+    if ((EPI == 0 || A.store_block_out) && live) {
+        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
+#pragma unroll
+        for (int G = 0; G < NG; ++G)
+            st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2], acc3[G >> 2][4 * (G & 3) + 3]));
+    }
+    if (EPI == 0) return;
+
+    // ---- epilogue Linear over the ring: a chunk holds SPC k16-steps x NTOP out tiles
+    const LinArgs& la = A.l.l;
+    f32x16 acc[NTO];
+    wacc_zero<NTO>(acc);
+    {
+        const float c = EPI == 2 ? rsqrtf(xm2 / (float)la.in_width + kLnEps) : 1.f, d = -xmean * c;
+#pragma unroll
+        for (int ch = 0; ch < 8 / SPC; ++ch) {
+            const int s = wide_event<1>(r, p);
+#pragma unroll
+            for (int sl = 0; sl < SPC; ++sl) {
+                const int S = ch * SPC + sl, t = S >> 1, r0 = 8 * (S & 1);
+                HFrag<NTO> w;
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    w.hi[nt] = r.rd[s * kChunkU4 + ((sl * NTOP + nt) * 2) * 64];
+                    w.lo[nt] = r.rd[s * kChunkU4 + ((sl * NTOP + nt) * 2 + 1) * 64];
+                }
+                const float x[8] = {acc3[t][r0], acc3[t][r0 + 1], acc3[t][r0 + 2], acc3[t][r0 + 3], acc3[t][r0 + 4], acc3[t][r0 + 5], acc3[t][r0 + 6],
+                                    acc3[t][r0 + 7]};
+                float v[8];
+                if (EPI == 2) {
+                    const float4 g0 = ld4(gLv + 16 * S + 4 * h), b0 = ld4(bLv + 16 * S + 4 * h);
+                    const float4 g1 = ld4(gLv + 16 * S + 8 + 4 * h), b1 = ld4(bLv + 16 * S + 8 + 4 * h);
+                    act8_l2(v, x, c, d, g0, b0, g1, b1);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = kRawScale * x[q];
+                }
+                h8 bhi, blo;
+                split8(v, bhi, blo);
+                mfma_step_h<NTO>(acc, w, bhi, blo);
+            }
+        }
+    }
+    acc_unscale_add_lds<NTO>(acc, ldexpf(1.0f / (EPI == 2 ? kActScale : kRawScale), -scale_exp(*A.l.m)), biasLv, h);
+    if (!live) return;
+    if (EPI == 1) {
+        const int NGo = (la.out_width + 7) / 8;
+        float s = 0.f;
+#pragma unroll
+        for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (8 * G + 4 * h + q < la.out_width) s += acc[G >> 2][4 * (G & 3) + q];
+        const float m = xhalf_sum(s) / (float)la.out_width;
+        float qq = 0.f;
+#pragma unroll
+        for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (8 * G + 4 * h + q < la.out_width) { const float dd = acc[G >> 2][4 * (G & 3) + q] - m; qq = fmaf(dd, dd, qq); }
+        qq = xhalf_sum(qq);
+        if (h == 0) reinterpret_cast<float2*>(la.out_stats)[(size_t)tile * 32 + j] = make_float2(m, qq);
+#pragma unroll
+        for (int G = 0; G < NTO * 4; ++G)
+            if (G < NGo)
+                st4(la.out + ((size_t)tile * NGo + G) * 256 + lane * 4,
+                    make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
+    } else {
+        const int pass = tile / la.tiles_per_pass, row = ptile * 32 + j;
+        if (row < la.nrows) {
+            float* o = la.out_rm + ((size_t)pass * la.nrows + row) * la.out_width;
+            if ((la.out_width & 3) == 0) {
+#pragma unroll
+                for (int G = 0; G < NTO * 4; ++G) {
+                    const int f = 8 * G + 4 * h;
+                    if (f < la.out_width)
+                        st4(o + f, make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
+                }
+            } else {
+#pragma unroll
+                for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f = 8 * G + 4 * h + q;
+                        if (f < la.out_width) o[f] = acc[G >> 2][4 * (G & 3) + q];
+                    }
+            }
+        }
+    }
+}
+
+}  // namespace dsg

@@ -23,6 +23,8 @@ def flatten_parameters(unet):
         flat[off:off + n].copy_(p.data.reshape(-1))
         p.data = flat[off:off + n].view_as(p)
         off += n
+    if hasattr(unet, "mark_weights_changed"):
+        unet.mark_weights_changed(rebuild=True)    # new storage behind the same Parameter objects
     return flat
 
 

@@ -34,6 +34,9 @@ typedef struct {
 dsg_handle* dsg_create(const dsg_unet_desc* desc);
 void dsg_destroy(dsg_handle* h);
 const char* dsg_last_error(void);
+/* sha256 of the sources this binary was built from (diffsg_amd/_lib.py refuses to load a library whose id differs from
+ * the tree's: a stale binary must not be what the parity tests and the bench run). */
+const char* dsg_build_id(void);
 
 /* Parameter table in UNet1D.state_dict() order: replaces nn.Module parameter registration,
  * UNetCF.py:272-316.  dsg_bind_weights takes one device pointer per entry, in this order, and packs the weights
@@ -48,12 +51,20 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
  *   DSG_PRECISION_SPLIT_F16 (default)  float32-accurate GEMMs as hi/lo fp16 splits on the f16 matrix cores, f32 accumulate
  *                                      (22 significant bits per operand);
  *   DSG_PRECISION_F32_MFMA             exact float32 v_mfma_f32_32x32x2_f32 (also selected by env DSG_PRECISION=f32).
- * Launches with at most 512 row tiles run the 64- and 128-wide blocks cooperatively (one tile per workgroup, N/32 waves);
- * env DSG_NO_COOP=1 keeps the one-wave-per-tile kernels there, DSG_COOP_MAX=<tiles> moves the threshold (A/B measurements).
- * Training and dsg_unet_forward always use the exact float32 kernels. */
+ * The mode applies to dsg_sample and to dsg_train_step (forward, data gradients and weight gradients); dsg_unet_forward
+ * always uses the exact float32 kernels. */
 #define DSG_PRECISION_SPLIT_F16 0
 #define DSG_PRECISION_F32_MFMA 1
 int dsg_set_precision(dsg_handle* h, int mode);
+
+/* Which FORM of the kernels a launch uses (same arithmetic per element, different work decomposition):
+ *   coop_max_tiles          launches of at most this many 32-row tiles (both CFG passes counted) run the 64/128-wide
+ *                           blocks cooperatively (one tile per workgroup, N/32 waves) and never as block+Linear pair
+ *                           kernels; larger launches run one wave per tile (weight planes shared through LDS) and pairs;
+ *   narrow_small_max_tiles  launches of at most this many tiles use the small-launch form of the fused narrow run.
+ * Defaults 512 / 1024; a negative value restores the default, 0 forces the large-launch forms at every size (the
+ * parity tests run every golden both ways).  Cached step graphs are dropped when the policy changes. */
+int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_max_tiles);
 
 /* Pre-size the workspace for up to `max_rows` batch rows and `max_entries` time-table rows. */
 int dsg_reserve(dsg_handle* h, int max_rows, int max_entries);

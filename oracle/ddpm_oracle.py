@@ -230,8 +230,18 @@ def ddpm_loss(p, plan, bufs, T, y, cond, ts, noise, cond_mask):
     return F.mse_loss(noise, eps_hat)
 
 
-def ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, cond_mask):
-    """Loss and d(loss)/d(param) for every denoiser tensor (autograd on CPU)."""
+def ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, cond_mask, f64=False):
+    """Loss and d(loss)/d(param) for every denoiser tensor (autograd on CPU).  f64=True evaluates the same graph in float64
+    (float32-valued parameters, buffers and inputs): the error budget of the reference's own float32 arithmetic."""
+    if f64:
+        leaf = OrderedDict((k, v.detach().double().requires_grad_(True)) for k, v in p.items())
+        b64 = {k: v.double() for k, v in bufs.items()}
+        y_t = q_sample(b64, y.double(), ts, noise.double())
+        eps_hat = unet_forward(leaf, plan, y_t, (ts / T).double(), cond.double(), cond_mask.double())
+        loss = F.mse_loss(noise.double(), eps_hat)
+        grads = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
+        return loss.detach(), OrderedDict(
+            (k, (g if g is not None else torch.zeros_like(v))) for (k, v), g in zip(leaf.items(), grads))
     leaf = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in p.items())
     loss = ddpm_loss(leaf, plan, bufs, T, y, cond, ts, noise, cond_mask)
     grads = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)

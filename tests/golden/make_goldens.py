@@ -10,7 +10,8 @@ committed.  Nothing here is imported by tests at run time except weights.py.
 Groups follow SURVEY.md section 8(c): G1 schedule, G2 denoiser forward (+ per
 module taps), G3 DDPM.forward loss/grads, G4 DDPM.sample trajectories (NU
 checkpoint + synthetic), G5 decoders/evaluators, G6 loaders on CSV slices,
-G7 state-dict layout + EMA, G8 the MSR label generator, G9 the CO self-check harness.
+G7 state-dict layout + EMA, G8 the MSR label generator, G9 the CO self-check harness,
+G10 DDPM.sample at T = 1000 (BASELINE config 2's schedule length).
 """
 import json
 import os
@@ -398,7 +399,47 @@ def g9():
     save("g9_co_validation.npz", **out)
 
 
+# ---------------------------------------------------------------- G10
+def g10():
+    """BASELINE config 2's schedule length: DDPM.sample at T = 1000 (MSR-3c, 16 rows), the reference's float32 result and a
+    float64 evaluation of the same trajectory (the error budget of 2 000 chained float32 forwards)."""
+    name, B, T, seed = "msr3", 16, 1000, 78
+    cfg = CONFIGS[name]
+    D, C = cfg["input_dim"], cfg["cond_dim"]
+    alphas = 1.0 - generate_cosine_schedule(T)
+    ddpm = RMSR.DDPM(T, ref_unet(cfg), D, 10.0, alphas, torch.device("cpu"), (1, D), None)
+    load_synth(ddpm.model, 31, "trained")
+    rs = np.random.RandomState(401)
+    cond = torch.from_numpy(rs.uniform(0, 1, (B, C)).astype(np.float32))
+    y_T, z = replay_sample_noise(seed, B, D, T)
+    out = dict(cond=cond.numpy(), y_T=y_T.numpy(), T=np.int64(T), z=np.stack([z[i].numpy() for i in range(T - 1, 1, -1)]))
+    with torch.no_grad():
+        for omega in (0.0, 1.0):
+            torch.manual_seed(seed)
+            out[f"om{omega:g}_y0"] = ddpm.sample(cond, omega).numpy()
+        d64 = RMSR.DDPM(T, ref_unet(cfg), D, 10.0, alphas, torch.device("cpu"), (1, D), None)
+        load_synth(d64.model, 31, "trained")
+        d64 = d64.double()
+        for omega in (0.0, 1.0):
+            y = y_T.double()
+            c64 = cond.double()
+            for i in range(T - 1, -1, -1):
+                t = (torch.full((1, B), i) / T).double()
+                e0 = d64.model(y, t, c64, torch.zeros(B, 1, dtype=torch.float64))
+                e1 = d64.model(y, t, c64, torch.ones(B, 1, dtype=torch.float64))
+                nz = z[i].double() if i > 1 else 0
+                e = (1 + omega) * e1 - omega * e0
+                y = (y - d64.betas[i] / d64.sqrt_one_minus_alphas_cumprod[i] * e) * d64.reciprocal_sqrt_alphas[i] \
+                    + (1.0 - d64.alphas_cumprod[i - 1 if i - 1 >= 0 else 0]) / (1.0 - d64.alphas_cumprod[i]) * nz
+                if i > T - 5:
+                    y = (y - torch.mean(y)) / torch.sqrt(torch.var(y))
+            out[f"om{omega:g}_y0_f64"] = y.numpy()
+            print("T=1000 omega", omega, "ref f32 vs f64 rel err",
+                  float(np.abs(out[f"om{omega:g}_y0"] - y.numpy()).max() / np.abs(y.numpy()).max()))
+    save("g4_sample_msr3_T1000.npz", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9)
+    groups = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

@@ -1,7 +1,12 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference-generated goldens.
 
-Tolerance: north_star asks for 1e-4 relative float32; every comparison below is `max|a-b| / max|b| <= tol` with the
-tol written at the call.  All tests need an MI355X: run with `-m gpu`.
+Tolerance: north_star asks for 1e-4 relative float32.  What is asserted is tighter, so that a regression inside the contract
+still shows: `max|a-b| / max|b| <= TOL = 1e-5` for every forward / sampling comparison at omega <= 3 (measured ~1.3e-6), and
+for gradients `max|g - ref| <= 1e-4 * max(max|ref of THAT tensor|, 1e-3 * max|ref of any tensor|)` (GTOL; per tensor, so
+that a small tensor cannot hide behind the largest one).  POLICIES runs a test twice: with the default launch policy
+(small launches take the cooperative / small-launch kernel forms) and with policy (0, 0), which forces the forms a
+65 536-row call uses -- one wave per tile with LDS-shared weights, block+Linear pair kernels, the large-launch narrow run
+-- onto the same goldens.  All tests need an MI355X: run with `-m gpu`.
 """
 import numpy as np
 import pytest
@@ -12,6 +17,28 @@ from oracle import ddpm_oracle as O
 from weights import CONFIGS
 
 pytestmark = pytest.mark.gpu
+
+TOL = 1e-5           # forward / sampling, omega <= 3
+GTOL = 1e-4          # gradients, per tensor (see grad_errs)
+POLICIES = ["default", "large"]
+
+
+def grad_errs(got, ref):
+    """{key: max|got - ref| / max(max|ref_k|, 1e-3 * global max|ref|)}: the error of every tensor on its own scale."""
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    return {k: float((got[k].detach().cpu().double() - ref[k].double()).abs().max()) / max(float(ref[k].abs().max()), 1e-3 * gmax)
+            for k in ref}
+
+
+def assert_grads(got, ref32, ref64, tag=""):
+    """Every gradient tensor within GTOL of the float32 reference on its own scale, plus what the float32 reference itself
+    is away from float64 there (x4: the split path carries 22-bit operands, float32 24): narrow LayerNorms (4-8 features)
+    amplify rounding, and the reference's own float32 gradients are up to 6e-5 off on this scale (tiny net)."""
+    errs, budget = grad_errs(got, ref32), grad_errs(ref32, ref64)
+    worst = max(errs, key=lambda k: errs[k] - 4.0 * budget[k])
+    print(f"{tag}: worst per-tensor grad err {errs[worst]:.2e} (reference f32 vs f64 there: {budget[worst]:.2e}) {worst}; "
+          f"max err {max(errs.values()):.2e}")
+    assert errs[worst] <= GTOL + 4.0 * budget[worst], (worst, errs[worst], budget[worst])
 
 
 def rel(a, b):
@@ -28,13 +55,16 @@ def make_model(name, params):
     return m.to("cuda")
 
 
-def make_ddpm(name, params, T):
+def make_ddpm(name, params, T, policy="default"):
     from diffsg_amd.classifier_free_MSR import DDPM
     cfg = CONFIGS[name]
     m = make_model(name, params)
     D = cfg["input_dim"]
     d = DDPM(T, m, D, 10.0, 1.0 - O.cosine_betas(T), torch.device("cuda"), (1, D), None)
-    return d.to("cuda")
+    d = d.to("cuda")
+    if policy == "large":
+        d.model.set_launch_policy(0, 0)
+    return d
 
 
 @pytest.mark.parametrize("name,flavour,seed", [
@@ -48,10 +78,10 @@ def test_unet_forward_vs_golden(gold, name, flavour, seed):
     B = x.shape[0]
     ts = torch.from_numpy(g["a_ts"]).cuda()
     eps = model(x, ts / int(g["a_T"]), cond, torch.from_numpy(g["a_mask"]).cuda())
-    assert rel(eps, g["a_eps"]) <= 1e-4
+    assert rel(eps, g["a_eps"]) <= TOL
     t = torch.full((1, B), int(g["b_step"]), dtype=torch.int64, device="cuda") / 20
-    assert rel(model(x, t, cond, torch.zeros(B, 1, device="cuda")), g["b_eps"]) <= 1e-4
-    assert rel(model(x, t, cond, torch.ones(B, 1, device="cuda")), g["c_eps"]) <= 1e-4
+    assert rel(model(x, t, cond, torch.zeros(B, 1, device="cuda")), g["b_eps"]) <= TOL
+    assert rel(model(x, t, cond, torch.ones(B, 1, device="cuda")), g["c_eps"]) <= TOL
 
 
 @pytest.mark.parametrize("name,B", [("msr80", 1), ("msr80", 31), ("msr80", 33), ("nu3", 257), ("co3", 64), ("msr3", 1000)])
@@ -68,7 +98,7 @@ def test_unet_forward_vs_oracle_ragged(name, B):
     with torch.no_grad():
         ref = O.unet_forward(p, plan, x, ts / 50, cond, mask)
     got = model(x.cuda(), (ts / 50).cuda(), cond.cuda(), mask.cuda())
-    assert rel(got, ref) <= 1e-4
+    assert rel(got, ref) <= TOL
 
 
 def _z(g, T):
@@ -88,14 +118,74 @@ def test_empty_batch_gives_empty_results():
 
 @pytest.mark.parametrize("name,T", [("tiny", 8), ("msr80", 6), ("msr3", 6), ("co3", 6), ("tiny", 3)])
 @pytest.mark.parametrize("graph", [True, False])
-def test_sample_vs_golden_synth(gold, name, T, graph):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_sample_vs_golden_synth(gold, name, T, graph, policy):
     g = gold(f"g4_sample_{name}_T{T}.npz")
     plan, p = synth_params(name, 31)
-    ddpm = make_ddpm(name, p, T)
+    ddpm = make_ddpm(name, p, T, policy)
     cond = torch.from_numpy(g["cond"]).cuda()
     for omega in (0.0, 1.0, 3.0):
         y0 = ddpm.sample(cond, omega, y_T=torch.from_numpy(g["y_T"]), noise=_z(g, T), use_graph=graph)
-        assert rel(y0, g[f"om{omega:g}_y0"]) <= 1e-4, omega
+        assert rel(y0, g[f"om{omega:g}_y0"]) <= TOL, omega
+
+
+@pytest.mark.parametrize("policy", POLICIES)
+def test_sample_T1000_vs_golden(gold, policy):
+    """BASELINE config 2's schedule length: 1 000 steps (1 000-entry time and coefficient tables, 2 000 chained forwards)
+    on the reference's own output (G10, MSR-3c, 16 rows); the reference's float32 run is itself 4.6e-6 from float64."""
+    g = gold("g4_sample_msr3_T1000.npz")
+    T = int(g["T"])
+    plan, p = synth_params("msr3", 31)
+    ddpm = make_ddpm("msr3", p, T, policy)
+    cond = torch.from_numpy(g["cond"]).cuda()
+    for omega in (0.0, 1.0):
+        y0 = ddpm.sample(cond, omega, y_T=torch.from_numpy(g["y_T"]), noise=torch.from_numpy(g["z"]))
+        e, e64 = rel(y0, g[f"om{omega:g}_y0"]), rel(y0, g[f"om{omega:g}_y0_f64"])
+        print(f"T=1000 {policy} omega={omega:g}: vs reference f32 {e:.2e}, vs float64 {e64:.2e}")
+        assert e <= 3e-5 and e64 <= 3e-5, omega
+
+
+def test_sample_T1000_full_size_properties():
+    """BASELINE config 2 as quoted (MSR-3c, 8 192 rows, T = 1000) through size-independent properties: duplicated rows give
+    bit-equal outputs after 1 000 steps, a seed reproduces, outputs are finite."""
+    plan, p = synth_params("msr3", 7)
+    T, B = 1000, 8192
+    ddpm = make_ddpm("msr3", p, T)
+    g = torch.Generator().manual_seed(0)
+    half = torch.rand(B // 2, 3, generator=g)
+    cond = torch.cat((half, half)).cuda()
+    yh = torch.randn(B // 2, 3, generator=g)
+    zh = torch.randn(T - 2, B // 2, 3, generator=g)
+    y0 = ddpm.sample(cond, 1.0, y_T=torch.cat((yh, yh)), noise=torch.cat((zh, zh), dim=1))
+    assert torch.isfinite(y0).all() and torch.equal(y0[: B // 2], y0[B // 2:])
+    a, b = ddpm.sample(cond, 1.0, seed=5), ddpm.sample(cond, 1.0, seed=5)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize("name,flavour,B,T,omega", [("msr80", "trained", 16384 + 33, 5, 2.0), ("msr80", "init", 65536, 3, 1.0),
+                                                    ("co3", "trained", 16384 + 7, 5, 2.0)])
+def test_sample_large_launch_vs_oracle(name, flavour, B, T, omega):
+    """The kernels a bench-size call runs (one wave per tile with LDS-shared weight planes, block+Linear pair kernels, the
+    large-launch narrow run, feature_proj shared by both CFG passes) DIRECTLY against the CPU oracle: 16 417 ragged rows,
+    and the north_star shape itself -- 65 536 x 80 with init_weights-flavour weights (the bench's)."""
+    plan, p = synth_params(name, 5, flavour)
+    cfg = CONFIGS[name]
+    ddpm = make_ddpm(name, p, T)
+    g = torch.Generator().manual_seed(9)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g)
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    y0 = ddpm.sample(cond.cuda(), omega, y_T=y_T, noise=z)
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    zd = {i: z[j] for j, i in enumerate(range(T - 1, 1, -1))}
+    with torch.no_grad():
+        ref = O.ddpm_sample(p, plan, bufs, T, cond, omega, y_T, zd)
+        ref64 = O.ddpm_sample({k: v.double() for k, v in p.items()}, plan, {k: v.double() for k, v in bufs.items()}, T, cond.double(), omega,
+                              y_T.double(), {i: v.double() for i, v in zd.items()})
+    e, budget = rel(y0, ref), rel(ref, ref64)
+    print(f"{name}/{flavour} B={B} T={T}: rel err vs oracle {e:.2e} (oracle float32 vs float64: {budget:.2e})")
+    # the worst row of 16 000+ sits further out than the 40-row goldens: the bound is the reference's own float32 error there
+    assert e <= TOL + 3.0 * budget
 
 
 @pytest.mark.parametrize("mode", ["split_f16", "f32"])
@@ -113,22 +203,23 @@ def test_sample_precision_modes_wide_blocks(gold, mode):
         y0 = ddpm.sample(cond, omega, y_T=torch.from_numpy(g["y_T"]), noise=_z(g, T))
         worst = max(worst, rel(y0, g[f"om{omega:g}_y0"]))
     print(f"{mode}: worst rel err {worst:.2e}")
-    assert worst <= (1e-4 if mode == "split_f16" else 2e-5)
+    assert worst <= TOL
 
 
-def test_sample_nu_checkpoint_known_answer(gold):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_sample_nu_checkpoint_known_answer(gold, policy):
     """The shipped NU checkpoint on its first 512 test rows: trajectory parity at small omega, and the
     task metric at omega=500, where float32 itself is only good to 2.6e-3 against float64."""
     g = gold("g4_sample_nu_ckpt.npz")
     p = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
     T = int(g["T"])
-    ddpm = make_ddpm("nu3", p, T)
+    ddpm = make_ddpm("nu3", p, T, policy)
     cond = torch.from_numpy(g["cond"]).cuda()
     y_T, z = torch.from_numpy(g["y_T"]), torch.from_numpy(g["z"])
     for omega in (0.0, 1.0):
         y0 = ddpm.sample(cond, omega, y_T=y_T, noise=z)
-        assert rel(y0, g[f"om{omega:g}_y0"]) <= 1e-4, omega
-        assert rel(y0, g[f"om{omega:g}_y0_f64"]) <= 1e-4, omega
+        assert rel(y0, g[f"om{omega:g}_y0"]) <= TOL, omega
+        assert rel(y0, g[f"om{omega:g}_y0_f64"]) <= TOL, omega
     y0 = ddpm.sample(cond, 500.0, y_T=y_T, noise=z)
     f64 = g["om500_y0_f64"]
     ref_err = rel(g["om500_y0"], f64)            # the reference's own float32 error against float64
@@ -161,13 +252,13 @@ def test_sample_large_launch_split_vs_exact_f32(name, B):
         out[mode] = ddpm.sample(cond, 2.0, y_T=y_T, noise=z)
     ddpm.model.set_precision("split_f16")
     assert torch.isfinite(out["f32"]).all()
-    assert rel(out["split_f16"], out["f32"]) <= 1e-4
+    assert rel(out["split_f16"], out["f32"]) <= 5e-5
     # and the small oracle check on a slice that spans the pass boundary tile: rows are independent after step T-5, but the
     # first steps couple them through the global renorm - so compare the full batch's statistics-free invariant instead:
     # duplicating the batch must reproduce the outputs row for row
     y2 = ddpm.sample(torch.cat((cond, cond)), 2.0, y_T=torch.cat((y_T, y_T)), noise=torch.cat((z, z), dim=1))
     assert torch.equal(y2[:B], y2[B:])
-    assert rel(y2[:B], out["split_f16"]) <= 1e-4
+    assert rel(y2[:B], out["split_f16"]) <= 5e-5
 
 
 def test_sample_full_size_properties():
@@ -229,11 +320,12 @@ def _train_inputs(g):
 
 
 @pytest.mark.parametrize("name", ["tiny", "nu3", "msr80"])
-def test_train_step_vs_reference_golden(gold, name):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_train_step_vs_reference_golden(gold, name, policy):
     g = gold(f"g3_loss_{name}.npz")
     plan, p = synth_params(name, 21)
     T = int(g["T"])
-    ddpm = make_ddpm(name, p, T)
+    ddpm = make_ddpm(name, p, T, policy)
     y, cond, ts, noise, mask = _train_inputs(g)
     loss = ddpm(y.cuda(), cond.cuda(), ts=ts.cuda(), noise=noise.cuda(), cond_mask=mask.cuda())
     loss.backward()
@@ -241,18 +333,19 @@ def test_train_step_vs_reference_golden(gold, name):
     bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
     _, ref = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask)
     gmax = max(float(v.abs().max()) for v in ref.values())
-    worst = 0.0
-    for k, prm in ddpm.model.named_parameters():
-        got = prm.grad.detach().cpu()
-        err = float((got - ref[k]).abs().max()) / gmax
-        worst = max(worst, err)
-        assert err <= 1e-4, (k, err)
+    got_all = {k: prm.grad for k, prm in ddpm.model.named_parameters()}
+    _, ref64 = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask, f64=True)
+    assert_grads(got_all, ref, ref64, f"{name}/{policy}")
+    budget = grad_errs(ref, ref64)
+    for k, got in got_all.items():
+        got = got.detach().cpu()
+        scale = max(float(ref[k].abs().max()), 1e-3 * gmax)     # the reference's own autograd output, same per-tensor scale
+        tol = GTOL + 4.0 * budget[k]
         if name == "tiny":
-            assert float(np.abs(got.numpy() - g["grad." + k]).max()) / gmax <= 1e-4, k
+            assert float(np.abs(got.numpy() - g["grad." + k]).max()) / scale <= tol, k
         else:
-            assert float(np.abs(got.reshape(-1)[:16].numpy() - g["gradhead." + k]).max()) / gmax <= 1e-4, k
+            assert float(np.abs(got.reshape(-1)[:16].numpy() - g["gradhead." + k]).max()) / scale <= tol, k
     assert all(q.grad is None for q in ddpm.ema.parameters())
-    print(f"{name}: worst grad err / max|grad| = {worst:.2e}")
 
 
 @pytest.mark.parametrize("name,B", [("msr80", 33), ("co3", 100), ("msr3", 512), ("nu3", 1)])
@@ -277,9 +370,33 @@ def test_train_step_vs_oracle_ragged(name, B):
     else:
         ref_loss, ref = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask)
     assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
-    gmax = max(float(v.abs().max()) for v in ref.values())
-    for k, prm in ddpm.model.named_parameters():
-        assert float((prm.grad.cpu() - ref[k]).abs().max()) / gmax <= 1e-4, k
+    if B == 1:
+        _, ref64 = O.ddpm_loss_and_grads(p, plan, bufs, T, y2, c2, ts.repeat(1, 2), n2, mask.repeat(2, 1), f64=True)
+    else:
+        _, ref64 = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask, f64=True)
+    assert_grads({k: q.grad for k, q in ddpm.model.named_parameters()}, ref, ref64, f"{name}/{B}")
+
+
+def test_train_step_large_launch_vs_oracle():
+    """BASELINE training shape (32 768 rows per GPU, + a ragged tail = 1 025 row tiles: the one-wave-per-tile forward,
+    k_resblock_bwd_h, the grouped k_wgrad_h) DIRECTLY against the CPU oracle's autograd: loss and every gradient."""
+    name, B, T = "msr80", 32768 + 17, 20
+    plan, p = synth_params(name, 13)
+    ddpm = make_ddpm(name, p, T)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(3)
+    y = torch.rand(B, cfg["input_dim"], generator=g) * 0.25
+    cond = torch.rand(B, cfg["cond_dim"], generator=g)
+    ts = torch.randint(0, T, (1, B), generator=g)
+    noise = torch.randn(B, cfg["input_dim"], generator=g)
+    mask = (torch.rand(B, 1, generator=g) < 0.9).float()
+    loss = ddpm(y.cuda(), cond.cuda(), ts=ts.cuda(), noise=noise.cuda(), cond_mask=mask.cuda())
+    loss.backward()
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    ref_loss, ref = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    _, ref64 = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask, f64=True)
+    assert_grads({k: q.grad for k, q in ddpm.model.named_parameters()}, ref, ref64, "train 32785 rows")
 
 
 def test_training_reduces_loss_and_matches_cpu_adam():
@@ -336,9 +453,9 @@ def test_train_step_large_launch_split_vs_exact_f32():
         res[mode] = (float(loss.detach()), {k: q.grad.detach().clone() for k, q in ddpm.model.named_parameters()})
     ddpm.model.set_precision("split_f16")
     assert abs(res["split_f16"][0] - res["f32"][0]) <= 1e-5 * abs(res["f32"][0])
-    gmax = max(float(v.abs().max()) for v in res["f32"][1].values())
-    for k, v in res["f32"][1].items():
-        assert float((res["split_f16"][1][k] - v).abs().max()) / gmax <= 1e-4, k
+    errs = grad_errs(res["split_f16"][1], {k: v.cpu() for k, v in res["f32"][1].items()})
+    worst = max(errs, key=errs.get)
+    assert errs[worst] <= GTOL, (worst, errs[worst])
 
 
 @pytest.mark.parametrize("name,B", [("msr80", 100), ("co3", 77)])
@@ -360,9 +477,8 @@ def test_train_step_exact_f32_mode(name, B):
     bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
     ref_loss, ref = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask)
     assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
-    gmax = max(float(v.abs().max()) for v in ref.values())
-    for k, prm in ddpm.model.named_parameters():
-        assert float((prm.grad.cpu() - ref[k]).abs().max()) / gmax <= 1e-4, k
+    _, ref64 = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask, f64=True)
+    assert_grads({k: q.grad for k, q in ddpm.model.named_parameters()}, ref, ref64, f"f32 mode {name}/{B}")
 
 
 @pytest.mark.parametrize("name,B", [("msr3", 512), ("msr80", 96)])
@@ -521,10 +637,10 @@ def test_record_denoise_path(gold):
     ddpm = make_ddpm("tiny", p, T)
     ddpm.record_denoise_path = True
     y0 = ddpm.sample(torch.from_numpy(g["cond"]).cuda(), 1.0, y_T=torch.from_numpy(g["y_T"]), noise=_z(g, T))
-    assert rel(y0, r["y0"]) <= 1e-4
+    assert rel(y0, r["y0"]) <= TOL
     assert ddpm.y_i_record.shape == r["y_i_record"].shape and ddpm.eps_i_record.shape == r["eps_i_record"].shape
-    assert rel(ddpm.eps_i_record, r["eps_i_record"]) <= 1e-4
-    assert rel(ddpm.y_i_record, r["y_i_record"]) <= 1e-4
+    assert rel(ddpm.eps_i_record, r["eps_i_record"]) <= TOL
+    assert rel(ddpm.y_i_record, r["y_i_record"]) <= TOL
     ddpm.record_denoise_path = False
     assert torch.equal(ddpm.sample(torch.from_numpy(g["cond"]).cuda(), 1.0, y_T=torch.from_numpy(g["y_T"]), noise=_z(g, T)), y0)
 

@@ -136,6 +136,18 @@ def test_g4_sample_synth(gold, name, T):
         close(y0, g[f"om{omega:g}_y0"], rtol=1e-5)
 
 
+def test_g4_sample_T1000(gold):
+    """BASELINE config 2's schedule length (G10): 1 000 steps = 2 000 chained forwards, 16 rows."""
+    g = gold("g4_sample_msr3_T1000.npz")
+    T = int(g["T"])
+    plan, p = synth_params("msr3", 31)
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    z = _z_dict(g["z"], T)
+    y0 = O.ddpm_sample(p, plan, bufs, T, torch.from_numpy(g["cond"]), 1.0, torch.from_numpy(g["y_T"]), z)
+    close(y0, g["om1_y0"], rtol=1e-5)
+    assert close(g["om1_y0"], g["om1_y0_f64"], rtol=2e-5) > 0     # the reference's own float32 error over 1 000 steps
+
+
 def test_g5_decoders(gold):
     g = gold("g5_decoders.npz")
     t = lambda k: torch.from_numpy(g[k])
