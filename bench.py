@@ -18,13 +18,16 @@ exact v_mfma_f32_32x32x2_f32 path (1.3e-6 vs 1.4e-6 worst relative error on the 
 "f32(2xf16-split MFMA, f32 accumulate)" names.  `--precision f32` times the exact-f32 MFMA path instead.
 
 Printed JSON (rank 0): the driver contract keys plus
-  roofline      dominant kernel (k_resblock of the proj_dim-wide up blocks): ALGORITHMIC float32 FLOP per launch / mean
-                launch time from HIP events recorded around each launch on the launch stream in a second, eager run of
-                the same K steps.  `peak` is the 157.3 TFLOP/s float32 MFMA/VALU rate of MI355X_MICROARCH.md, the roof
-                SURVEY 8(d) names for this path; the split kernel issues 3 f16 MFMAs per float32 block and so can exceed
-                it (frac > 1).  Against the f16 matrix-core peak (2500 TFLOP/s dense, 3 MFMA FLOP per algorithmic FLOP)
-                the same kernel is at `frac_f16_mfma`; it is VALU-issue-bound (LayerNorm/SiLU/split), see DESIGN.md.
-                `step_roofline` gives the whole step against the float32 roof and the HBM roof.
+  roofline      dominant kernel (the proj_dim-wide up blocks): mean launch time from HIP events recorded around each launch
+                on the launch stream in a second, eager run of the same K steps.  `achieved` = EXECUTED matrix-core FLOP per
+                second: the split path issues 3 v_mfma_f32_32x32x16_f16 per float32 product, so 3 x the algorithmic FLOP
+                (SURVEY 8(d) per-row figure x rows per launch) / launch time, against `peak` = 2500 TFLOP/s, the dense f16
+                MFMA rate of the unit the kernel runs on (`--precision f32`: 1 x, against the 157.3 TFLOP/s f32 MFMA rate).
+                `algorithmic_tflops` / `frac_f32_equiv` keep the float32-equivalent figure (algorithmic FLOP only, against
+                the f32 roof SURVEY 8(d) names) under their own keys.  `traffic` (HBM bytes per launch) and `valu_per_mfma`
+                are NOT measured in this run: they are imported from the committed rocprofv3 PMC summary named in
+                `traffic_source` (separate --pmc passes, FETCH_SIZE doubled per the gfx950 correction).
+                `step_roofline` gives the whole step against the same roofs.
   cpu_baseline  the CPU oracle (oracle/ddpm_oracle.py, the bit-checked restatement of the reference) timed on this
                 box's host cores on a bounded sample, converted to the same unit.
 """
@@ -41,6 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (fp32 vector = fp32 MFMA)
+PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0     # spec; 6290 measured
 MSR80 = dict(input_dim=80, proj_dim=128, cond_dim=80, dims=(64, 32, 16, 8), n_blocks=2)
 # Algorithmic work per sample-step: 2 passes x trunk MACs.  The time path (depends only on the step) and the condition
@@ -58,6 +62,29 @@ def build_model(device, T, seed=0):
     ddpm = DDPM(T, model, 80, 20.0, 1.0 - generate_cosine_schedule(T), device, (1, 80), None, 0.1, 0.9999, 10, 5, False)
     ddpm.apply(init_weights)
     return ddpm.to(device)
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as CHILD processes -- before this process touches the
+    GPU in any way -- with the env torch.distributed.run would give them, relay rank 0's JSON line, exit with the worst code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    raise SystemExit(rc)
 
 
 def cpu_baseline(sample_rows=4096, steps=2, B_ref=65536):
@@ -91,7 +118,7 @@ def _cpu_baseline_run(nthreads, sample_rows, steps, B_ref):
             y, _ = O.sample_step(p, plan, bufs, T, 10 - i, y, cond, 1.0, z)
         dt = time.perf_counter() - t0
     row_steps = sample_rows * steps / dt
-    return {"value": row_steps / B_ref, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": row_steps / B_ref, "unit": "steps/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{steps} reverse steps of a {sample_rows}x80 batch (T=20, omega=1) with oracle/ddpm_oracle.py on "
                       f"{torch.get_num_threads()} torch threads = {row_steps:.0f} row-steps/s, scaled to B={B_ref}",
             "row_steps_per_s": row_steps}
@@ -130,7 +157,45 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
     # algorithmic FLOP per sample: 3 x 2 x (trunk + cond) MACs with the time path tabulated over T rows
     f_train = 3 * 2 * (566_400 + 100_480)
     sps = world * B * steps / dt
-    return {"samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": B, "global_batch": world * B,
+    roof = None
+    # phase times of the fused step from HIP events on the launch stream (dsg_train_profile): a few extra untimed steps, on
+    # every rank (the step holds a collective), read on rank 0
+    import ctypes
+    from diffsg_amd import _lib
+    L, hd = _lib.lib(), ddpm.model.native_handle()
+    _lib.check(L.dsg_train_profile_enable(hd, 1))
+    acc = [0.0] * 5
+    n_prof = 5
+    for _ in range(n_prof):
+        one()
+        ms5 = (ctypes.c_float * 5)()
+        _lib.check(L.dsg_train_profile(hd, ms5))
+        acc = [x + float(v) for x, v in zip(acc, ms5)]
+    _lib.check(L.dsg_train_profile_enable(hd, 0))
+    if rank == 0:
+        fwd, bwd, cs, wg, tail = [x / n_prof for x in acc]
+        # dominant kernel of the step: the grouped weight-gradient launch k_wgrad_h, dW = G^T A for every Linear:
+        # 2 x (trunk + cond + T-row time table) MAC-FLOP per row, 3 f16 MFMAs per product; operands read from HBM:
+        # per Linear its G tensor once per 128-feature k-block of A and its A tensor once (bytes from the layer widths)
+        f_wg = 2 * (566_400 + 100_480)
+        roof = {"bound": "hbm", "kernel": "k_wgrad_h (one grouped launch: dW = G^T A of all 162 Linears + the time-table one-hot GEMM)",
+                "avg_launch_ms": wg, "share_of_step": wg / (dt / steps * 1e3),
+                "algorithmic_tflops": f_wg * B / (wg * 1e-3) / 1e12,
+                "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "phase_ms": {"forward": fwd, "activation_backward": bwd, "column_sums": cs, "weight_gradients": wg, "reduce_and_time_path": tail}}
+        # algorithmic bytes of the launch: every saved activation (A operand: x, h1, h2 per block + Linear inputs) and every
+        # gradient tensor (G operand) read once, float32
+        blocks = [(128, 128, 0)] * 2 + [(64, 64, 0)] * 2 + [(32, 32, 0)] * 2 + [(16, 16, 0)] * 2 + [(8, 8, 0)] * 4 + \
+                 [(8, 8, 8)] * 3 + [(16, 16, 16)] * 3 + [(32, 32, 32)] * 3 + [(64, 64, 64)] * 3 + [(128, 128, 128)] * 3
+        per_row = 0
+        for n, i0, i1 in blocks:
+            per_row += 4 * ((i0 + i1) + 2 * n + 3 * n + 80)        # A: x, h1, h2, cond ; G: dh1, dh2, dout
+        lins = [(80, 128), (128, 64), (64, 32), (32, 16), (16, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 80)]
+        per_row += sum(4 * (k + n) for k, n in lins)
+        roof["algorithmic_bytes_per_launch"] = per_row * B
+        roof["achieved"] = per_row * B / (wg * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / PEAK_HBM_GBS
+    return {"roofline": roof, "samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": B, "global_batch": world * B,
             "steps": steps, "T": 20, "final_loss": float(loss.detach()), "achieved_tflops": sps / world * f_train / 1e12,
             "frac_f32_mfma": sps / world * f_train / 1e12 / PEAK_F32_TFLOPS, "grad_bucket_bytes": int(ddpm.grad_bucket.numel()) * 4,
             "collective": "one all_reduce(SUM)/world per step over the flat bucket" if world > 1 else "none (1 GPU)"}
@@ -152,13 +217,15 @@ def main():
     ap.add_argument("--warm-seconds", type=float, default=0.3, help="untimed clock warm-up before the timed steps")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)                      # never returns; nothing has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU path)")
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -224,12 +291,20 @@ def main():
         dom = [r for r in pure if r[1] == fl and r[0].split(".")[0] == name.split(".")[0]]
         ms_sum, n_calls = sum(r[3] for r in dom), sum(r[4] for r in dom)
         avg_ms = ms_sum / n_calls
-        ach = fl * B / (avg_ms * 1e-3) / 1e12
+        ach = fl * B / (avg_ms * 1e-3) / 1e12            # algorithmic (float32-equivalent) TFLOP/s
+        split = a.precision == "split_f16"
+        mfma_x = 3.0 if split else 1.0                  # executed MFMA FLOP per algorithmic FLOP
+        unit_peak = PEAK_F16_TFLOPS if split else PEAK_F32_TFLOPS
         step_ms = dt / K * 1e3
-        traffic = None
+        traffic = valu_per_mfma = tsrc = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic, valu_per_mfma = tj.get("hbm_bytes_per_launch"), tj.get("valu_per_mfma")
+            tsrc = "imported, not measured in this run: profiles/traffic.json <- " + tj.get("summary", "profiles/") + " (kernel " + tj.get("kernel", "?") + ")"
+        large = 2 * ((B + 31) // 32) > 512
+        kname = ("k_wide128_h<linear-shortcut> (4 tiles per workgroup, weight planes through an LDS ring)" if large else "k_resblock_c<128,linear-shortcut>") \
+            if split else "k_resblock<128,linear-shortcut>"
         out = {
             "metric": "ddpm_reverse_sample_steps_per_sec_msr80c", "value": world * K / dt, "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True,
@@ -239,14 +314,16 @@ def main():
                                    f"(64,32,16,8), n_blocks 2), omega={a.omega:g}, device Philox noise; rows sharded, no collective",
                        "batch_per_gpu": B, "solution_dim": 80, "parallelism": f"rows x{world}"},
             "row_steps_per_s": world * K * B / dt,
-            "roofline": {"bound": "mfma", "kernel": f"{'k_resblock_h' if a.precision == 'split_f16' else 'k_resblock'}<128,linear-shortcut> "
-                                                    f"({len(dom)} launches/step: {', '.join(r[0] for r in dom)})",
-                         "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS,
-                         "frac_f16_mfma": (3 * ach / 2500.0) if a.precision == "split_f16" else None,
-                         "traffic": traffic, "avg_launch_ms": avg_ms, "flop_per_launch": fl * B,
-                         "share_of_step": ms_sum / sum(r[3] for r in prof)},
+            "roofline": {"bound": "mfma", "kernel": f"{kname} ({len(dom)} launches/step: {', '.join(r[0] for r in dom)})",
+                         "achieved": mfma_x * ach, "peak": unit_peak, "unit": "TFLOP/s", "frac": mfma_x * ach / unit_peak,
+                         "mfma_unit": "v_mfma_f32_32x32x16_f16, 3 per float32 product (hi*hi + hi*lo + lo*hi)" if split else "v_mfma_f32_32x32x2_f32",
+                         "algorithmic_tflops": ach, "frac_f32_equiv": ach / PEAK_F32_TFLOPS,
+                         "traffic": traffic, "valu_per_mfma": valu_per_mfma, "traffic_source": tsrc,
+                         "algorithmic_bytes_per_launch": by * B, "avg_launch_ms": avg_ms, "flop_per_launch": fl * B,
+                         "executed_mfma_flop_per_launch": mfma_x * fl * B, "share_of_step": ms_sum / sum(r[3] for r in prof)},
             "step_roofline": {"f_alg_per_row": F_ALG, "achieved_tflops": F_ALG * B / (step_ms * 1e-3) / 1e12,
-                              "frac_f32_mfma": F_ALG * B / (step_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                              "frac_mfma_unit": mfma_x * F_ALG * B / (step_ms * 1e-3) / 1e12 / unit_peak,
+                              "frac_f32_equiv": F_ALG * B / (step_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                               "achieved_gbs_alg": BYT_ALG * B / (step_ms * 1e-3) / 1e9,
                               "frac_hbm": BYT_ALG * B / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             "op_ms_per_step": {r[0]: r[3] / K for r in prof},

@@ -101,6 +101,8 @@ _SIGS = {
     "dsg_set_launch_policy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "dsg_build_id": (ctypes.c_char_p, []),
     "dsg_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "dsg_train_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "dsg_train_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "dsg_unet_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
     "dsg_row_softmax": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
     "dsg_msr_decode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
@@ -112,6 +114,8 @@ _SIGS = {
     "dsg_nu_rate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
     "dsg_sum_rate_gen": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double,
                                         ctypes.c_void_p]),
+    "dsg_co_minlp_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+                                           ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
     "dsg_sample": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong,
                                   ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_void_p]),

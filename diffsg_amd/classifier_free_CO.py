@@ -92,16 +92,18 @@ def train_ddpm_co(dataset_path=DEFAULT_DATASET, epochs=200, T=20, use_ema=False,
     """classifier_free_CO.py:203-252."""
     X_train, Y_train, _, _, custom_config = co_data_load(dataset_path)
     dataset = data.TensorDataset(torch.tensor(X_train, dtype=torch.float32), torch.tensor(Y_train, dtype=torch.float32))
-    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True)
+    from .train import FlatAdam, dp_context, make_loader, run_epochs, sync_replicas
+    device, rank, world = dp_context()      # one process per GPU when launched under torch.distributed.run; else cuda:0
+    loader = make_loader(dataset, batch_size, rank, world)
     node_num = Y_train.shape[1]
-    device = _device()
+    if device is None:
+        device = _device()                  # raises: no CPU path
     diffusion_model = build_model(node_num, custom_config['sfn'] * node_num, device, T, custom_config)
     diffusion_model.apply(init_weights)
     diffusion_model.to(device)
-    from .train import FlatAdam
+    sync_replicas(diffusion_model)          # data parallel: rank 0's initial weights everywhere (no-op for one process)
     optimizer = FlatAdam(diffusion_model, lr=lr)  # torch Adam, same update rule, over one flat tensor (one launch)
     scheduler = optim.lr_scheduler.MultiStepLR(optimizer, list(milestones))
-    from .train import run_epochs
     run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log)
     return diffusion_model
 
@@ -178,7 +180,9 @@ def validate_ddpm_co(epochs=500, T=500, use_ema=False, warmup_epoch=5, batch_siz
     """classifier_free_CO.py:451-502: train on the validation set (uncond_prob 0.0, MultiStepLR [30,150,350])."""
     X_train, Y_train, _, _, custom_config = data_split if data_split is not None else validation_data_gen()
     dataset = data.TensorDataset(torch.tensor(X_train, dtype=torch.float32), torch.tensor(Y_train, dtype=torch.float32))
-    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True)
+    from .train import FlatAdam, dp_context, make_loader, run_epochs, sync_replicas
+    device, rank, world = dp_context()      # one process per GPU when launched under torch.distributed.run; else cuda:0
+    loader = make_loader(dataset, batch_size, rank, world)
     node_num = Y_train.shape[1]
     device = _device()
     diffusion_model = _validation_model(node_num, custom_config['sfn'] * node_num, device, T, custom_config, 0.0)

@@ -72,16 +72,18 @@ def train_ddpm_msr(dataset_path=DEFAULT_DATASET, epochs=200, T=20, use_ema=False
     """classifier_free_MSR.py:187-236 (hot loop :217-234)."""
     X_train, Y_train, _, _, custom_config = msr_data_load(dataset_path)
     dataset = data.TensorDataset(torch.tensor(X_train, dtype=torch.float32), torch.tensor(Y_train, dtype=torch.float32))
-    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True)
+    from .train import FlatAdam, dp_context, make_loader, run_epochs, sync_replicas
+    device, rank, world = dp_context()      # one process per GPU when launched under torch.distributed.run; else cuda:0
+    loader = make_loader(dataset, batch_size, rank, world)
     M, W = custom_config['M'], custom_config['W']
-    device = _device()
+    if device is None:
+        device = _device()                  # raises: no CPU path
     diffusion_model = build_model(M, custom_config['sfn'] * M, device, T, custom_config, W)
     diffusion_model.apply(init_weights)
     diffusion_model.to(device)
-    from .train import FlatAdam
+    sync_replicas(diffusion_model)          # data parallel: rank 0's initial weights everywhere (no-op for one process)
     optimizer = FlatAdam(diffusion_model, lr=lr)  # torch Adam, same update rule, over one flat tensor (one launch)
     scheduler = optim.lr_scheduler.MultiStepLR(optimizer, list(milestones))
-    from .train import run_epochs
     run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log)
     return diffusion_model
 

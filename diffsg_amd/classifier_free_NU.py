@@ -74,15 +74,17 @@ def train_ddpm_nu(dataset_path=DEFAULT_DATASET, epochs=200, T=20, use_ema=False,
     """classifier_free_NU.py:213-264."""
     X_train, Y_train, _, _, _, custom_config = nu_data_load(dataset_path, width, height)
     dataset = data.TensorDataset(torch.tensor(X_train, dtype=torch.float32), torch.tensor(Y_train, dtype=torch.float32))
-    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=True)
-    device = _device()
+    from .train import FlatAdam, dp_context, make_loader, run_epochs, sync_replicas
+    device, rank, world = dp_context()      # one process per GPU when launched under torch.distributed.run; else cuda:0
+    loader = make_loader(dataset, batch_size, rank, world)
+    if device is None:
+        device = _device()                  # raises: no CPU path
     diffusion_model = build_model(custom_config['K'], custom_config['P_sum'], device, T, custom_config)
     diffusion_model.apply(init_weights)
     diffusion_model.to(device)
-    from .train import FlatAdam
+    sync_replicas(diffusion_model)          # data parallel: rank 0's initial weights everywhere (no-op for one process)
     optimizer = FlatAdam(diffusion_model, lr=lr)  # torch Adam, same update rule, over one flat tensor (one launch)
     scheduler = optim.lr_scheduler.MultiStepLR(optimizer, list(milestones))
-    from .train import run_epochs
     run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log)
     return diffusion_model
 

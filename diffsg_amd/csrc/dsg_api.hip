@@ -8,6 +8,7 @@
 #include "dsg_train_split.hpp"
 #include "dsg_eval.hpp"
 #include "dsg_labelgen.hpp"
+#include "dsg_cogen.hpp"
 #include "../../include/diffsg.h"
 
 #include <math.h>
@@ -163,6 +164,9 @@ struct dsg_handle {
     CallParams* call_dev = nullptr;
     hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream)
     std::vector<double> op_ms;   // DSG_SAMPLE_PROFILE: summed HIP-event time per op
+    bool train_prof = false;     // dsg_train_profile_enable: HIP events at the phase boundaries of dsg_train_step
+    hipEvent_t tev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool tev_valid = false;
     std::vector<int> op_calls;
 
     // fused narrow run [fuse_lo, fuse_hi) of `ops` (inference only)
@@ -617,6 +621,7 @@ void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStr
         BlockLinArgsH w;
         memset(&w, 0, sizeof w);
         w.b = a; w.store_block_out = 1;
+        if (const char* e = getenv("DSG_WIDE_DBG")) w.dbg = atoi(e);   // measurement only (dsg_wide.hpp)
         const dim3 grid(cdiv(a.b.ntiles, 4)), block(256);
         if (r.sclin) hipLaunchKernelGGL((k_wide128_h<true, 0, 1>), grid, block, 0, s, w);
         else hipLaunchKernelGGL((k_wide128_h<false, 0, 1>), grid, block, 0, s, w);
@@ -654,6 +659,7 @@ bool launch_res_lin_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, co
     fill_block_args_h(h, r, b, a.b);
     fill_lin_args_h(h, l, la, a.l);
     a.store_block_out = store_block_out ? 1 : 0;
+    a.dbg = 0;
     const dim3 grid(cdiv(b.ntiles, kWavesPerBlock)), block(256);
     const int NTO = cdiv(l.l.N, 32);
     if (wide128_ok(r, b) && l.l.K == 128) {
@@ -1253,6 +1259,9 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
 }
 
 void dsg_destroy(dsg_handle* h) {
+    if (h)
+        for (auto& e : h->tev)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (!h) return;
     (void)hipDeviceSynchronize();
     free_workspace(h);
@@ -1604,6 +1613,8 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     const Param* P = h->params.data();
 
     // ---- forward
+    auto mark = [&](int i) { if (h->train_prof) (void)hipEventRecord(h->tev[i], s); };
+    mark(0);
     HIPCK(hipMemcpyAsync(h->tr_ts, ts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_linspace_t, dim3(cdiv(T, 256)), dim3(256), 0, s, h->tvals, T);
     run_time_path(h, T, s, true);
@@ -1619,6 +1630,7 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, s, h->red, kRedBlocks, (double)B * (double)D, loss_out);
 
     // ---- backward: activation gradients in reverse operator order
+    mark(1);
     HIPCK(hipMemsetAsync(h->tr_gmax_t, 0, (size_t)h->n_gmax * h->gmax_ld * sizeof(unsigned), s));
     for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
         const Op& op = h->ops[oi];
@@ -1673,17 +1685,20 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
         }
     }
     // ---- weight / bias / LayerNorm gradients: two grouped launches into per-chunk slabs, then a fixed-order reduce
+    mark(2);
     hipLaunchKernelGGL(k_cs_reduce, dim3(cdiv(h->cs_slots, 256), h->tr_chunks), dim3(256), 0, s, h->tr_cs, h->cs_map_dev, h->cs_slots,
                        h->tr_slabs, h->slab_stride, tiles, h->tr_chunks);
     hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->cs_units, 4)), dim3(256), 0, s, h->cs_desc_dev, h->cs_unit_dev, h->cs_units, h->tr_slabs,
                        h->slab_stride, tiles, h->tr_chunks, B, h->tr_gmax_t, h->gmax_ld);
     hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, s, h->tr_gmax_t, h->gmax_ld, h->tr_gmax);
+    mark(3);
     if (h->use_split)
         hipLaunchKernelGGL(k_wgrad_h, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_gmax, h->tr_slabs,
                            h->slab_stride, tiles, h->tr_chunks);
     else
         hipLaunchKernelGGL(k_wgrad, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_slabs, h->slab_stride, tiles,
                            h->tr_chunks);
+    mark(4);
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((h->slab_stride + 255) / 256 < 4096 ? (h->slab_stride + 255) / 256 : 4096)), dim3(256),
                        0, s, h->tr_slabs, h->slab_stride, h->tr_chunks, h->tr_gsum, h->slab_stride);
 
@@ -1711,7 +1726,26 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
         hipLaunchKernelGGL(k_col_sum_small, dim3(cdiv(td, 256)), dim3(256), 0, s, d_h1s, T, td, (long long)td, G + P[h->temb_l1b].off);
     }
     HIPCK(hipMemcpyAsync(grads_flat, h->tr_gsum, (size_t)h->total_params * sizeof(float), hipMemcpyDeviceToDevice, s));
+    mark(5);
+    if (h->train_prof) h->tev_valid = true;
     HIPCK(hipGetLastError());
+    return 0;
+}
+
+int dsg_train_profile_enable(dsg_handle* h, int on) {
+    if (!h) return fail("null handle");
+    if (on && !h->tev[0])
+        for (auto& e : h->tev) HIPCK(hipEventCreate(&e));
+    h->train_prof = on != 0;
+    h->tev_valid = false;
+    return 0;
+}
+
+int dsg_train_profile(dsg_handle* h, float* ms5) {
+    if (!h || !ms5) return fail("dsg_train_profile: null argument");
+    if (!h->tev_valid) return fail("dsg_train_profile: no profiled dsg_train_step yet (dsg_train_profile_enable first)");
+    HIPCK(hipEventSynchronize(h->tev[5]));
+    for (int i = 0; i < 5; ++i) HIPCK(hipEventElapsedTime(&ms5[i], h->tev[i], h->tev[i + 1]));
     return 0;
 }
 
@@ -1836,6 +1870,19 @@ int dsg_sum_rate_gen(const double* gs, double* schemes, double* rates, long long
     }
     hipLaunchKernelGGL(k_sumrate_rates, grid, dim3(256), 0, s, gs, schemes, rates, rows, M);
     HIPCK(hipFreeAsync(flags, s));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int dsg_co_minlp_search(const double* params, const double* choices, int nch, double* Y, int* tolerable, long long rows, int n,
+                        double F_t, double P_t, double P_I, double theta, void* stream) {
+    if (!params || !choices || !Y || !tolerable) return fail("dsg_co_minlp_search: null pointer argument");
+    if (n < 1 || n > kCoMaxNodes) return fail("dsg_co_minlp_search: node_num must be in [1, %d] (got %d)", kCoMaxNodes, n);
+    if (nch < 1 || nch > 4096) return fail("dsg_co_minlp_search: bad grid size %d", nch);
+    if (rows < 0 || rows > 0x7fffffffLL) return fail("dsg_co_minlp_search: bad row count");
+    if (rows == 0) return 0;
+    const CoGenConst cc{F_t, P_t, P_I, theta};
+    hipLaunchKernelGGL(k_co_minlp, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, params, choices, nch, n, cc, Y, tolerable);
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -796,7 +796,7 @@ __device__ __forceinline__ void linear_epilogue_h(const LinArgsH& ah, int tile, 
     }
 }
 
-struct BlockLinArgsH { BlockArgsH b; LinArgsH l; int store_block_out; };
+struct BlockLinArgsH { BlockArgsH b; LinArgsH l; int store_block_out; int dbg; };   // dbg: dsg_wide.hpp measurement switches (0 in production)
 
 template <int N, bool SCLIN, int NTO, bool FINAL>
 __global__ __launch_bounds__(256, 2) void k_resblock_lin_h(const BlockLinArgsH a) {

@@ -26,33 +26,27 @@
 
 namespace dsg {
 
-constexpr int kRingChunks = 9;     // 72 KiB; two workgroups per CU
-constexpr int kRingDist = 6;       // chunks in flight ahead of the consumer
+constexpr int kRingChunks = 8;     // 64 KiB; two workgroups per CU
+constexpr int kRingDist = 6;       // chunks in flight ahead of the consumer; an event consumes 2: 6 + 2 = the ring
 constexpr int kChunkU4 = 512;      // uint4 per chunk
+constexpr int kWideMaxChunks = 96; // chunk program length bound (2*16 + 8 + 8 + 8 + 2*16 + 8)
 constexpr int kWideVec = 2 * kLnLdsW1 + 10 * 128;   // floats: LN1 | LN2 | LN3 (gamma', beta'), time bias, c2, c3, epilogue LN + bias
 
-// two 1 KiB pieces: global (wave-uniform base + per-lane byte offset) -> LDS (wave-uniform address, lane-linear)
-__device__ __forceinline__ void glds_pair(unsigned voff, const void* sbase, unsigned lds_dst) {
+// two 1 KiB pieces: global (per-lane address) -> LDS (wave-uniform address, lane-linear); the instruction offset of the second
+// DMA moves the global AND the LDS address
+__device__ __forceinline__ void glds_pair(const void* gsrc_lane, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
 }
 
-__device__ __forceinline__ void wide_wait_vm(int n) {   // n = DMAs of this wave that may stay in flight (wave-uniform)
-    switch (n) {
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
-// The chunk program of one block (+ optional Linear epilogue), as seen by ONE wave: where chunk c comes from.
+// The chunk program of one block (+ optional Linear epilogue), as seen by ONE wave: where chunk c comes from.  Evaluated once
+// per wave at kernel start, one chunk per lane, into an LDS table; the producer then reads one 8-byte entry per chunk (the
+// first version decoded the chunk index with scalar branches at every issue: 3 400 SALU instructions and 1 200 branches per
+// wave against 4 300 VALU, all of it in the in-order issue stream of the wave that also has to feed the matrix core).
 struct WideProg {
     int cA, cB, cC, cD, cE, cF;   // cumulative ends of: stage 1 (x, W1 per step) | stage 2 (W2) | condition embedding (private) |
                                   // stage 3 (W3) | shortcut (x, Wsc per step) or residual re-read (private) | epilogue Linear
@@ -61,60 +55,63 @@ struct WideProg {
     const uint4 *w1, *w2, *w3, *wsc, *wl;   // this wave's out tile of each packed matrix (step 0, hi plane)
     int lin_spc;                  // epilogue Linear: k16-steps per chunk (4 / pow2(NTO))
     bool sclin;
-    unsigned voff;                // lane * 16
-    unsigned lds_w;               // LDS byte address of this wave's first piece of slot 0
 
-    __device__ __forceinline__ void issue(int c, int slot) const {
-        const void* src;
-        if (c < cA) {
-            const int S = c >> 1;
-            if (c & 1) src = w1 + (size_t)S * 128;
-            else src = S < ks0 ? (const void*)(x0 + (size_t)S * 512) : (const void*)(x1 + (size_t)(S - ks0) * 512);
-        } else if (c < cB) {
-            src = w2 + (size_t)(c - cA) * 128;
-        } else if (c < cC) {
-            src = cp + (size_t)(c - cB) * 512;
-        } else if (c < cD) {
-            src = w3 + (size_t)(c - cC) * 128;
-        } else if (c < cE) {
-            const int i = c - cD;
-            if (sclin) {
-                const int S = i >> 1;
-                if (i & 1) src = wsc + (size_t)S * 128;
-                else src = S < ks0 ? (const void*)(x0 + (size_t)S * 512) : (const void*)(x1 + (size_t)(S - ks0) * 512);
-            } else {
-                src = x0 + (size_t)i * 512;
-            }
-        } else {
-            src = wl + (size_t)(c - cE) * lin_spc * 128;
-        }
-        glds_pair(voff, src, lds_w + (unsigned)slot * 8192u);
+    __device__ __forceinline__ const void* source(int c) const {   // c may differ per lane
+        const int iA = c, iB = c - cA, iC = c - cB, iD = c - cC, iE = c - cD, iF = c - cE;
+        const int S1 = iA >> 1, SE = iE >> 1;
+        const void* xa = S1 < ks0 ? (const void*)(x0 + (size_t)S1 * 512) : (const void*)(x1 + (size_t)(S1 - ks0) * 512);
+        const void* xe = SE < ks0 ? (const void*)(x0 + (size_t)SE * 512) : (const void*)(x1 + (size_t)(SE - ks0) * 512);
+        const void* sA = (iA & 1) ? (const void*)(w1 + (size_t)S1 * 128) : xa;
+        const void* sE = sclin ? ((iE & 1) ? (const void*)(wsc + (size_t)SE * 128) : xe) : (const void*)(x0 + (size_t)iE * 512);
+        const void* r = wl + (size_t)iF * lin_spc * 128;
+        r = c < cE ? sE : r;
+        r = c < cD ? (const void*)(w3 + (size_t)iD * 128) : r;
+        r = c < cC ? (const void*)(cp + (size_t)iC * 512) : r;
+        r = c < cB ? (const void*)(w2 + (size_t)iB * 128) : r;
+        r = c < cA ? sA : r;
+        return r;
     }
 };
 
+// Measurement switches (BlockLinArgsH::dbg, env DSG_WIDE_DBG read by the host launcher; results are WRONG with any of them
+// set -- they exist to time the kernel with one ingredient removed): 1 no barrier, 2 no DMA wait, 4 no MFMA, 8 no LayerNorm /
+// SiLU / split VALU, 16 no DMA issue.
 struct WideRing {
-    const uint4* rd;   // the ring as ordinary LDS (+ lane)
-    int gc, pi;        // chunks consumed / issued so far
-    int sc, sp;        // slot of chunk gc / of chunk pi
+    int dbg;
+    const uint4* rd;                 // the ring as ordinary LDS (+ lane)
+    const unsigned long long* tab;   // this wave's chunk-source table (LDS)
+    unsigned long long nsrc[2];      // sources of the next two chunks to issue (read one event ahead)
+    unsigned long long lane16;       // lane * 16
+    unsigned lds_w;                  // LDS byte address of this wave's first piece of slot 0
+    int gc, pi;                      // chunks consumed / issued so far
     int total;
 };
 
-__device__ __forceinline__ int ring_next(int s, int n = 1) { return s + n >= kRingChunks ? s + n - kRingChunks : s + n; }
+__device__ __forceinline__ void ring_issue(WideRing& r, unsigned long long src) {
+    glds_pair(reinterpret_cast<const void*>(src + r.lane16), r.lds_w + (unsigned)(r.pi & (kRingChunks - 1)) * 8192u);
+    ++r.pi;
+}
 
-// Consume NEV chunks: returns the slot of the first one (the others follow, modulo the ring).
-template <int NEV>
-__device__ __forceinline__ int wide_event(WideRing& r, const WideProg& p) {
-    wide_wait_vm(2 * (r.pi - r.gc - NEV));
+// Consume two chunks: returns the slot of the first one (the second is the next slot, modulo the ring).
+__device__ __forceinline__ int wide_event(WideRing& r) {
+    const int fl = r.pi - r.gc;                       // chunks issued and not consumed: kRingDist until the program runs out
+    if (!(r.dbg & 2)) {
+        if (fl == kRingDist) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // 4 chunks (8 DMAs of this wave) stay in flight
+        else if (fl == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < NEV; ++i)
-        if (r.pi < r.total) { p.issue(r.pi, r.sp); ++r.pi; r.sp = ring_next(r.sp); }
-    const int s = r.sc;
-    r.gc += NEV;
-    r.sc = ring_next(r.sc, NEV);
+    if (!(r.dbg & 1)) __builtin_amdgcn_s_barrier();
+    if (r.pi < r.total) {                             // chunk counts of all segments are even: two at a time
+        if (!(r.dbg & 16)) { ring_issue(r, r.nsrc[0]); ring_issue(r, r.nsrc[1]); } else r.pi += 2;
+        const int n0 = r.pi < kWideMaxChunks - 1 ? r.pi : kWideMaxChunks - 2;
+        r.nsrc[0] = r.tab[n0]; r.nsrc[1] = r.tab[n0 + 1];
+    }
+    const int s = r.gc & (kRingChunks - 1);
+    r.gc += 2;
     return s;
 }
+__device__ __forceinline__ int ring_next(int s) { return (s + 1) & (kRingChunks - 1); }
 
 // 16 * silu(u) from u' = -log2(e) * u:  p = 2^u' = e^-u;  16 u / (1 + p) = u' / ((1 + p) * (-log2(e) / 16))
 __device__ __forceinline__ float silu_scaled_l2(float up) {
@@ -145,59 +142,67 @@ __device__ __forceinline__ void wacc_zero(f32x16 (&acc)[NT]) {
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 }
 
-// register-fed stage over the ring: out += W * split(16 silu(LN(in))), one chunk (= one k16-step, 4 out tiles) per event
-__device__ __forceinline__ void wide_stage_reg(f32x16 (&out)[4], const f32x16 (&in)[4], WideRing& r, const WideProg& p, const float* gamma,
-                                               const float* beta, float mean, float rstd, int h) {
+// register-fed stage over the ring: out += W * split(16 silu(LN(in))), two chunks (= two k16-steps x 4 out tiles) per event
+__device__ __forceinline__ void wide_stage_reg(f32x16 (&out)[4], const f32x16 (&in)[4], WideRing& r, const float* gamma, const float* beta,
+                                               float mean, float rstd, int h) {
     const float c = rstd, d = -mean * rstd;
 #pragma unroll
-    for (int S = 0; S < 8; ++S) {
-        const int s = wide_event<1>(r, p);
-        HFrag<4> w;
-        ring_wfrag<4>(w, r.rd + s * kChunkU4);
-        const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
-        const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
-        const int t = S >> 1, r0 = 8 * (S & 1);
-        const float x[8] = {in[t][r0], in[t][r0 + 1], in[t][r0 + 2], in[t][r0 + 3], in[t][r0 + 4], in[t][r0 + 5], in[t][r0 + 6], in[t][r0 + 7]};
-        float v[8];
-        act8_l2(v, x, c, d, g0, b0, g1, b1);
-        h8 bhi, blo;
-        split8(v, bhi, blo);
-        mfma_step_h<4>(out, w, bhi, blo);
+    for (int E = 0; E < 4; ++E) {
+        const int s0 = wide_event(r);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int S = 2 * E + half, s = half ? ring_next(s0) : s0;
+            HFrag<4> w;
+            ring_wfrag<4>(w, r.rd + s * kChunkU4);
+            const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
+            const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
+            const int t = S >> 1, r0 = 8 * (S & 1);
+            const float x[8] = {in[t][r0], in[t][r0 + 1], in[t][r0 + 2], in[t][r0 + 3], in[t][r0 + 4], in[t][r0 + 5], in[t][r0 + 6], in[t][r0 + 7]};
+            float v[8];
+            h8 bhi, blo;
+            if (!(r.dbg & 8)) { act8_l2(v, x, c, d, g0, b0, g1, b1); split8(v, bhi, blo); }
+            else { bhi = __builtin_bit_cast(h8, make_float4(x[0], x[1], x[2], x[3])); blo = __builtin_bit_cast(h8, make_float4(x[4], x[5], x[6], x[7])); }
+            if (!(r.dbg & 4)) mfma_step_h<4>(out, w, bhi, blo);
+            else { out[0][0] += (float)bhi[0] + __builtin_bit_cast(float4, w.hi[0]).x; out[1][0] += (float)blo[0] + __builtin_bit_cast(float4, w.lo[3]).x; }
+        }
     }
 }
 
 // memory-fed stage over the ring: per k16-step one private chunk (this wave's two groups of x) and one weight chunk
 template <bool LNACT>
-__device__ __forceinline__ void wide_stage_mem(f32x16 (&acc)[4], int steps, WideRing& r, const WideProg& p, int wave, const float* gamma,
+__device__ __forceinline__ void wide_stage_mem(f32x16 (&acc)[4], int steps, WideRing& r, int wave, const float* gamma,
                                                const float* beta, float mean, float rstd, int h) {
     const float c = rstd, d = -mean * rstd;
     for (int S = 0; S < steps; ++S) {
-        const int s0 = wide_event<2>(r, p), s1 = ring_next(s0);
+        const int s0 = wide_event(r), s1 = ring_next(s0);
         const uint4* xs = r.rd + s0 * kChunkU4 + (2 * wave) * 64;
         const float4 xa = __builtin_bit_cast(float4, xs[0]), xb = __builtin_bit_cast(float4, xs[64]);
         HFrag<4> w;
         ring_wfrag<4>(w, r.rd + s1 * kChunkU4);
         const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
         float v[8];
-        if (LNACT) {
-            const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
-            const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
-            act8_l2(v, x, c, d, g0, b0, g1, b1);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = kRawScale * x[q];
-        }
         h8 bhi, blo;
-        split8(v, bhi, blo);
-        mfma_step_h<4>(acc, w, bhi, blo);
+        if (!(r.dbg & 8)) {
+            if (LNACT) {
+                const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
+                const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
+                act8_l2(v, x, c, d, g0, b0, g1, b1);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = kRawScale * x[q];
+            }
+            split8(v, bhi, blo);
+        } else { bhi = __builtin_bit_cast(h8, xa); blo = __builtin_bit_cast(h8, xb); }
+        if (!(r.dbg & 4)) mfma_step_h<4>(acc, w, bhi, blo);
+        else { acc[0][0] += (float)bhi[0] + __builtin_bit_cast(float4, w.hi[0]).x; acc[1][0] += (float)blo[0] + __builtin_bit_cast(float4, w.lo[3]).x; }
     }
 }
 
 // acc += private tensor (16 groups of this wave's tile), two chunks (4 groups = one accumulator tile) per event
-__device__ __forceinline__ void wide_add_private(f32x16 (&acc)[4], WideRing& r, const WideProg& p, int wave, bool take) {
+__device__ __forceinline__ void wide_add_private(f32x16 (&acc)[4], WideRing& r, int wave, bool take) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int s0 = wide_event<2>(r, p), s1 = ring_next(s0);
+        const int s0 = wide_event(r), s1 = ring_next(s0);
         if (take) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -226,8 +231,9 @@ template <bool SCLIN, int EPI, int NTO>
 __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     constexpr int N = 128, NT = 4, NG = 16;
     constexpr int NTOP = NTO <= 1 ? 1 : (NTO == 2 ? 2 : 4), SPC = 4 / NTOP;       // epilogue Linear: k16-steps per chunk
-    __shared__ uint4 lds[kRingChunks * kChunkU4 + kWideVec / 4];
+    __shared__ uint4 lds[kRingChunks * kChunkU4 + kWideVec / 4 + 4 * kWideMaxChunks / 2];
     float* const vec = reinterpret_cast<float*>(lds + kRingChunks * kChunkU4);
+    unsigned long long* const tab_all = reinterpret_cast<unsigned long long*>(lds + kRingChunks * kChunkU4 + kWideVec / 4);
     float* const g1v = vec, * const b1v = vec + kLnLdsW1, * const v2 = vec + 2 * kLnLdsW1;
     float* const g2v = v2, * const b2v = v2 + 128, * const g3v = v2 + 256, * const b3v = v2 + 384, * const tbv = v2 + 512, * const c2v = v2 + 640,
          * const c3v = v2 + 768, * const gLv = v2 + 896, * const bLv = v2 + 1024, * const biasLv = v2 + 1152;
@@ -299,19 +305,26 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     } else {
         p.wl = p.w1;
     }
-    p.voff = (unsigned)lane * 16u;
     const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds;
-    p.lds_w = lds0 + (unsigned)wave * 2048u;
     WideRing r;
-    r.rd = lds + lane; r.gc = 0; r.pi = 0; r.sc = 0; r.sp = 0; r.total = p.cF;
-    __syncthreads();                                        // the staged vectors are visible; no DMA is in flight yet
+    r.rd = lds + lane; r.gc = 0; r.pi = 0; r.total = p.cF; r.dbg = A.dbg;
+    r.lds_w = lds0 + (unsigned)wave * 2048u;
+    r.lane16 = (unsigned long long)lane * 16ull;
+    {   // this wave's chunk-source table: one chunk per lane
+        unsigned long long* tab = tab_all + wave * kWideMaxChunks;
+        for (int c = lane; c < kWideMaxChunks; c += 64)
+            tab[c] = reinterpret_cast<unsigned long long>(p.source(c < p.cF ? c : p.cF - 1));
+        r.tab = tab;
+    }
+    __syncthreads();                                        // the staged vectors and tables are visible; no DMA is in flight yet
 #pragma unroll
-    for (int i = 0; i < kRingDist; ++i) { p.issue(r.pi, r.sp); ++r.pi; r.sp = ring_next(r.sp); }
+    for (int i = 0; i < kRingDist; ++i) ring_issue(r, r.tab[i]);
+    r.nsrc[0] = r.tab[kRingDist]; r.nsrc[1] = r.tab[kRingDist + 1];
 
     // ---- stage 1
     f32x16 acc1[NT];
     wacc_zero<NT>(acc1);
-    wide_stage_mem<true>(acc1, KS1, r, p, wave, g1v, b1v, mean1, rstd1, h);
+    wide_stage_mem<true>(acc1, KS1, r, wave, g1v, b1v, mean1, rstd1, h);
     if (a.ts) acc_unscale_add<NT>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
     else acc_unscale_add_lds<NT>(acc1, inv1, tbv, h);
     if (a.save_h1 && live) {
@@ -327,10 +340,10 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     {
         float mean, m2;
         acc_stats<N, NT>(acc1, h, mean, m2);
-        wide_stage_reg(acc2, acc1, r, p, g2v, b2v, mean, rsqrtf(m2 * (1.0f / N) + kLnEps), h);
+        wide_stage_reg(acc2, acc1, r, g2v, b2v, mean, rsqrtf(m2 * (1.0f / N) + kLnEps), h);
         acc_unscale_add_lds<NT>(acc2, inv2, c2v, h);
     }
-    if (wg_cond) wide_add_private(acc2, r, p, wave, my_cond);
+    if (wg_cond) wide_add_private(acc2, r, wave, my_cond);
     if (a.save_h2 && live) {
 #pragma unroll
         for (int G = 0; G < NG; ++G)
@@ -344,14 +357,14 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     {
         float mean, m2;
         acc_stats<N, NT>(acc2, h, mean, m2);
-        wide_stage_reg(acc3, acc2, r, p, g3v, b3v, mean, rsqrtf(m2 * (1.0f / N) + kLnEps), h);
+        wide_stage_reg(acc3, acc2, r, g3v, b3v, mean, rsqrtf(m2 * (1.0f / N) + kLnEps), h);
     }
     if (SCLIN) {
-        wide_stage_mem<false>(acc3, KS1, r, p, wave, nullptr, nullptr, 0.f, 1.f, h);
+        wide_stage_mem<false>(acc3, KS1, r, wave, nullptr, nullptr, 0.f, 1.f, h);
         acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
     } else {
         acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
-        wide_add_private(acc3, r, p, wave, true);
+        wide_add_private(acc3, r, wave, true);
     }
 
     // ---- statistics + store
@@ -372,9 +385,10 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     wacc_zero<NTO>(acc);
     {
         const float c = EPI == 2 ? rsqrtf(xm2 / (float)la.in_width + kLnEps) : 1.f, d = -xmean * c;
+        int sl0 = 0;
 #pragma unroll
         for (int ch = 0; ch < 8 / SPC; ++ch) {
-            const int s = wide_event<1>(r, p);
+            const int s = (ch & 1) ? ring_next(sl0) : (sl0 = wide_event(r));
 #pragma unroll
             for (int sl = 0; sl < SPC; ++sl) {
                 const int S = ch * SPC + sl, t = S >> 1, r0 = 8 * (S & 1);

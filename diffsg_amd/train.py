@@ -65,10 +65,70 @@ class FlatAdam(torch.optim.Adam):
             p.grad = None
 
 
+def dp_context(backend=None):
+    """(device, rank, world) of this process for the train entry points.
+
+    Single process: cuda:0 (the reference's `torch.device("cuda:0")`, classifier_free_MSR.py:196), rank 0 of 1.
+    Launched one process per GPU (torch.distributed.run, or any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE): the device
+    is cuda:LOCAL_RANK and the process group is created here if the caller has not done it (backend "nccl" = RCCL over
+    xGMI; tests pass "gloo").  Every rank then draws its own ts / noise / mask: the global generators are re-seeded with
+    `initial_seed + rank` (torch's default seed is the same constant in every process)."""
+    import os
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size()
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend)
+    rank = dist.get_rank() if world > 1 else 0
+    if torch.cuda.is_available():
+        local = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = None                       # the caller raises: there is no CPU path for the compute
+    if world > 1:
+        torch.manual_seed(torch.initial_seed() + rank)
+    return device, rank, world
+
+
+def make_loader(dataset, batch_size, rank=0, world=1, seed=0):
+    """The reference's `DataLoader(dataset, batch_size, shuffle=True)` (classifier_free_MSR.py:190-192); data parallel: every
+    rank iterates its own 1/world of a per-epoch permutation (DistributedSampler pads so that all ranks make the same number
+    of steps -- each step holds a collective)."""
+    import torch.utils.data as data
+    if world == 1:
+        return data.DataLoader(dataset, batch_size=batch_size, shuffle=True)
+    sampler = data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=seed)
+    return data.DataLoader(dataset, batch_size=batch_size, sampler=sampler)
+
+
+def sync_replicas(diffusion_model):
+    """Data parallel: every replica starts from rank 0's weights -- `apply(init_weights)` drew them from each rank's own
+    generator -- for `model.*` and `ema.module.*` alike; then the library re-packs (the broadcast writes through `.data`)."""
+    from . import parallel
+    _, world = parallel.world()
+    if world == 1:
+        return
+    parallel.broadcast_parameters(diffusion_model)
+    for m in (diffusion_model.model, diffusion_model.ema.module):
+        if hasattr(m, "mark_weights_changed"):
+            m.mark_weights_changed()
+
+
 def run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log=print):
+    from . import parallel
+    rank, world = parallel.world()
+    if rank != 0:
+        log = lambda *_a, **_k: None        # rank 0 reports (its local metric); every rank trains
     ema_step_cnt = 1
     for epoch in range(epochs):
         epoch_loss, epoch_rows = 0.0, 0
+        if hasattr(getattr(loader, "sampler", None), "set_epoch"):
+            loader.sampler.set_epoch(epoch)
         for x, y_true in loader:
             x = x.to(device)
             y_true = y_true.to(device)

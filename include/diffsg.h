@@ -107,6 +107,12 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
                    const float* cond_mask, const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat,
                    float* loss_out, int B, void* stream);
 
+/* Measurement hook for bench.py's train leg: with the profile enabled every dsg_train_step records HIP events on `stream`
+ * at its phase boundaries (no synchronisation); dsg_train_profile waits for the last profiled step and returns the times in
+ * ms of { forward (+ q_sample, loss), activation backward, column sums, grouped weight-gradient launch, reduce + time path }. */
+int dsg_train_profile_enable(dsg_handle* h, int on);
+int dsg_train_profile(dsg_handle* h, float* ms5);
+
 /* avg = decay*avg + one_minus_decay*p over n floats   (ddpm_opt/ema.py:11-12). */
 int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_decay, long long n, void* stream);
 
@@ -132,6 +138,15 @@ int dsg_nu_rate(const float* Yd, const float* X, float* rate, long long rows, in
  * descent", float64 like the reference).  gs [rows][M] channel gains (the reference draws them with np.random.uniform; the
  * caller does), W total power; schemes [rows][M] and rates [rows] are written.  M <= 128.  Stream-ordered. */
 int dsg_sum_rate_gen(const double* gs, double* schemes, double* rates, long long rows, int M, double W, void* stream);
+
+/* ---- Label generator of the CO problem: the exhaustive search of CONV_CO_MINLP_GEN,
+ * utils/dataset_generate.py:147-245 (float64): per sample all 2^n offloading decisions x all allocations of the server capacity
+ * on the grid `choices` [nch] (np.arange(0.02, 1.02, 0.02), drawn up by the caller) that sum to 1.  params [rows][7][n] =
+ * s, c, f_local, alpha, beta, r_u, cost_local per node (the caller's numpy draws and derived values, :169-184); Y [rows][2n+1]
+ * receives decision | allocation | cost of the LAST delay-tolerable candidate if there is one (tolerable[r] = 1), else of the
+ * FIRST cheapest one -- the reference's update rules.  n <= 7.  Stream-ordered. */
+int dsg_co_minlp_search(const double* params, const double* choices, int nch, double* Y, int* tolerable, long long rows, int n,
+                        double F_t, double P_t, double P_I, double theta, void* stream);
 
 /* Measurement hooks for bench.py: the per-step operator list and a timed replay of one operator's kernel with HIP
  * events on `stream` (rows = B rows, both passes, as inside dsg_sample). */

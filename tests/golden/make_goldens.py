@@ -11,7 +11,7 @@ Groups follow SURVEY.md section 8(c): G1 schedule, G2 denoiser forward (+ per
 module taps), G3 DDPM.forward loss/grads, G4 DDPM.sample trajectories (NU
 checkpoint + synthetic), G5 decoders/evaluators, G6 loaders on CSV slices,
 G7 state-dict layout + EMA, G8 the MSR label generator, G9 the CO self-check harness,
-G10 DDPM.sample at T = 1000 (BASELINE config 2's schedule length).
+G10 DDPM.sample at T = 1000 (BASELINE config 2's schedule length), G11 the CO label generator.
 """
 import json
 import os
@@ -439,7 +439,28 @@ def g10():
     save("g4_sample_msr3_T1000.npz", **out)
 
 
+# ---------------------------------------------------------------- G11
+def g11():
+    """utils/dataset_generate.py:147-245: CONV_CO_MINLP_GEN (exhaustive-search labels of the CO problem), float64.
+    The reference calls `np.alltrue`, which numpy 2 removed: it is aliased to `np.all` (its definition) for this run only."""
+    import contextlib, io
+    import utils.dataset_generate as DG
+    had = hasattr(np, "alltrue")
+    if not had:
+        np.alltrue = np.all
+    out = {}
+    for tag, n, samples, seed in (("n2", 2, 6, 2024), ("n3", 3, 8, 2025), ("n4", 4, 1, 2026)):
+        np.random.seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()) as buf, contextlib.redirect_stderr(io.StringIO()):
+            X, Y = DG.CONV_CO_MINLP_GEN(n, samples)
+        out[tag + "_X"], out[tag + "_Y"], out[tag + "_seed"] = X, Y, np.int64(seed)
+        print(tag, X.shape, Y.shape, buf.getvalue().splitlines()[0])
+    if not had:
+        del np.alltrue
+    save("g11_co_minlp.npz", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10)
+    groups = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

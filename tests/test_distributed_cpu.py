@@ -76,6 +76,49 @@ def _worker(rank, ws, port, q):
         d._grad_work = torch.full((total,), 1.0)
         d._publish(torch.tensor(2.0))
         assert torch.all(d.model.final.bias.grad == want + 2.0)
+        # ---- the train entry points' data-parallel plumbing (train.dp_context / make_loader / sync_replicas / run_epochs) with a
+        # stand-in for the fused HIP step: replicas that start from different weights and see different row shards must hold
+        # bit-identical weights after two steps, and only rank 0 reports
+        from diffsg_amd import train as tr
+        from diffsg_amd.ddpm import _PublishGrads
+        dev_, rank_, world_ = tr.dp_context()
+        assert (rank_, world_) == (rank, ws) and dev_ is None        # no GPU here: the entry points raise at this point
+        assert torch.initial_seed() != 0 or rank == 0                # per-rank seed offset applied
+        torch.manual_seed(100 + rank)
+        m2 = UNet1D(input_dim=3, proj_dim=16, cond_dim=3, dims=(16, 8, 4), is_attn=(False,) * 3, n_blocks=2)
+        d2 = DDPM(20, m2, 3, 10.0, 1.0 - generate_cosine_schedule(20), torch.device("cpu"), (1, 3), None)
+        w0 = d2.model.final.weight.detach().clone()
+        tr.sync_replicas(d2)
+        ws_ = [torch.zeros_like(w0) for _ in range(ws)]
+        dist.all_gather(ws_, d2.model.final.weight.detach().clone())
+        assert torch.equal(ws_[0], ws_[1]) and (rank == 0) == torch.equal(ws_[0], w0)
+        total2 = sum(p.numel() for p in d2.model.parameters())
+        seen = []
+
+        def fake_forward(y, cond):                                    # loss and "gradients" that depend on this rank's rows
+            seen.append(y[:, 0].clone())
+            d2._grad_work = torch.full((total2,), float(y.mean()))
+            if getattr(d2, "_grad_bucket", None) is None:
+                d2._grad_bucket = torch.zeros(total2)
+                d2._loss_anchor = torch.zeros((), requires_grad=True)
+            return _PublishGrads.apply(d2._loss_anchor, y.mean().detach(), d2)
+        d2.forward = fake_forward
+        rows = torch.arange(40, dtype=torch.float32)[:, None].repeat(1, 3)
+        ds = torch.utils.data.TensorDataset(rows.clone(), rows.clone())
+        loader = tr.make_loader(ds, 10, rank, ws, seed=3)
+        opt = tr.FlatAdam(d2, lr=1e-2, fused=False)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, [5])
+        logs = []
+        before = d2.model.final.weight.detach().clone()
+        tr.run_epochs(d2, loader, opt, sched, 1, False, 5, torch.device("cpu"), logs.append)
+        assert len(seen) == 2 and (len(logs) == 1) == (rank == 0)
+        mine = torch.cat(seen)
+        both = [torch.zeros_like(mine) for _ in range(ws)]
+        dist.all_gather(both, mine)
+        assert sorted(torch.cat(both).tolist()) == list(map(float, range(40)))   # the ranks' shards partition the rows
+        after = d2.model.final.weight.detach().clone()
+        dist.all_gather(ws_, after)
+        assert torch.equal(ws_[0], ws_[1]) and not torch.equal(after, before)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback

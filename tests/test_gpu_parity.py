@@ -804,3 +804,34 @@ def test_sum_rate_gen_draws_gains_like_the_reference():
     gs, rates, schemes = SUM_RATE_GEN(sample_num=7, M=5, W=10.0)
     np.random.seed(11)
     assert np.array_equal(gs, np.random.uniform(0.5, 2.5, size=(7, 5))) and rates.shape == (7,) and schemes.shape == (7, 5)
+
+
+# ---------------------------------------------------------------- CO label generator
+@pytest.mark.parametrize("tag,n", [("n2", 2), ("n3", 3), ("n4", 4)])
+def test_co_minlp_gen_matches_reference_goldens(gold, tag, n):
+    """CONV_CO_MINLP_GEN on the device (dsg_co_minlp_search) against the reference's own outputs for the same numpy seed:
+    features and labels (decision | allocation | cost) bit for bit -- the search is exact float64 in the reference's order."""
+    from diffsg_amd.labelgen import CONV_CO_MINLP_GEN
+    g = gold("g11_co_minlp.npz")
+    Xr, Yr = g[tag + "_X"], g[tag + "_Y"]
+    np.random.seed(int(g[tag + "_seed"]))
+    logs = []
+    X, Y = CONV_CO_MINLP_GEN(n, Xr.shape[0], log=logs.append)
+    assert np.array_equal(X, Xr)
+    assert np.array_equal(Y, Yr), np.abs(Y - Yr).max()
+    assert logs[0].endswith("satisfy the tolerable delay.") and logs[1].endswith("ms per sample.")
+
+
+@pytest.mark.parametrize("n,samples", [(1, 5), (3, 300), (5, 2)])
+def test_co_minlp_gen_vs_oracle(n, samples):
+    from diffsg_amd.labelgen import CONV_CO_MINLP_GEN
+    from oracle import co_minlp_oracle as C
+    np.random.seed(50 + n)
+    X, Y = CONV_CO_MINLP_GEN(n, samples, log=lambda *_: None)
+    np.random.seed(50 + n)
+    if n == 5:      # 50^5 allocations per decision: the numpy restatement needs minutes; check the properties instead
+        D, F = Y[:, :n], Y[:, n:2 * n]
+        assert np.all((F > 0) == (D > 0)) and np.allclose(F.sum(1)[D.sum(1) > 0], 1.0, atol=1e-5) and np.all(np.isfinite(Y))
+        return
+    Xo, Yo, _ = C.conv_co_minlp_gen(n, samples)
+    assert np.array_equal(X, Xo) and np.array_equal(Y, Yo)

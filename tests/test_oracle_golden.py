@@ -198,3 +198,19 @@ def test_g8_sum_rate_label_generator(gold):
         assert np.allclose(schemes, g[tag + "_schemes"], rtol=1e-11, atol=1e-13), tag
         assert np.allclose(rates, g[tag + "_rates"], rtol=1e-12), tag
         assert np.allclose(schemes.sum(1), float(g[tag + "_W"]), rtol=1e-12), tag     # total power is conserved
+
+
+@pytest.mark.parametrize("tag,n", [("n2", 2), ("n3", 3), ("n4", 4)])
+def test_g11_co_minlp_label_generator(gold, tag, n):
+    """CONV_CO_MINLP_GEN (utils/dataset_generate.py:147-245): the restatement replays the reference's numpy draws from the
+    same seed and must reproduce its features and labels (decision | allocation | cost) bit for bit."""
+    from oracle import co_minlp_oracle as C
+    g = gold("g11_co_minlp.npz")
+    Xr, Yr = g[tag + "_X"], g[tag + "_Y"]
+    np.random.seed(int(g[tag + "_seed"]))
+    X, Y, hits = C.conv_co_minlp_gen(n, Xr.shape[0])
+    assert np.array_equal(X, Xr)
+    assert np.array_equal(Y, Yr), np.abs(Y - Yr).max()
+    # domain properties: an offloading decision's allocation sums to 1 and is zero where nothing is offloaded
+    D, F = Y[:, :n], Y[:, n:2 * n]
+    assert np.all((F > 0) == (D > 0)) and np.allclose(F.sum(1)[D.sum(1) > 0], 1.0, atol=1e-5)
