@@ -268,6 +268,19 @@ class UNet1D(nn.Module):
         code = {"split_f16": 0, "f32": 1}[mode]
         _lib.check(_lib.lib().dsg_set_precision(self.native_handle(), code))
 
+    def range_exceeded(self):
+        """True if, since the last query, a raw operand of the split-f16 path left fp16's range (dsg_range_status;
+        synchronises the device and clears the flag).  Outputs computed meanwhile are then wrong."""
+        flag = ctypes.c_int(0)
+        _lib.check(_lib.lib().dsg_range_status(self.native_handle(), ctypes.byref(flag)))
+        return bool(flag.value)
+
+    def check_range(self):
+        """Raise if `range_exceeded()`: the caller should switch to `set_precision("f32")` and repeat the call."""
+        if self.range_exceeded():
+            raise RuntimeError("libdiffsg_hip: an activation exceeded the fp16 range of the split-f16 path (|x| > 6e4); "
+                               "the results of the last calls are invalid -- use set_precision('f32') for this model")
+
     def set_launch_policy(self, coop_max_tiles=-1, narrow_small_max_tiles=-1):
         """Kernel forms by launch size (dsg_set_launch_policy): launches of at most `coop_max_tiles` 32-row tiles run
         the wide blocks cooperatively, at most `narrow_small_max_tiles` the small-launch narrow run; -1 = default,

@@ -99,6 +99,8 @@ _SIGS = {
     "dsg_bind_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
     "dsg_set_precision": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "dsg_set_launch_policy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "dsg_set_renorm_hook": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "dsg_range_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "dsg_build_id": (ctypes.c_char_p, []),
     "dsg_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "dsg_train_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
@@ -133,6 +135,9 @@ _SIGS = {
     "dsg_time_op": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                    ctypes.c_void_p]),
 }
+
+
+RENORM_REDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 
 
 def exported_symbols():

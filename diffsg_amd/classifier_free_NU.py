@@ -112,7 +112,7 @@ def load_test_nu(ckpt_path, dataset_path=DEFAULT_DATASET, T=20, omega=500, batch
     diffusion_model.load_state_dict(torch.load(ckpt_path, map_location="cpu"))
     diffusion_model.to(device)
     X = torch.tensor(X_test, dtype=torch.float32)
-    Y_pred = torch.cat([diffusion_model.sample(X[i:i + batch_size].to(device), omega) for i in range(0, len(X), batch_size)])
+    Y_pred = torch.cat([diffusion_model.sample_checked(X[i:i + batch_size].to(device), omega) for i in range(0, len(X), batch_size)])
     Xt = X.to(device).clone()
     Xt[:, 0::2] *= width
     Xt[:, 1::2] *= height

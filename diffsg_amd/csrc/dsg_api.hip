@@ -142,6 +142,7 @@ struct dsg_handle {
     const float** mx_ptrs_dev = nullptr; long long* mx_numel_dev = nullptr; int* mx_idx_dev = nullptr; int mx_n = 0;
     std::vector<int> mx_param;         // param index of each k_maxabs block
     PackHDesc* packh_dev = nullptr; int packh_n = 0; long long packh_blocks = 0;
+    OpConstDesc* opc_desc_dev = nullptr; float* opc_dev = nullptr;   // [res | lin][4]: un-scale factors, refreshed at every bind (k_op_consts)
 
     // forward workspace
     int cap_rows = 0, cap_entries = 0;
@@ -161,6 +162,9 @@ struct dsg_handle {
     float* freq = nullptr;      // [proj/2]
     double* red = nullptr;      // [2][kRedBlocks]
     int* step_dev = nullptr;
+    double* renorm_stats = nullptr;              // dsg_set_renorm_hook: caller's 3 doubles (device), reduced across ranks by `renorm_fn`
+    void (*renorm_fn)(void*) = nullptr; void* renorm_user = nullptr;
+    int* range_flag = nullptr;   // device word: a raw split-path operand left fp16's range since the last dsg_range_status
     CallParams* call_dev = nullptr;
     hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream)
     std::vector<double> op_ms;   // DSG_SAMPLE_PROFILE: summed HIP-event time per op
@@ -546,6 +550,11 @@ void fill_block_args(const dsg_handle* h, const Op& op, const RunCtx& c, BlockAr
     if (c.train) { a.save_h1 = trp(h, r.h1); a.save_h2 = trp(h, r.h2); }
     if (c.cond_pre) a.cond_pre = h->cembed + r.ce_off * (cap_tiles_of(h) / 2);
     a.ntiles = tpp * c.npass; a.tiles_per_pass = tpp; a.uncond_tiles = c.uncond_tiles; a.nrows = c.nrows;
+    a.range_flag = h->range_flag;
+    {
+        const float n0 = (float)a.in0.width, n1 = (float)a.in1.width, nt = n0 + n1;
+        a.chan_w = n0 * n1 / nt; a.chan_f = n1 / nt; a.inv_nin = 1.0f / nt;
+    }
 }
 
 void fill_lin_args(const dsg_handle* h, const Op& op, const RunCtx& c, LinArgs& a) {
@@ -557,6 +566,8 @@ void fill_lin_args(const dsg_handle* h, const Op& op, const RunCtx& c, LinArgs& 
     a.in_width = l.l.K; a.in_groups = groups_of(l.l.K);
     a.out_width = l.l.N;
     a.ntiles = tpp * c.npass; a.tiles_per_pass = tpp; a.nrows = c.nrows;
+    a.range_flag = h->range_flag;
+    a.inv_in_w = 1.0f / (float)l.l.K; a.inv_out_w = 1.0f / (float)l.l.N;
     if (op.kind == OP_PROJ) {
         a.in_rm = c.y; a.advance_step = c.advance_step;
         if (c.share_proj) a.ntiles = tpp;            // one pass: the second pass's consumers wrap onto these tiles
@@ -578,11 +589,13 @@ void fill_block_args_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, B
     a.W1h = reinterpret_cast<const uint4*>(A + r.W1h); a.W2h = reinterpret_cast<const uint4*>(A + r.W2h);
     a.W3h = reinterpret_cast<const uint4*>(A + r.W3h); a.Wsch = r.sclin ? reinterpret_cast<const uint4*>(A + r.Wsch) : nullptr;
     a.m1 = h->maxabs + r.l1.w; a.m2 = h->maxabs + r.l2.w; a.m3 = h->maxabs + r.l3.w; a.msc = r.sclin ? h->maxabs + r.sc.w : nullptr;
+    a.kc = h->opc_dev + 4 * (size_t)(&r - h->res.data());
 }
 void fill_lin_args_h(const dsg_handle* h, const LinOpP& l, const LinArgs& b, LinArgsH& a) {
     a.l = b;
     a.Wh = reinterpret_cast<const uint4*>(h->arena + l.Wh);
     a.m = h->maxabs + l.l.w;
+    a.kc = h->opc_dev + 4 * (h->res.size() + (size_t)(&l - h->lin.data()));
 }
 
 template <int N>
@@ -1243,9 +1256,19 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
               hipMalloc(&h->tdesc_dev, h->res.size() * sizeof(TimeBlockDesc)) == hipSuccess &&
               hipMalloc(&h->freq, (d.proj_dim / 2) * sizeof(float)) == hipSuccess &&
               hipMalloc(&h->red, 2 * kRedBlocks * sizeof(double)) == hipSuccess &&
-              hipMalloc(&h->step_dev, 64) == hipSuccess &&
+              hipMalloc(&h->step_dev, 128) == hipSuccess &&
+              hipMemset(h->step_dev, 0, 128) == hipSuccess &&
               hipMalloc(&h->call_dev, sizeof(CallParams)) == hipSuccess &&
               hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
+    if (ok) h->range_flag = h->step_dev + 16;      // its own 64-byte line of the same small allocation
+    if (ok) {
+        std::vector<OpConstDesc> oc;
+        for (const ResP& r : h->res) oc.push_back(OpConstDesc{r.l1.w, r.l2.w, r.l3.w, r.sclin ? r.sc.w : -1});
+        for (const LinOpP& l : h->lin) oc.push_back(OpConstDesc{l.l.w, -1, -1, -1});
+        ok = hipMalloc(&h->opc_desc_dev, oc.size() * sizeof(OpConstDesc)) == hipSuccess &&
+             hipMalloc(&h->opc_dev, oc.size() * 4 * sizeof(float)) == hipSuccess &&
+             hipMemcpy(h->opc_desc_dev, oc.data(), oc.size() * sizeof(OpConstDesc), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (ok) {
         // freq[k] = exp(k * -(ln 1e4 / (half-1))) in float32 (UNetCF.py:37-38)
         const int half = d.proj_dim / 2;
@@ -1266,7 +1289,7 @@ void dsg_destroy(dsg_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev, h->maxabs,
-                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->fusedh_dev, h->fusedh_train_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->ce_dev, h->ctile_dev};
+                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->opc_desc_dev, h->opc_dev, h->fusedh_dev, h->fusedh_train_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->ce_dev, h->ctile_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1429,6 +1452,8 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
         HIPCK(hipMemsetAsync(h->maxabs, 0, h->params.size() * sizeof(float), s));
         hipLaunchKernelGGL(k_maxabs, dim3(h->mx_n, kMaxabsSlices), dim3(256), 0, s, h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->maxabs);
         hipLaunchKernelGGL(k_pack_h, dim3((unsigned)h->packh_blocks), dim3(256), 0, s, h->packh_dev, h->packh_n);
+        const int nopc = (int)(h->res.size() + h->lin.size());
+        hipLaunchKernelGGL(k_op_consts, dim3(cdiv(nopc, 64)), dim3(64), 0, s, h->maxabs, h->opc_desc_dev, nopc, h->opc_dev);
     }
     HIPCK(hipGetLastError());
     h->bound = true;
@@ -1440,6 +1465,21 @@ int dsg_set_precision(dsg_handle* h, int mode) {
     if (mode != DSG_PRECISION_SPLIT_F16 && mode != DSG_PRECISION_F32_MFMA) return fail("unknown precision mode %d", mode);
     const bool split = mode == DSG_PRECISION_SPLIT_F16;
     if (split != h->use_split) { (void)hipDeviceSynchronize(); free_graphs(h); h->use_split = split; }
+    return 0;
+}
+
+int dsg_set_renorm_hook(dsg_handle* h, double* stats3, void (*reduce)(void*), void* user) {
+    if (!h) return fail("null handle");
+    if (reduce && !stats3) return fail("dsg_set_renorm_hook: a reduce function needs the 3-double device buffer");
+    h->renorm_stats = stats3; h->renorm_fn = reduce; h->renorm_user = user;
+    return 0;
+}
+
+int dsg_range_status(dsg_handle* h, int* exceeded) {
+    if (!h || !exceeded) return fail("dsg_range_status: null argument");
+    HIPCK(hipDeviceSynchronize());
+    HIPCK(hipMemcpy(exceeded, h->range_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (*exceeded) HIPCK(hipMemset(h->range_flag, 0, sizeof(int)));
     return 0;
 }
 
@@ -1500,7 +1540,15 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
     UpdateArgs ua = u;
     ua.record_y = renorm ? 0 : 1;
     hipLaunchKernelGGL(k_update, dim3(ublocks), dim3(256), 0, s, ua);
-    if (renorm) {   // the record is of the renormalised y (MSR.py:136-141): separate launches on these (at most 4) steps
+    if (renorm && h->renorm_fn) {
+        // sharded call that standardises with the statistics of the WHOLE batch (MSR.py:136-137 on the concatenation of all
+        // ranks' rows): local moments -> the caller's all-reduce of 3 doubles (enqueued on this stream) -> apply
+        hipLaunchKernelGGL(k_renorm_moments, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
+        hipLaunchKernelGGL(k_renorm_moments_final, dim3(1), dim3(1), 0, s, h->red, h->red + kRedBlocks, u.n, h->renorm_stats);
+        h->renorm_fn(h->renorm_user);
+        hipLaunchKernelGGL(k_renorm_apply_stats, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->renorm_stats);
+        hipLaunchKernelGGL(k_record, dim3(ublocks), dim3(256), 0, s, u.y, u.n, u.cp, u.step_ptr);
+    } else if (renorm) {   // the record is of the renormalised y (MSR.py:136-141): separate launches on these (at most 4) steps
         hipLaunchKernelGGL(k_renorm_sum, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red);
         hipLaunchKernelGGL(k_renorm_sqdiff, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
         hipLaunchKernelGGL(k_renorm_apply, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
@@ -1589,7 +1637,13 @@ int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const flo
             }
             h->g_rows = B;
         }
-        for (int k = 0; k < T; ++k) HIPCK(hipGraphLaunch(h->gexec[k < n_renorm ? 0 : 1], s));
+        for (int k = 0; k < T; ++k) {
+            if (k < n_renorm && h->renorm_fn) {          // the hook calls back into the host: these (<= 4) steps run eagerly
+                if (enqueue_step(h, c, u, true, s)) return 1;
+            } else {
+                HIPCK(hipGraphLaunch(h->gexec[k < n_renorm ? 0 : 1], s));
+            }
+        }
     }
     HIPCK(hipMemcpyAsync(out, h->ywork, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;

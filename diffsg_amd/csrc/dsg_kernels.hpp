@@ -252,6 +252,10 @@ struct BlockArgs {
     int tiles_per_pass;
     int uncond_tiles;     // tiles [0, uncond_tiles) skip the condition term (Swish(0) = 0)
     int nrows;            // valid rows per pass
+    int* range_flag;      // split path: set to 1 when a RAW operand row may exceed fp16's range (dsg_range_status), or null
+    // host-side constants of the LN1 statistics merge (Chan) over the concat: n0*n1/(n0+n1), n1/(n0+n1), 1/(n0+n1) -- three
+    // float divisions per wave and block otherwise (~30 VALU; the narrow blocks have ~170 VALU of real work)
+    float chan_w, chan_f, inv_nin;
 };
 
 template <int N, bool SCLIN>
@@ -416,6 +420,8 @@ struct LinArgs {
     int ntiles, tiles_per_pass, nrows;
     int* advance_step;      // reverse loop: the step's first operator (feature_proj, which does not read the step index)
                             // moves it on - no kernel of its own, and nothing else is running that could read it
+    int* range_flag;        // split path: see BlockArgs::range_flag
+    float inv_in_w, inv_out_w;   // 1 / in_width, 1 / out_width (host)
 };
 
 enum { IN_FRAG = 0, IN_ROWMAJOR = 1 };
@@ -906,6 +912,32 @@ __global__ __launch_bounds__(256) void k_renorm_sqdiff(const float* __restrict__
     if (threadIdx.x == 0) part2[blockIdx.x] = s;
 }
 
+// Sharded form of the early-step renorm (dsg_set_renorm_hook): the shard's (sum y, sum y^2, count) in float64 -- the caller
+// sums the three over the ranks -- then the same standardisation from the reduced moments.
+__global__ __launch_bounds__(256) void k_renorm_moments(const float* __restrict__ y, size_t n, double* __restrict__ part, double* __restrict__ part2) {
+    __shared__ double sm[4];
+    double s = 0.0, q = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = (double)y[i];
+        s += v; q += v * v;
+    }
+    s = block_sum(s, sm);
+    __syncthreads();
+    q = block_sum(q, sm);
+    if (threadIdx.x == 0) { part[blockIdx.x] = s; part2[blockIdx.x] = q; }
+}
+__global__ void k_renorm_moments_final(const double* __restrict__ part, const double* __restrict__ part2, size_t n, double* __restrict__ stats3) {
+    double tot = 0.0, tot2 = 0.0;
+    for (int i = 0; i < kRedBlocks; ++i) { tot += part[i]; tot2 += part2[i]; }
+    stats3[0] = tot; stats3[1] = tot2; stats3[2] = (double)n;
+}
+__global__ __launch_bounds__(256) void k_renorm_apply_stats(float* __restrict__ y, size_t n, const double* __restrict__ stats3) {
+    const double N = stats3[2], m = stats3[0] / N;
+    const float mean = (float)m;
+    const float sd = sqrtf((float)((stats3[1] - N * m * m) / (N - 1.0)));
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = (y[i] - mean) / sd;
+}
 __global__ __launch_bounds__(256) void k_renorm_apply(float* __restrict__ y, size_t n, const double* __restrict__ part,
                                                       const double* __restrict__ part2) {
     double tot = 0.0, tot2 = 0.0;

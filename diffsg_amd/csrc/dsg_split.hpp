@@ -25,6 +25,14 @@ typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
 
 constexpr float kActScale = 16.0f;       // B operands that are LayerNorm+SiLU outputs (bounded by ~sqrt(width))
 constexpr float kRawScale = 1.0f;        // B operands that are raw residual-stream values
+// Raw operands (Linear shortcut, Down/Upsample, feature_proj) go through v_cvt_pkrtz unnormalised: beyond +-65504 the hi part
+// saturates (round-toward-zero never gives inf) and the product is silently wrong.  Every kernel that splits a raw operand
+// bounds its rows -- |mean| + sqrt(M2) >= max|x| from the LayerNorm statistics it has anyway -- and raises the handle's range
+// flag above this limit; dsg_range_status reports it (the caller then switches to DSG_PRECISION_F32_MFMA).
+constexpr float kRawLimit = 6.0e4f / kRawScale;
+__device__ __forceinline__ void range_check(int* flag, float mean, float m2) {
+    if (flag && fabsf(mean) + sqrtf(m2) > kRawLimit) *flag = 1;
+}
 
 // Weight scale exponent of one Linear from max|W|: max|W| * 2^e in [4096, 8192).
 __device__ __forceinline__ int scale_exp(float maxabs) {
@@ -73,6 +81,18 @@ __device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[NT], const HFrag<NT>& 
     for (int nt = 0; nt < NT; ++nt) DSG_MFMA_H(acc[nt], __builtin_bit_cast(h8, w.lo[nt]), bhi);
 }
 
+// first k16-step of a chain: the hi*hi products start from the inline constant 0 (no zero-fill of the 16 * NT accumulators)
+template <int NT>
+__device__ __forceinline__ void mfma_step_h0(f32x16 (&acc)[NT], const HFrag<NT>& w, const h8 bhi, const h8 blo) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, w.hi[nt]), bhi, z, 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) DSG_MFMA_H(acc[nt], __builtin_bit_cast(h8, w.hi[nt]), blo);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) DSG_MFMA_H(acc[nt], __builtin_bit_cast(h8, w.lo[nt]), bhi);
+}
+
 // kActScale * silu(u): the scale rides in the denominator (u * rcp((1 + e)/16)). exp(-u) is one v_exp_f32 of the rounded
 // product u * log2(e): its rounding moves exp by at most |u| * 4e-8 relative, which only matters where silu is already
 // ~0 (a compensated form was measured: no accuracy gain on any parity case, 4% of the wide operator's time)
@@ -92,7 +112,7 @@ __device__ __forceinline__ void act8(float (&v)[8], const float4 x0, const float
 
 // Register-fed stage (stages 2 and 3): B = split(16 * silu(LN(in))).  An odd group count (N = 8, 4) pairs the last group
 // with the accumulator's zero padding (rows >= N of the producer's packed weights and biases are zero).
-template <int N, int NT, int NTI = NT>
+template <int N, int NT, int NTI = NT, bool ZERO = false>
 __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16 (&in)[NTI], const uint4* __restrict__ wp,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float mean, float rstd,
                                                  int lane, int h, size_t nt_stride_override = 0, const HFrag<NT>* w0 = nullptr) {
@@ -130,13 +150,14 @@ __device__ __forceinline__ void chain_from_acc_h(f32x16 (&out)[NT], const f32x16
         }
         h8 bhi, blo;
         split8(v, bhi, blo);
-        mfma_step_h<NT>(out, wc, bhi, blo);
+        if (ZERO && S == 0) mfma_step_h0<NT>(out, wc, bhi, blo);   // `out` is undefined on entry: the chain starts from the constant 0
+        else mfma_step_h<NT>(out, wc, bhi, blo);
     }
 }
 
 // Register-fed RAW stage (no LayerNorm / SiLU): Linear shortcut and the plain Linears of the narrow run when their input
 // lives in registers.  `groups` (runtime, <= 4*NT) real groups; the missing group of an odd count is accumulator padding.
-template <int NT, int NTI = NT>
+template <int NT, int NTI = NT, bool ZERO = false>
 __device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f32x16 (&in)[NTI], int groups, const uint4* __restrict__ wp,
                                                      size_t nt_stride, int lane, const HFrag<NT>* w0 = nullptr) {
     const int steps = (groups + 1) >> 1;
@@ -152,7 +173,8 @@ __device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f3
             for (int p = 0; p < 8; ++p) v[p] = kRawScale * in[t][r0 + p];
             h8 bhi, blo;
             split8(v, bhi, blo);
-            mfma_step_h<NT>(out, w, bhi, blo);
+            if (ZERO && S == 0) mfma_step_h0<NT>(out, w, bhi, blo);
+            else mfma_step_h<NT>(out, w, bhi, blo);
         }
     }
 }
@@ -226,6 +248,8 @@ struct BlockArgsH {
     const float* m2;
     const float* m3;
     const float* msc;
+    const float* kc;         // device: { 2^-e1 / 16, 2^-e2 / 16, 2^-e3 / 16 } of this block, computed ONCE at bind time (k_op_consts)
+                             // from the same max|W| -- scale_exp is a log2 + floor + ldexp per stage, per wave, per block otherwise
 };
 
 // Needs cond_pre: the condition embedding Wc silu(cond*mask) is precomputed per call (sampling) or per step (training)
@@ -255,23 +279,20 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     // ---- LN1 statistics (Chan merge of the producers' (mean, M2))
     float mean1, rstd1;
     {
-        float mean, m2, n = (float)a.in0.width;
+        float mean, m2;
         if (XIN) { mean = *xr_mean; m2 = *xr_m2; }
         else { const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)seg_tile(a.in0, tile) * 32 + j]; mean = s0.x; m2 = s0.y; }
         if (a.in1.groups) {
             const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)seg_tile(a.in1, tile) * 32 + j];
-            const float n1 = (float)a.in1.width, nt_ = n + n1;
             const float dd = s1.x - mean;
-            m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
-            mean = mean + dd * (n1 / nt_);
-            n = nt_;
+            m2 = m2 + s1.y + dd * dd * a.chan_w;
+            mean = mean + dd * a.chan_f;
         }
         mean1 = mean;
-        rstd1 = rsqrtf(m2 / n + kLnEps);
+        rstd1 = rsqrtf(m2 * a.inv_nin + kLnEps);
+        if (SCLIN) range_check(a.range_flag, mean, m2);
     }
-    const int e1 = scale_exp(*ah.m1), e2 = scale_exp(*ah.m2);
-    const int e3 = SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3);
-    const float inv1 = ldexpf(1.0f / kActScale, -e1), inv2 = ldexpf(1.0f / kActScale, -e2), inv3 = ldexpf(1.0f / kActScale, -e3);
+    const float inv1 = ah.kc[0], inv2 = ah.kc[1], inv3 = ah.kc[2];
     // Narrow run, small launches (PRE): a stage is one or two k16-steps, so the first step of every chain is an exposed L2
     // round trip unless its planes are requested before the previous stage's arithmetic: request all six of them now.  (Costs
     // ~40 VGPRs: the large-launch form of the narrow kernel keeps four waves per SIMD instead.)
@@ -290,14 +311,16 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
 
     // ---- stage 1
     f32x16 acc1[NT];
+    if (!XIN) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
+    }
     {
         const size_t nt_stride = (size_t)KS1 * 128;
         if (XIN)    // in0 has the block's own width N here (down / middle: in = N; up: cat(N, N))
-            chain_from_acc_h<N, NT>(acc1, *xr, ah.W1h, gamma1, beta1, mean1, rstd1, lane, h, nt_stride, PRE ? &p1a : nullptr);
+            chain_from_acc_h<N, NT, NT, true>(acc1, *xr, ah.W1h, gamma1, beta1, mean1, rstd1, lane, h, nt_stride, PRE ? &p1a : nullptr);
         else
             chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
                                        gamma1 + 4 * h, beta1 + 4 * h, mean1, rstd1);
@@ -325,15 +348,11 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
 
     // ---- stage 2
     f32x16 acc2[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.f;
     {
         float mean, m2;
         acc_stats<N, NT>(acc1, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
-        chain_from_acc_h<N, NT>(acc2, acc1, ah.W2h, gamma2, beta2, mean, rstd, lane, h, 0, PRE ? &p2 : nullptr);
+        chain_from_acc_h<N, NT, NT, true>(acc2, acc1, ah.W2h, gamma2, beta2, mean, rstd, lane, h, 0, PRE ? &p2 : nullptr);
         acc_unscale_add<NT, NG>(acc2, inv2, a.c2, h);
     }
     if (tile >= a.uncond_tiles) {
@@ -355,15 +374,11 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
 
     // ---- stage 3 (+ shortcut in the same scaled accumulator)
     f32x16 (&acc3)[NT] = acc1;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc3[nt][r] = 0.f;
     {
         float mean, m2;
         acc_stats<N, NT>(acc2, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
-        chain_from_acc_h<N, NT>(acc3, acc2, ah.W3h, gamma3, beta3, mean, rstd, lane, h, 0, PRE ? &p3 : nullptr);
+        chain_from_acc_h<N, NT, NT, true>(acc3, acc2, ah.W3h, gamma3, beta3, mean, rstd, lane, h, 0, PRE ? &p3 : nullptr);
     }
     if (SCLIN) {
         const size_t nt_stride = (size_t)KS1 * 128;
@@ -512,21 +527,18 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
     float mean1, rstd1;
     {
         const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)seg_tile(a.in0, tile) * 32 + j];
-        float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
+        float mean = s0.x, m2 = s0.y;
         if (a.in1.groups) {
             const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)seg_tile(a.in1, tile) * 32 + j];
-            const float n1 = (float)a.in1.width, nt_ = n + n1;
             const float dd = s1.x - mean;
-            m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
-            mean = mean + dd * (n1 / nt_);
-            n = nt_;
+            m2 = m2 + s1.y + dd * dd * a.chan_w;
+            mean = mean + dd * a.chan_f;
         }
         mean1 = mean;
-        rstd1 = rsqrtf(m2 / n + kLnEps);
+        rstd1 = rsqrtf(m2 * a.inv_nin + kLnEps);
+        if (SCLIN) range_check(a.range_flag, mean, m2);
     }
-    const int e1 = scale_exp(*ah.m1), e2 = scale_exp(*ah.m2);
-    const int e3 = SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3);
-    const float inv1 = ldexpf(1.0f / kActScale, -e1), inv2 = ldexpf(1.0f / kActScale, -e2), inv3 = ldexpf(1.0f / kActScale, -e3);
+    const float inv1 = ah.kc[0], inv2 = ah.kc[1], inv3 = ah.kc[2];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- stage 1 operands: this wave transforms k16-steps w, w + NT, ... of the (concatenated) input
@@ -730,7 +742,26 @@ struct LinArgsH {
     LinArgs l;
     const uint4* Wh;   // [NT][ceil(KG/2)][2][64]
     const float* m;    // max|W|
+    const float* kc;   // device: { 2^-e (raw operand), 2^-e / 16 (LayerNorm + SiLU operand) } (k_op_consts)
 };
+
+// Bind-time constants of the split path: the un-scale factors of every block and Linear from max|W| (same arithmetic as the
+// kernels used per wave before: scale_exp / scale_exp_lin3 + ldexp).
+struct OpConstDesc { int w1, w2, w3, wsc; };   // parameter indices of lin1, lin2, lin3, shortcut (-1: none); Linear: w1 only
+__global__ void k_op_consts(const float* __restrict__ maxabs, const OpConstDesc* __restrict__ d, int n, float* __restrict__ out /* [n][4] */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const OpConstDesc c = d[i];
+    if (c.w2 < 0) {          // Linear
+        const int e = scale_exp(maxabs[c.w1]);
+        out[4 * i + 0] = ldexpf(1.0f / kRawScale, -e); out[4 * i + 1] = ldexpf(1.0f / kActScale, -e); out[4 * i + 2] = 0.f; out[4 * i + 3] = 0.f;
+        return;
+    }
+    const int e1 = scale_exp(maxabs[c.w1]), e2 = scale_exp(maxabs[c.w2]);
+    const int e3 = c.wsc >= 0 ? scale_exp_lin3(maxabs[c.w3], maxabs[c.wsc]) : scale_exp(maxabs[c.w3]);
+    out[4 * i + 0] = ldexpf(1.0f / kActScale, -e1); out[4 * i + 1] = ldexpf(1.0f / kActScale, -e2);
+    out[4 * i + 2] = ldexpf(1.0f / kActScale, -e3); out[4 * i + 3] = 0.f;
+}
 
 template <int NTO, int NTI, bool FINAL>
 __device__ __forceinline__ void linear_epilogue_h(const LinArgsH& ah, int tile, int lane, const f32x16 (&x)[NTI], float xmean, float xm2) {
@@ -739,17 +770,14 @@ __device__ __forceinline__ void linear_epilogue_h(const LinArgsH& ah, int tile, 
     const int KS = (a.in_groups + 1) >> 1;
     const size_t nt_stride = (size_t)KS * 128;
     f32x16 acc[NTO];
-#pragma unroll
-    for (int nt = 0; nt < NTO; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
     if (FINAL) {
-        const float rstd = rsqrtf(xm2 / (float)a.in_width + kLnEps);
-        chain_from_acc_h<NTI * 32, NTO, NTI>(acc, x, ah.Wh, a.gamma, a.beta, xmean, rstd, lane, h, nt_stride);
+        const float rstd = rsqrtf(xm2 * a.inv_in_w + kLnEps);
+        chain_from_acc_h<NTI * 32, NTO, NTI, true>(acc, x, ah.Wh, a.gamma, a.beta, xmean, rstd, lane, h, nt_stride);
     } else {
-        chain_raw_from_reg_h<NTO, NTI>(acc, x, a.in_groups, ah.Wh, nt_stride, lane);
+        range_check(a.range_flag, xmean, xm2);
+        chain_raw_from_reg_h<NTO, NTI, true>(acc, x, a.in_groups, ah.Wh, nt_stride, lane);
     }
-    acc_unscale_add<NTO>(acc, ldexpf(1.0f / (FINAL ? kActScale : kRawScale), -scale_exp(*ah.m)), a.bias, h);
+    acc_unscale_add<NTO>(acc, ah.kc[FINAL ? 1 : 0], a.bias, h);
     if (!FINAL) {
         const int NG = (a.out_width + 7) / 8;
         float s = 0.f;
@@ -758,7 +786,7 @@ __device__ __forceinline__ void linear_epilogue_h(const LinArgsH& ah, int tile, 
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 if (8 * G + 4 * h + p < a.out_width) s += acc[G >> 2][4 * (G & 3) + p];
-        const float m = xhalf_sum(s) / (float)a.out_width;
+        const float m = xhalf_sum(s) * a.inv_out_w;
         float q = 0.f;
 #pragma unroll
         for (int G = 0; G < NTO * 4; ++G)
@@ -830,8 +858,12 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
     if (LNACT) {
         const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)seg_tile(a.in, tile) * 32 + j];
         mean = s.x;
-        rstd = rsqrtf(s.y / (float)a.in.width + kLnEps);
+        rstd = rsqrtf(s.y * a.inv_in_w + kLnEps);
+    } else if (INMODE == IN_FRAG && a.range_flag && a.in.stats) {
+        const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)seg_tile(a.in, tile) * 32 + j];
+        range_check(a.range_flag, s.x, s.y);
     }
+    float vmax = 0.f;
     if (INMODE == IN_FRAG) {
         chain_from_mem_h<NT, LNACT>(acc, a.in.data + (size_t)seg_tile(a.in, tile) * KG * 256 + lane * 4, KG, ah.Wh + lane, nt_stride,
                                     LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
@@ -855,13 +887,15 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
                     v[jj] = (row < a.nrows && f < a.in_width) ? kRawScale * a.in_rm[(size_t)row * a.in_width + f] : 0.f;
                 }
             }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) vmax = fmaxf(vmax, fabsf(v[jj]));
             h8 bhi, blo;
             split8(v, bhi, blo);
             mfma_step_h<NT>(acc, wc, bhi, blo);
         }
+        if (a.range_flag && vmax > kRawLimit * kRawScale) *a.range_flag = 1;
     }
-    const float inv = ldexpf(1.0f / (LNACT ? kActScale : kRawScale), -scale_exp(*ah.m));
-    acc_unscale_add<NT>(acc, inv, a.bias, h);
+    acc_unscale_add<NT>(acc, ah.kc[LNACT ? 1 : 0], a.bias, h);
 
     if (OUTMODE == OUT_FRAG) {
         const int NG = (a.out_width + 7) / 8;
@@ -871,7 +905,7 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 if (8 * G + 4 * h + p < a.out_width) s += acc[G >> 2][4 * (G & 3) + p];
-        const float m = xhalf_sum(s) / (float)a.out_width;
+        const float m = xhalf_sum(s) * a.inv_out_w;
         float q = 0.f;
 #pragma unroll
         for (int G = 0; G < NT * 4; ++G)
@@ -938,10 +972,9 @@ __device__ __forceinline__ void linear_reg_h(const LinArgsH& ah, const int tile,
     const int h = lane >> 5, j = lane & 31;
     const int KS = (a.in_groups + 1) >> 1;
     f32x16 acc[1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-    chain_raw_from_reg_h<1>(acc, x, a.in_groups, ah.Wh, (size_t)KS * 128, lane);
-    acc_unscale_add<1>(acc, ldexpf(1.0f / kRawScale, -scale_exp(*ah.m)), a.bias, h);
+    range_check(a.range_flag, xmean, xm2);
+    chain_raw_from_reg_h<1, 1, true>(acc, x, a.in_groups, ah.Wh, (size_t)KS * 128, lane);
+    acc_unscale_add<1>(acc, ah.kc[0], a.bias, h);
     const int NG = (a.out_width + 7) / 8;
     float s = 0.f;
 #pragma unroll
@@ -949,7 +982,7 @@ __device__ __forceinline__ void linear_reg_h(const LinArgsH& ah, const int tile,
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             if (8 * G + 4 * h + p < a.out_width) s += acc[0][4 * G + p];
-    const float m = xhalf_sum(s) / (float)a.out_width;
+    const float m = xhalf_sum(s) * a.inv_out_w;
     float q = 0.f;
 #pragma unroll
     for (int G = 0; G < 4; ++G)

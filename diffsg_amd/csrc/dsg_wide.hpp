@@ -55,12 +55,13 @@ struct WideProg {
     const uint4 *w1, *w2, *w3, *wsc, *wl;   // this wave's out tile of each packed matrix (step 0, hi plane)
     int lin_spc;                  // epilogue Linear: k16-steps per chunk (4 / pow2(NTO))
     bool sclin;
+    int dbg;                      // measurement: 32 = the second read of x hits one hot KiB, 64 = so does the first read of in0
 
     __device__ __forceinline__ const void* source(int c) const {   // c may differ per lane
         const int iA = c, iB = c - cA, iC = c - cB, iD = c - cC, iE = c - cD, iF = c - cE;
         const int S1 = iA >> 1, SE = iE >> 1;
-        const void* xa = S1 < ks0 ? (const void*)(x0 + (size_t)S1 * 512) : (const void*)(x1 + (size_t)(S1 - ks0) * 512);
-        const void* xe = SE < ks0 ? (const void*)(x0 + (size_t)SE * 512) : (const void*)(x1 + (size_t)(SE - ks0) * 512);
+        const void* xa = S1 < ks0 ? (const void*)(x0 + ((dbg & 64) ? 0 : (size_t)S1 * 512)) : (const void*)(x1 + (size_t)(S1 - ks0) * 512);
+        const void* xe = (dbg & 32) ? (const void*)x0 : (SE < ks0 ? (const void*)(x0 + (size_t)SE * 512) : (const void*)(x1 + (size_t)(SE - ks0) * 512));
         const void* sA = (iA & 1) ? (const void*)(w1 + (size_t)S1 * 128) : xa;
         const void* sE = sclin ? ((iE & 1) ? (const void*)(wsc + (size_t)SE * 128) : xe) : (const void*)(x0 + (size_t)iE * 512);
         const void* r = wl + (size_t)iF * lin_spc * 128;
@@ -74,8 +75,12 @@ struct WideProg {
 };
 
 // Measurement switches (BlockLinArgsH::dbg, env DSG_WIDE_DBG read by the host launcher; results are WRONG with any of them
-// set -- they exist to time the kernel with one ingredient removed): 1 no barrier, 2 no DMA wait, 4 no MFMA, 8 no LayerNorm /
-// SiLU / split VALU, 16 no DMA issue.
+// set -- they exist to time the kernel with one ingredient removed): 1 no barrier, 2 no DMA wait, 16 no DMA issue, 32 / 64 hot-line sources
+// (the 4 = no MFMA and 8 = no LayerNorm / SiLU / split VALU switches of the sweep in DESIGN.md 3.2 were removed with it).  Compiled out unless the library is built with
+// -DDSG_WIDE_DBG_ENABLE=127 (tools/dbg_sweep.sh): the production kernel carries none of the branches.
+#ifndef DSG_WIDE_DBG_ENABLE
+#define DSG_WIDE_DBG_ENABLE 0
+#endif
 struct WideRing {
     int dbg;
     const uint4* rd;                 // the ring as ordinary LDS (+ lane)
@@ -142,7 +147,31 @@ __device__ __forceinline__ void wacc_zero(f32x16 (&acc)[NT]) {
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 }
 
-// register-fed stage over the ring: out += W * split(16 silu(LN(in))), two chunks (= two k16-steps x 4 out tiles) per event
+// B operand of one k16-step: split(16 silu(LN(x))) or split(x)
+struct BOp { h8 hi, lo; };
+template <bool LNACT>
+__device__ __forceinline__ BOp wide_prep(const float (&x)[8], const float* gamma, const float* beta, int S, float c, float d, int h) {
+    float v[8];
+    if (LNACT) {
+        const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
+        const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
+        act8_l2(v, x, c, d, g0, b0, g1, b1);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = kRawScale * x[q];
+    }
+    BOp b;
+    split8(v, b.hi, b.lo);
+    return b;
+}
+template <bool FIRST>
+__device__ __forceinline__ void wide_mma(f32x16 (&acc)[4], const HFrag<4>& w, const BOp& b) {
+    if (FIRST) mfma_step_h0<4>(acc, w, b.hi, b.lo); else mfma_step_h<4>(acc, w, b.hi, b.lo);
+}
+// register-fed stage over the ring: out = W * split(16 silu(LN(in))), two chunks (= two k16-steps x 4 out tiles) per event.
+// (A form software-pipelined by one step -- the operand of step S+1 computed next to the MFMAs of step S, with
+// sched_group_barrier asking for MFMA / 7 VALU / MFMA ... -- measured 105.3 vs 103.8 us on the dominant launch: the kernel is
+// not bound by the order of a wave's own VALU and MFMA instructions.  Taken out again.)
 __device__ __forceinline__ void wide_stage_reg(f32x16 (&out)[4], const f32x16 (&in)[4], WideRing& r, const float* gamma, const float* beta,
                                                float mean, float rstd, int h) {
     const float c = rstd, d = -mean * rstd;
@@ -154,48 +183,34 @@ __device__ __forceinline__ void wide_stage_reg(f32x16 (&out)[4], const f32x16 (&
             const int S = 2 * E + half, s = half ? ring_next(s0) : s0;
             HFrag<4> w;
             ring_wfrag<4>(w, r.rd + s * kChunkU4);
-            const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
-            const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
             const int t = S >> 1, r0 = 8 * (S & 1);
             const float x[8] = {in[t][r0], in[t][r0 + 1], in[t][r0 + 2], in[t][r0 + 3], in[t][r0 + 4], in[t][r0 + 5], in[t][r0 + 6], in[t][r0 + 7]};
-            float v[8];
-            h8 bhi, blo;
-            if (!(r.dbg & 8)) { act8_l2(v, x, c, d, g0, b0, g1, b1); split8(v, bhi, blo); }
-            else { bhi = __builtin_bit_cast(h8, make_float4(x[0], x[1], x[2], x[3])); blo = __builtin_bit_cast(h8, make_float4(x[4], x[5], x[6], x[7])); }
-            if (!(r.dbg & 4)) mfma_step_h<4>(out, w, bhi, blo);
-            else { out[0][0] += (float)bhi[0] + __builtin_bit_cast(float4, w.hi[0]).x; out[1][0] += (float)blo[0] + __builtin_bit_cast(float4, w.lo[3]).x; }
+            const BOp b = wide_prep<true>(x, gamma, beta, S, c, d, h);
+            if (S == 0) wide_mma<true>(out, w, b); else wide_mma<false>(out, w, b);
         }
     }
 }
 
-// memory-fed stage over the ring: per k16-step one private chunk (this wave's two groups of x) and one weight chunk
-template <bool LNACT>
+// memory-fed stage over the ring: per k16-step one private chunk (this wave's two groups of x) and one weight chunk.
+// FIRST: the chain starts here (accumulators undefined before).
+template <bool LNACT, bool FIRST>
+__device__ __forceinline__ void wide_mem_step(f32x16 (&acc)[4], int S, WideRing& r, int wave, const float* gamma, const float* beta, float c, float d,
+                                              int h) {
+    const int s0 = wide_event(r), s1 = ring_next(s0);
+    const uint4* xs = r.rd + s0 * kChunkU4 + (2 * wave) * 64;
+    const float4 xa = __builtin_bit_cast(float4, xs[0]), xb = __builtin_bit_cast(float4, xs[64]);
+    HFrag<4> w;
+    ring_wfrag<4>(w, r.rd + s1 * kChunkU4);
+    const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+    const BOp b = wide_prep<LNACT>(x, gamma, beta, S, c, d, h);
+    wide_mma<FIRST>(acc, w, b);
+}
+template <bool LNACT, bool ZERO>
 __device__ __forceinline__ void wide_stage_mem(f32x16 (&acc)[4], int steps, WideRing& r, int wave, const float* gamma,
                                                const float* beta, float mean, float rstd, int h) {
     const float c = rstd, d = -mean * rstd;
-    for (int S = 0; S < steps; ++S) {
-        const int s0 = wide_event(r), s1 = ring_next(s0);
-        const uint4* xs = r.rd + s0 * kChunkU4 + (2 * wave) * 64;
-        const float4 xa = __builtin_bit_cast(float4, xs[0]), xb = __builtin_bit_cast(float4, xs[64]);
-        HFrag<4> w;
-        ring_wfrag<4>(w, r.rd + s1 * kChunkU4);
-        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-        float v[8];
-        h8 bhi, blo;
-        if (!(r.dbg & 8)) {
-            if (LNACT) {
-                const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
-                const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
-                act8_l2(v, x, c, d, g0, b0, g1, b1);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = kRawScale * x[q];
-            }
-            split8(v, bhi, blo);
-        } else { bhi = __builtin_bit_cast(h8, xa); blo = __builtin_bit_cast(h8, xb); }
-        if (!(r.dbg & 4)) mfma_step_h<4>(acc, w, bhi, blo);
-        else { acc[0][0] += (float)bhi[0] + __builtin_bit_cast(float4, w.hi[0]).x; acc[1][0] += (float)blo[0] + __builtin_bit_cast(float4, w.lo[3]).x; }
-    }
+    wide_mem_step<LNACT, ZERO>(acc, 0, r, wave, gamma, beta, c, d, h);
+    for (int S = 1; S < steps; ++S) wide_mem_step<LNACT, false>(acc, S, r, wave, gamma, beta, c, d, h);
 }
 
 // acc += private tensor (16 groups of this wave's tile), two chunks (4 groups = one accumulator tile) per event
@@ -267,21 +282,18 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     float mean1, rstd1;
     {
         const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)seg_tile(a.in0, tile) * 32 + j];
-        float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
+        float mean = s0.x, m2 = s0.y;
         if (a.in1.groups) {
             const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)seg_tile(a.in1, tile) * 32 + j];
-            const float n1 = (float)a.in1.width, nt_ = n + n1;
             const float dd = s1.x - mean;
-            m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
-            mean = mean + dd * (n1 / nt_);
-            n = nt_;
+            m2 = m2 + s1.y + dd * dd * a.chan_w;
+            mean = mean + dd * a.chan_f;
         }
         mean1 = mean;
-        rstd1 = rsqrtf(m2 / n + kLnEps);
+        rstd1 = rsqrtf(m2 * a.inv_nin + kLnEps);
+        if (SCLIN) range_check(a.range_flag, mean, m2);
     }
-    const int e1 = scale_exp(*ah.m1), e2 = scale_exp(*ah.m2);
-    const int e3 = SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3);
-    const float inv1 = ldexpf(1.0f / kActScale, -e1), inv2 = ldexpf(1.0f / kActScale, -e2), inv3 = ldexpf(1.0f / kActScale, -e3);
+    const float inv1 = ah.kc[0], inv2 = ah.kc[1], inv3 = ah.kc[2];
     int entry = 0;
     if (a.ts) {
         int row = ptile * 32 + j;
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
 
     // ---- chunk program
     WideProg p;
-    p.ks0 = ks0; p.sclin = SCLIN; p.lin_spc = SPC;
+    p.ks0 = ks0; p.sclin = SCLIN; p.lin_spc = SPC; p.dbg = A.dbg & DSG_WIDE_DBG_ENABLE;
     p.cA = 2 * KS1; p.cB = p.cA + 8; p.cC = p.cB + (wg_cond ? 8 : 0); p.cD = p.cC + 8; p.cE = p.cD + (SCLIN ? 2 * KS1 : 8);
     p.cF = p.cE + (EPI != 0 ? 8 / SPC : 0);
     p.x0 = a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256;
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     }
     const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds;
     WideRing r;
-    r.rd = lds + lane; r.gc = 0; r.pi = 0; r.total = p.cF; r.dbg = A.dbg;
+    r.rd = lds + lane; r.gc = 0; r.pi = 0; r.total = p.cF; r.dbg = A.dbg & DSG_WIDE_DBG_ENABLE;
     r.lds_w = lds0 + (unsigned)wave * 2048u;
     r.lane16 = (unsigned long long)lane * 16ull;
     {   // this wave's chunk-source table: one chunk per lane
@@ -323,8 +335,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
 
     // ---- stage 1
     f32x16 acc1[NT];
-    wacc_zero<NT>(acc1);
-    wide_stage_mem<true>(acc1, KS1, r, wave, g1v, b1v, mean1, rstd1, h);
+    wide_stage_mem<true, true>(acc1, KS1, r, wave, g1v, b1v, mean1, rstd1, h);
     if (a.ts) acc_unscale_add<NT>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
     else acc_unscale_add_lds<NT>(acc1, inv1, tbv, h);
     if (a.save_h1 && live) {
@@ -336,7 +347,6 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
 
     // ---- stage 2
     f32x16 acc2[NT];
-    wacc_zero<NT>(acc2);
     {
         float mean, m2;
         acc_stats<N, NT>(acc1, h, mean, m2);
@@ -353,14 +363,13 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
 
     // ---- stage 3 (+ shortcut in the same scaled accumulator)
     f32x16 (&acc3)[NT] = acc1;
-    wacc_zero<NT>(acc3);
     {
         float mean, m2;
         acc_stats<N, NT>(acc2, h, mean, m2);
         wide_stage_reg(acc3, acc2, r, g3v, b3v, mean, rsqrtf(m2 * (1.0f / N) + kLnEps), h);
     }
     if (SCLIN) {
-        wide_stage_mem<false>(acc3, KS1, r, wave, nullptr, nullptr, 0.f, 1.f, h);
+        wide_stage_mem<false, false>(acc3, KS1, r, wave, nullptr, nullptr, 0.f, 1.f, h);
         acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
     } else {
         acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     // ---- statistics + store
     float xmean, xm2;
     acc_stats<N, NT>(acc3, h, xmean, xm2);
-    if ((EPI == 0 || A.store_block_out) && live) {
+    if ((EPI == 0 || A.store_block_out) && live && !(A.dbg & DSG_WIDE_DBG_ENABLE & 64)) {
         if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
 #pragma unroll
         for (int G = 0; G < NG; ++G)
@@ -378,13 +387,13 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
                 make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2], acc3[G >> 2][4 * (G & 3) + 3]));
     }
     if (EPI == 0) return;
+    if (EPI == 1) range_check(a.range_flag, xmean, xm2);
 
     // ---- epilogue Linear over the ring: a chunk holds SPC k16-steps x NTOP out tiles
     const LinArgs& la = A.l.l;
     f32x16 acc[NTO];
-    wacc_zero<NTO>(acc);
     {
-        const float c = EPI == 2 ? rsqrtf(xm2 / (float)la.in_width + kLnEps) : 1.f, d = -xmean * c;
+        const float c = EPI == 2 ? rsqrtf(xm2 * la.inv_in_w + kLnEps) : 1.f, d = -xmean * c;
         int sl0 = 0;
 #pragma unroll
         for (int ch = 0; ch < 8 / SPC; ++ch) {
@@ -411,11 +420,11 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
                 }
                 h8 bhi, blo;
                 split8(v, bhi, blo);
-                mfma_step_h<NTO>(acc, w, bhi, blo);
+                if (S == 0) mfma_step_h0<NTO>(acc, w, bhi, blo); else mfma_step_h<NTO>(acc, w, bhi, blo);
             }
         }
     }
-    acc_unscale_add_lds<NTO>(acc, ldexpf(1.0f / (EPI == 2 ? kActScale : kRawScale), -scale_exp(*A.l.m)), biasLv, h);
+    acc_unscale_add_lds<NTO>(acc, A.l.kc[EPI == 2 ? 1 : 0], biasLv, h);
     if (!live) return;
     if (EPI == 1) {
         const int NGo = (la.out_width + 7) / 8;
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (8 * G + 4 * h + q < la.out_width) s += acc[G >> 2][4 * (G & 3) + q];
-        const float m = xhalf_sum(s) / (float)la.out_width;
+        const float m = xhalf_sum(s) * la.inv_out_w;
         float qq = 0.f;
 #pragma unroll
         for (int G = 0; G < NTO * 4; ++G)

@@ -124,6 +124,25 @@ class DDPMCore(nn.Module):
         self._keepalive = (cond, y_T, noise, coef)
         return out
 
+    @torch.no_grad()
+    def sample_checked(self, cond, omega=1.0, **kw):
+        """`sample`, then the fp16 range check of the split path (synchronises): if a raw activation left fp16's range
+        (very large omega on an untrained net), the call is repeated on the exact-f32 kernels with the same seed -- the
+        evaluation entry points use this, they synchronise right after sampling anyway."""
+        import warnings
+        if kw.get("seed") is None:
+            kw["seed"] = int(torch.randint(0, 2 ** 62, (1,)).item())
+        y = self.sample(cond, omega, **kw)
+        if cond.shape[0] and self.model.range_exceeded():
+            warnings.warn("DDPM.sample: activations exceeded the fp16 range of the split-f16 path; repeating the call with "
+                          "precision='f32'")
+            self.model.set_precision("f32")
+            try:
+                y = self.sample(cond, omega, **kw)
+            finally:
+                self.model.set_precision("split_f16")
+        return y
+
     def _decode_recorded(self, i, y):
         """Post-processing of the i-th recorded state (problem specific; overridden by the problem modules)."""
         return y
@@ -168,19 +187,24 @@ class DDPMCore(nn.Module):
             raise ValueError("ts / noise / cond_mask do not match the batch")
         L = _lib.lib()
         total = L.dsg_param_total(hd)
-        if getattr(self, "_grad_work", None) is None or self._grad_work.device != dev or self._grad_work.numel() != total:
-            self._grad_work = torch.zeros(total, device=dev, dtype=torch.float32)
+        if getattr(self, "_grad_bucket", None) is None or self._grad_bucket.device != dev or self._grad_bucket.numel() != total:
+            self._grad_pool = []
             self._grad_bucket = torch.zeros(total, device=dev, dtype=torch.float32)
             self._loss_anchor = torch.zeros((), device=dev, requires_grad=True)
+        # the step's gradients land in a buffer that belongs to THIS call until its backward() publishes them: two forward
+        # calls before one backward ((m(a, c) + m(b, c)).backward()) must not share it.  Buffers return to the pool in _publish
+        # (the common one-forward-one-backward loop reuses a single buffer); a call whose graph is dropped just loses its buffer
+        work = self._grad_pool.pop() if self._grad_pool else torch.empty(total, device=dev, dtype=torch.float32)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             _lib.check(L.dsg_train_step(hd, _lib.ptr(y32), _lib.ptr(c32), _lib.ptr(ts32), _lib.ptr(nz), _lib.ptr(mk),
                                         _lib.ptr(self.sqrt_alphas_cumprod), _lib.ptr(self.sqrt_one_minus_alphas_cumprod),
-                                        self.T, _lib.ptr(self._grad_work), _lib.ptr(loss), B, _lib.stream_ptr()))
+                                        self.T, _lib.ptr(work), _lib.ptr(loss), B, _lib.stream_ptr()))
         self._keepalive = (y32, c32, ts32, nz, mk)
         if not torch.is_grad_enabled():
+            self._grad_pool.append(work)
             return loss
-        return _PublishGrads.apply(self._loss_anchor, loss, self)
+        return _PublishGrads.apply(self._loss_anchor, loss, self, work)
 
     @property
     def grad_bucket(self):
@@ -188,8 +212,8 @@ class DDPMCore(nn.Module):
         message of the data-parallel all-reduce."""
         return getattr(self, "_grad_bucket", None)
 
-    def _publish(self, grad_out):
-        work, bucket = self._grad_work, self._grad_bucket
+    def _publish(self, grad_out, work):
+        bucket = self._grad_bucket
         work.mul_(grad_out.to(work.dtype))
         params = self.model.param_list()
         installed = params[0].grad is not None and params[-1].grad is not None and params[0].grad.data_ptr() == bucket.data_ptr()
@@ -207,6 +231,8 @@ class DDPMCore(nn.Module):
                 views = self._grad_views = (bucket, vs)
             for p, v in zip(params, views[1]):
                 p.grad = v
+        if len(self._grad_pool) < 2:
+            self._grad_pool.append(work)       # stream-ordered reuse: the next dsg_train_step is enqueued behind these kernels
         self._grads_ready = True
 
     def allreduce_grads(self):
@@ -221,11 +247,15 @@ class _PublishGrads(torch.autograd.Function):
     """Connects the already-computed loss to autograd: backward() publishes the fused kernel's gradients."""
 
     @staticmethod
-    def forward(ctx, anchor, loss, owner):
+    def forward(ctx, anchor, loss, owner, work):
         ctx.owner = owner
+        ctx.work = work
         return loss.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.owner._publish(grad_out)
-        return None, None, None
+        work, ctx.work = ctx.work, None
+        if work is None:
+            raise RuntimeError("DDPM.forward: backward() called twice on the same loss (the fused step keeps no graph to retain)")
+        ctx.owner._publish(grad_out, work)
+        return None, None, None, None

@@ -24,12 +24,43 @@ def shard_rows(n_rows: int, rank: int, world_size: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def sample_sharded(ddpm, cond_all, omega=1.0, gather=False, **kw):
-    """Each rank samples its shard of `cond_all` (no collective).  With gather=True the shards are all-gathered
-    afterwards (a convenience for evaluation, outside the sampling path)."""
+class global_renorm:
+    """Context: while active, `ddpm.sample` standardises the early steps with the moments of ALL ranks' rows (one all-reduce
+    of 3 float64 scalars on each of the <= 4 renorm steps; dsg_set_renorm_hook) -- the sharded call then reproduces a single
+    reference call on the whole batch instead of one call per shard.  `reduce` defaults to torch.distributed.all_reduce."""
+
+    def __init__(self, ddpm, reduce=None):
+        from . import _lib
+        self.ddpm, self._lib = ddpm, _lib
+        self.reduce = reduce if reduce is not None else (lambda t: dist.all_reduce(t))
+
+    def __enter__(self):
+        import ctypes
+        dev = next(self.ddpm.model.parameters()).device
+        self.stats = torch.zeros(3, device=dev, dtype=torch.float64)
+        self.cb = self._lib.RENORM_REDUCE_FN(lambda _user: self.reduce(self.stats))
+        hd = self.ddpm.model.native_handle()
+        self._lib.check(self._lib.lib().dsg_set_renorm_hook(hd, self._lib.ptr(self.stats), ctypes.cast(self.cb, ctypes.c_void_p), None))
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()          # the hook's buffer and callback must outlive the enqueued steps
+        self._lib.check(self._lib.lib().dsg_set_renorm_hook(self.ddpm.model.native_handle(), None, None, None))
+        return False
+
+
+def sample_sharded(ddpm, cond_all, omega=1.0, gather=False, global_renorm_stats=False, **kw):
+    """Each rank samples its shard of `cond_all`.  Default: NO collective -- every shard is its own `sample()` call, exactly
+    as the reference treats its 512-row chunks (the early-step renorm is per call).  global_renorm_stats=True: the renorm uses
+    the whole batch's statistics (`global_renorm`; 3 scalars all-reduced on 4 steps), matching one reference call on
+    `cond_all`.  With gather=True the shards are all-gathered afterwards (a convenience for evaluation, outside the path)."""
     rank, ws = world()
     lo, hi = shard_rows(cond_all.shape[0], rank, ws)
-    y = ddpm.sample(cond_all[lo:hi], omega, **kw)
+    if global_renorm_stats and ws > 1:
+        with global_renorm(ddpm):
+            y = ddpm.sample(cond_all[lo:hi], omega, **kw)
+    else:
+        y = ddpm.sample(cond_all[lo:hi], omega, **kw)
     if not gather or ws == 1:
         return y
     sizes = [shard_rows(cond_all.shape[0], r, ws) for r in range(ws)]

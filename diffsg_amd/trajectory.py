@@ -28,12 +28,12 @@ def record_trajectories(diffusion_model, X_test, omega, batch_size=None):
     dev = next(diffusion_model.model.parameters()).device
     X = torch.as_tensor(np.asarray(X_test), dtype=torch.float32)
     if batch_size is None:
-        diffusion_model.sample(X.to(dev), omega)
+        diffusion_model.sample_checked(X.to(dev), omega)
         return np.asarray(diffusion_model.y_i_record)
     D = diffusion_model.model.cfg["input_dim"]
     out = np.zeros((X.shape[0], D * diffusion_model.T), dtype=float)
     for i in range(0, X.shape[0], batch_size):
-        diffusion_model.sample(X[i:i + batch_size].to(dev), omega)
+        diffusion_model.sample_checked(X[i:i + batch_size].to(dev), omega)
         out[i:i + batch_size, :] = diffusion_model.y_i_record
     return out
 

@@ -57,6 +57,22 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
 #define DSG_PRECISION_F32_MFMA 1
 int dsg_set_precision(dsg_handle* h, int mode);
 
+/* Sharded sampling that must reproduce ONE reference call on the concatenation of all ranks' rows: the early-step renorm
+ * (classifier_free_MSR.py:136-137: mean / unbiased variance over ALL B*D elements, the only cross-row coupling of the path)
+ * then needs the other shards' moments.  With a hook set, on each of the (at most 4) renorm steps dsg_sample writes the
+ * shard's { sum y, sum y^2, count } as float64 to stats3 (device), calls reduce(user) on the host -- the caller enqueues an
+ * all-reduce(SUM) of the 3 doubles, in place, ordered on the same stream (torch.distributed does) -- and standardises with
+ * the reduced moments; those steps are launched eagerly instead of from the captured graph.  reduce = NULL removes the hook
+ * (default: every dsg_sample call standardises over its own rows, as the reference does per 512-row chunk, :273-279). */
+int dsg_set_renorm_hook(dsg_handle* h, double* stats3, void (*reduce)(void* user), void* user);
+
+/* fp16 range of the split path's RAW operands (Linear shortcuts, Down/Upsample, feature_proj inputs are split without
+ * normalisation; LayerNorm outputs are bounded and weights are scaled at bind time).  Every kernel that splits a raw operand
+ * bounds its rows by |mean| + sqrt(M2) from the LayerNorm statistics and raises a per-handle flag above 6e4 (fp16 saturates at
+ * 65504: the result would be silently wrong, not inf).  dsg_range_status synchronises the device, returns the flag in
+ * *exceeded and clears it; on 1 the outputs since the last query are not to be trusted: rerun with DSG_PRECISION_F32_MFMA. */
+int dsg_range_status(dsg_handle* h, int* exceeded);
+
 /* Which FORM of the kernels a launch uses (same arithmetic per element, different work decomposition):
  *   coop_max_tiles          launches of at most this many 32-row tiles (both CFG passes counted) run the 64/128-wide
  *                           blocks cooperatively (one tile per workgroup, N/32 waves) and never as block+Linear pair

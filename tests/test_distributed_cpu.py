@@ -59,9 +59,9 @@ def _worker(rank, ws, port, q):
 
         # ---- training: ONE all-reduce over the flat bucket gives the mean of the ranks' gradients in every .grad view
         total = sum(p.numel() for p in d.model.parameters())
-        d._grad_work = torch.full((total,), float(rank + 1))
+        d._grad_pool = []
         d._grad_bucket = torch.zeros(total)
-        d._publish(torch.tensor(1.0))
+        d._publish(torch.tensor(1.0), torch.full((total,), float(rank + 1)))
         calls = []
         orig = dist.all_reduce
         dist.all_reduce = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
@@ -73,8 +73,7 @@ def _worker(rank, ws, port, q):
         assert all(p.grad is None for p in d.ema.parameters())
         assert d.model.feature_proj.weight.grad.data_ptr() == d.grad_bucket.data_ptr()
         # a second backward without zero_grad accumulates, as autograd would
-        d._grad_work = torch.full((total,), 1.0)
-        d._publish(torch.tensor(2.0))
+        d._publish(torch.tensor(2.0), torch.full((total,), 1.0))
         assert torch.all(d.model.final.bias.grad == want + 2.0)
         # ---- the train entry points' data-parallel plumbing (train.dp_context / make_loader / sync_replicas / run_epochs) with a
         # stand-in for the fused HIP step: replicas that start from different weights and see different row shards must hold
@@ -97,11 +96,11 @@ def _worker(rank, ws, port, q):
 
         def fake_forward(y, cond):                                    # loss and "gradients" that depend on this rank's rows
             seen.append(y[:, 0].clone())
-            d2._grad_work = torch.full((total2,), float(y.mean()))
             if getattr(d2, "_grad_bucket", None) is None:
+                d2._grad_pool = []
                 d2._grad_bucket = torch.zeros(total2)
                 d2._loss_anchor = torch.zeros((), requires_grad=True)
-            return _PublishGrads.apply(d2._loss_anchor, y.mean().detach(), d2)
+            return _PublishGrads.apply(d2._loss_anchor, y.mean().detach(), d2, torch.full((total2,), float(y.mean())))
         d2.forward = fake_forward
         rows = torch.arange(40, dtype=torch.float32)[:, None].repeat(1, 3)
         ds = torch.utils.data.TensorDataset(rows.clone(), rows.clone())

@@ -261,6 +261,90 @@ def test_sample_large_launch_split_vs_exact_f32(name, B):
     assert rel(y2[:B], out["split_f16"]) <= 5e-5
 
 
+def test_fp16_range_guard_and_omega500_msr80():
+    """The split path feeds RAW residual-stream values (shortcuts, Down/Upsample, feature_proj) to the matrix core without
+    normalisation.  (1) omega = 500 on MSR-80c, T = 20: values stay in range, the flag stays clear and the result is as close
+    to the float64 trajectory as the reference's own float32 run (budget x3, as for the NU checkpoint).  (2) A start state
+    of 1e6 overflows fp16: the flag must come up, `check_range` must raise, and `sample_checked` must fall back to the exact
+    float32 kernels and agree with a run made in f32 mode from the start."""
+    name, T, B = "msr80", 20, 96
+    plan, p = synth_params(name, 31)
+    cfg = CONFIGS[name]
+    ddpm = make_ddpm(name, p, T)
+    g = torch.Generator().manual_seed(2)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g)
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    zd = {i: z[j] for j, i in enumerate(range(T - 1, 1, -1))}
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    y0 = ddpm.sample(cond.cuda(), 500.0, y_T=y_T, noise=z)
+    assert not ddpm.model.range_exceeded()
+    with torch.no_grad():
+        ref = O.ddpm_sample(p, plan, bufs, T, cond, 500.0, y_T, zd)
+        ref64 = O.ddpm_sample({k: v.double() for k, v in p.items()}, plan, {k: v.double() for k, v in bufs.items()}, T, cond.double(), 500.0,
+                              y_T.double(), {i: v.double() for i, v in zd.items()})
+    budget = rel(ref, ref64)
+    e = rel(y0, ref64)
+    print(f"omega=500 msr80 T=20: HIP vs float64 {e:.2e}, reference float32 vs float64 {budget:.2e}, max|y| {float(ref64.abs().max()):.3g}")
+    assert e <= 3.0 * budget + 1e-4
+    big = y_T * 1e6
+    ddpm.sample(cond.cuda(), 1.0, y_T=big, noise=z)
+    with pytest.raises(RuntimeError):
+        ddpm.model.check_range()
+    assert not ddpm.model.range_exceeded()                      # the query cleared it
+    with pytest.warns(UserWarning):
+        ya = ddpm.sample_checked(cond.cuda(), 1.0, y_T=big, noise=z)
+    ddpm.model.set_precision("f32")
+    yb = ddpm.sample(cond.cuda(), 1.0, y_T=big, noise=z)
+    ddpm.model.set_precision("split_f16")
+    assert torch.equal(ya, yb)
+
+
+def test_global_renorm_hook_matches_one_call_on_the_whole_batch():
+    """parallel.global_renorm (dsg_set_renorm_hook): two row shards, each sampled by its own handle with the 3-scalar
+    reduction of the early-step moments between them (two host threads stand in for two ranks; the reduce function is the
+    all-reduce), reproduce ONE sample() call on the concatenated batch -- which per-shard calls do not (per-call renorm)."""
+    import threading
+    from diffsg_amd import parallel as par
+    name, T, B = "msr80", 6, 96
+    plan, p = synth_params(name, 31)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(4)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    whole = make_ddpm(name, p, T).sample(cond, 1.0, y_T=y_T, noise=z)
+    shards = [(0, 40), (40, B)]
+    models = [make_ddpm(name, p, T) for _ in shards]
+    for m, (lo, hi) in zip(models, shards):      # handles, workspaces and step graphs are created one thread at a time (a
+        m.sample(cond[lo:hi], 1.0, seed=1)       # stream capture in one thread makes another thread's hipMalloc fail)
+    torch.cuda.synchronize()
+    bar = threading.Barrier(2)
+    slots, outs, errs = [None, None], [None, None], []
+
+    def run(i):
+        try:
+            def reduce(stats):
+                slots[i] = stats.clone()
+                bar.wait(60)
+                stats.copy_(slots[0] + slots[1])
+                bar.wait(60)
+            lo, hi = shards[i]
+            with par.global_renorm(models[i], reduce=reduce):
+                outs[i] = models[i].sample(cond[lo:hi], 1.0, y_T=y_T[lo:hi], noise=z[:, lo:hi])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            bar.abort()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not errs, errs
+    both = torch.cat(outs)
+    assert rel(both, whole) <= 1e-6
+    separate = torch.cat([models[i].sample(cond[lo:hi], 1.0, y_T=y_T[lo:hi], noise=z[:, lo:hi]) for i, (lo, hi) in enumerate(shards)])
+    assert rel(separate, whole) > 1e-4          # without the hook each shard standardises over its own rows (the default)
+
+
 def test_sample_full_size_properties():
     """A BASELINE-size call (B=8192, D=C=80) checked through size-independent properties:
     duplicated rows give duplicated outputs (rows only couple through the global renorm statistics, which a
@@ -595,6 +679,34 @@ def test_flat_adam_is_adam_bit_for_bit():
     assert all(q.grad is None for q in b.model.parameters())
     lb = b(y, cond, ts=ts, noise=noise, cond_mask=mask); lb.backward()
     assert torch.equal(w.grad, g1)
+
+
+def test_two_forwards_before_one_backward():
+    """(m(a, c) + m(b, c)).backward() -- each call's gradients live in their own buffer until published: the result is the
+    sum of the two calls' gradients, as autograd gives for the reference."""
+    name, T, B = "tiny", 20, 64
+    plan, p = synth_params(name, 19)
+    ddpm = make_ddpm(name, p, T)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(8)
+    draws = []
+    for _ in range(2):
+        draws.append((torch.rand(B, cfg["input_dim"], generator=g).cuda(), torch.rand(B, cfg["cond_dim"], generator=g).cuda(),
+                      torch.randint(0, T, (1, B), generator=g).cuda(), torch.randn(B, cfg["input_dim"], generator=g).cuda(),
+                      (torch.rand(B, 1, generator=g) < 0.9).float().cuda()))
+    single = []
+    for y, c, ts, nz, mk in draws:
+        for q in ddpm.model.parameters():
+            q.grad = None
+        ddpm(y, c, ts=ts, noise=nz, cond_mask=mk).backward()
+        single.append([q.grad.detach().clone() for q in ddpm.model.parameters()])
+    for q in ddpm.model.parameters():
+        q.grad = None
+    la = ddpm(*draws[0][:2], ts=draws[0][2], noise=draws[0][3], cond_mask=draws[0][4])
+    lb = ddpm(*draws[1][:2], ts=draws[1][2], noise=draws[1][3], cond_mask=draws[1][4])
+    (la + lb).backward()
+    for q, ga, gb in zip(ddpm.model.parameters(), single[0], single[1]):
+        assert torch.allclose(q.grad, ga + gb, rtol=1e-6, atol=1e-12)
 
 
 def test_entry_points_train_save_load_eval(tmp_path):

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from a PMC summary (tools/pmc_summary.py output for ONE kernel section):
+    python tools/make_traffic.py <pmc_summary.txt> "<section header substring>" <out.json> [summary path to cite]
+HBM bytes per launch = FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE, both
+reported in KiB by rocprofv3; valu_per_mfma = SQ_INSTS_VALU / SQ_INSTS_MFMA."""
+import json, re, sys
+src, pat, out = sys.argv[1], sys.argv[2], sys.argv[3]
+cite = sys.argv[4] if len(sys.argv) > 4 else src
+sec, vals = None, {}
+for line in open(src):
+    if line.startswith("== "):
+        sec = line[3:].strip()
+        continue
+    if sec is not None and pat in sec:
+        m = re.match(r"(\S+)\s+n=\s*(\d+)\s+mean=(\S+)", line)
+        if m:
+            vals[m.group(1)] = float(m.group(3))
+fetch, write = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+d = {"kernel": pat, "summary": cite,
+     "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_bench.sh), mean per dispatch; FETCH_SIZE "
+               "doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counters are in KiB",
+     "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+     "valu_per_mfma": vals["SQ_INSTS_VALU"] / vals["SQ_INSTS_MFMA"] if "SQ_INSTS_MFMA" in vals else None,
+     "vmem_rd_per_wave": vals.get("SQ_INSTS_VMEM_RD", 0) / vals["SQ_WAVES"] if "SQ_WAVES" in vals else None,
+     "wait_any_share": vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in vals else None,
+     "wait_inst_share": vals["SQ_WAIT_INST_ANY"] / vals["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in vals else None}
+json.dump(d, open(out, "w"), indent=1)
+print(json.dumps(d))

@@ -11,6 +11,8 @@ from diffsg_amd.train import FlatAdam
 opt = FlatAdam(ddpm, lr=0.005) if not os.environ.get('PLAIN_ADAM') else torch.optim.Adam(ddpm.parameters(), lr=0.005, fused=True)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 cond = torch.rand(B, 80, device=dev); y = torch.rand(B, 80, device=dev) * 0.25
+if os.environ.get('POLICY'):          # "coop_max_tiles,narrow_small_max_tiles" (dsg_set_launch_policy), e.g. POLICY=1024,1024
+    ddpm.model.set_launch_policy(*[int(v) for v in os.environ['POLICY'].split(',')])
 def one():
     loss = ddpm(y, cond); loss.backward(); opt.step(); opt.zero_grad(); return loss
 for _ in range(3): one()
@@ -18,3 +20,12 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps): one()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"train: {dt/steps*1e3:.3f} ms/step, {B*steps/dt/1e6:.2f} M samples/s")
+if os.environ.get('PHASES'):
+    import ctypes
+    from diffsg_amd import _lib
+    L, hd = _lib.lib(), ddpm.model.native_handle()
+    _lib.check(L.dsg_train_profile_enable(hd, 1))
+    acc = [0.0] * 5
+    for _ in range(5):
+        one(); ms5 = (ctypes.c_float * 5)(); _lib.check(L.dsg_train_profile(hd, ms5)); acc = [a + float(v) for a, v in zip(acc, ms5)]
+    print("phases ms (fwd, act-bwd, colsum, wgrad, tail):", [round(a / 5, 3) for a in acc])
