@@ -73,7 +73,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             # different results on gfx950 ("Build flags"); without it the library is deterministic and 2-5 % faster.
             tmp = LIB_PATH + f".{os.getpid()}.tmp"
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-fno-slp-vectorize",
-                   f'-DDSG_BUILD_ID_STR="{source_id()}"', "-o", tmp] + SOURCES
+                   f'-DDSG_BUILD_ID_STR="{source_id()}"', "-o", tmp] + os.environ.get("DSG_EXTRA_CXXFLAGS", "").split() + SOURCES
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
