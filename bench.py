@@ -226,12 +226,20 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    if local >= ndev and not os.environ.get("DSG_BENCH_BACKEND"):
+        raise SystemExit(f"LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+    local_dev = local % ndev                 # (only DSG_BENCH_BACKEND=gloo lets several ranks share a GPU: plumbing smoke test on one GPU)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DSG_BENCH_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only for the one-GPU smoke test
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     K, W, B = a.steps, max(a.warmup, 1), a.batch
     ddpm_k = build_model(dev, K)

@@ -77,7 +77,7 @@ struct WideProg {
 // Measurement switches (BlockLinArgsH::dbg, env DSG_WIDE_DBG read by the host launcher; results are WRONG with any of them
 // set -- they exist to time the kernel with one ingredient removed): 1 no barrier, 2 no DMA wait, 16 no DMA issue, 32 / 64 hot-line sources
 // (the 4 = no MFMA and 8 = no LayerNorm / SiLU / split VALU switches of the sweep in DESIGN.md 3.2 were removed with it).  Compiled out unless the library is built with
-// -DDSG_WIDE_DBG_ENABLE=127 (tools/dbg_sweep.sh): the production kernel carries none of the branches.
+// -DDSG_WIDE_DBG_ENABLE=127 (tools/dbg_sweep.sh does that and restores the production build afterwards).
 #ifndef DSG_WIDE_DBG_ENABLE
 #define DSG_WIDE_DBG_ENABLE 0
 #endif
