@@ -110,6 +110,9 @@ constexpr int kCoopMaxTilesDefault = 512, kNarrowSmallMaxTilesDefault = 1024;
 
 }  // namespace
 
+constexpr int kMaxWgParts = 8;      // early parts of the weight-gradient launch (dsg_train_step)
+constexpr int kWgForkMinTiles = 1024;
+
 struct dsg_handle {
     dsg_unet_desc d;
     int td = 0;  // time_dim = 4*proj
@@ -211,6 +214,14 @@ struct dsg_handle {
     float* tr_tsave = nullptr;   // emb | h1pre | h1s | tpre | d_st | d_h1s
     long long* tw_dst_dev = nullptr; const float** tw_src_dev = nullptr; int tw_rows = 0;  // time_emb.weight rows of all blocks
     WgradDesc* wg_desc_dev = nullptr; WgradUnit* wg_unit_dev = nullptr; int wg_units = 0;
+    // early parts of the weight-gradient launch: after the backward kernel of residual block number wg_forks[k] (counted from the
+    // LAST block, the first one the backward reaches) the weight gradients of the blocks since the previous fork run on
+    // side_stream beside the rest of the activation-gradient chain, see dsg_train_step
+    std::vector<int> wg_forks = {3, 6};
+    std::vector<int> wg_part_end;      // units [wg_part_end[k-1], wg_part_end[k]) = part k; the rest runs on the caller's stream
+    std::vector<int> wg_fork_ops;      // operator index after whose backward kernel part k starts
+    int wg_early_lds = 40960;
+    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ColsumDesc* cs_desc_dev = nullptr; ColsumUnit* cs_unit_dev = nullptr; int cs_units = 0;
     // the descriptor tables depend only on (rows, T, precision mode) and the workspace addresses: built once, reused every step
     bool td_valid = false; int td_B = 0, td_T = 0, td_rows = 0; bool td_split = false; const void* td_key[6] = {};
@@ -921,7 +932,7 @@ int ensure_train_workspace(dsg_handle* h, int rows, int T) {
     HIPCK(hipMalloc(&h->tr_slabs, (size_t)max_chunks * h->slab_stride * sizeof(float)));
     HIPCK(hipMemset(h->tr_slabs, 0, (size_t)max_chunks * h->slab_stride * sizeof(float)));
     HIPCK(hipMalloc(&h->tr_gsum, h->slab_stride * sizeof(float)));
-    HIPCK(hipMalloc(&h->tr_gmax, (size_t)kMaxGmax * sizeof(unsigned)));
+    HIPCK(hipMalloc(&h->tr_gmax, (size_t)(1 + kMaxWgParts) * kMaxGmax * sizeof(unsigned)));   // + one set per early weight-gradient part
     h->gmax_ld = (int)tiles;
     HIPCK(hipMalloc(&h->tr_gmax_t, (size_t)kMaxGmax * h->gmax_ld * sizeof(unsigned)));
     {   // per-tile column sums of the residual blocks, one contiguous [tile][slot] region per block:
@@ -988,6 +999,23 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
     std::vector<WgradDesc> wd;
     std::vector<int> wd_op;            // operator each descriptor belongs to
     int cur_op = 0;
+    // part of each operator: k for a residual block reached before fork k (only blocks: the scale of their G operands comes
+    // from their own backward kernel, a plain Linear's from k_colsum at the end), -1 = the final launch on the caller's stream
+    std::vector<int> op_part(h->ops.size() + 1, -1);
+    h->wg_fork_ops.clear();
+    // Only where the step is GPU-bound (>= 1 024 row tiles): the cross-stream hand-offs cost host time, and below that the step is
+    // bound by the host's enqueue rate (measured: 32 768 rows 2.65 -> 2.53 ms, 65 536 rows 4.03 -> 3.98; 16 384 rows 2.00 -> 2.26).
+    if (h->use_split && tiles >= kWgForkMinTiles) {
+        int n = 0;
+        size_t k = 0;
+        for (int oi = (int)h->ops.size() - 1; oi >= 0 && k < h->wg_forks.size(); --oi) {
+            if (h->ops[oi].kind != OP_RES) continue;
+            op_part[oi + 1] = (int)k;
+            if (++n == h->wg_forks[k]) { h->wg_fork_ops.push_back(oi); ++k; }
+        }
+        if (k < h->wg_forks.size())                   // fewer blocks than the last fork asks for: those stay in the final launch
+            for (size_t i = 0; i < op_part.size(); ++i) if (op_part[i] == (int)k) op_part[i] = -1;
+    }
     std::vector<ColsumDesc> cd;
     std::vector<int> bwd_slots;        // slots tracked by the block backward kernels
     std::vector<const float*> gsrc;    // distinct G tensors, by first pointer: slot of max|G|
@@ -1089,10 +1117,18 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
             }
         }
         std::stable_sort(ou.begin(), ou.end(), [](const OpUnits& a, const OpUnits& b) { return a.cost > b.cost; });
-        for (const OpUnits& o : ou)
-            for (int c0 = 0; c0 < h->tr_chunks; c0 += 8)
-                for (const auto& u : o.u)
-                    for (int c = c0; c < c0 + 8 && c < h->tr_chunks; ++c) wu.push_back(WgradUnit{u.first, u.second, c, 0});
+        h->wg_part_end.clear();
+        const int nparts = (int)h->wg_fork_ops.size();
+        for (int part = 0; part <= nparts; ++part) {
+            for (const OpUnits& o : ou) {
+                const int pt = op_part[wd_op[o.u.front().first]];
+                if (pt != (part < nparts ? part : -1)) continue;
+                for (int c0 = 0; c0 < h->tr_chunks; c0 += 8)
+                    for (const auto& u : o.u)
+                        for (int c = c0; c < c0 + 8 && c < h->tr_chunks; ++c) wu.push_back(WgradUnit{u.first, u.second, c, 0});
+            }
+            if (part < nparts) h->wg_part_end.push_back((int)wu.size());
+        }
     }
     std::vector<ColsumUnit> cu;
     // chunk-major, group-minor: neighbouring waves stream neighbouring 1 KiB fragments of the same row tiles
@@ -1293,6 +1329,9 @@ void dsg_destroy(dsg_handle* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
 }
 
@@ -1686,6 +1725,13 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     // ---- backward: activation gradients in reverse operator order
     mark(1);
     HIPCK(hipMemsetAsync(h->tr_gmax_t, 0, (size_t)h->n_gmax * h->gmax_ld * sizeof(unsigned), s));
+    int next_part = 0;
+    if (h->use_split && !h->wg_fork_ops.empty() && !h->side_stream) {
+        HIPCK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    }
     for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
         const Op& op = h->ops[oi];
         if (op.kind == OP_PROJ) continue;
@@ -1716,6 +1762,20 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
                 ah.msc = r.sclin ? h->maxabs + r.sc.w : nullptr;
                 ah.gmax_t = h->tr_gmax_t; ah.gmax_ld = h->gmax_ld; ah.slot_out = r.gslot_out; ah.slot_h2 = r.gslot_h2; ah.slot_h1 = r.gslot_h1;
                 launch_res_bwd_h(r.N, r.sclin, ah, s);
+                if (next_part < (int)h->wg_fork_ops.size() && oi == h->wg_fork_ops[next_part]) {
+                    // the G and A operands of this part are final: its weight gradients run on the side stream from here,
+                    // beside the remaining chain kernels (one wave per SIMD below 65 536 rows: latency-bound, half the CU idle).
+                    // Extra dynamic LDS keeps it to one workgroup per CU so that a chain kernel's workgroup always finds room.
+                    const int u0 = next_part ? h->wg_part_end[next_part - 1] : 0, u1 = h->wg_part_end[next_part];
+                    unsigned* gm = h->tr_gmax + (size_t)(1 + next_part) * kMaxGmax;
+                    HIPCK(hipEventRecord(h->ev_fork, s));
+                    HIPCK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+                    hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, h->side_stream, h->tr_gmax_t, h->gmax_ld, gm);
+                    if (u1 > u0)
+                        hipLaunchKernelGGL(k_wgrad_h, dim3(u1 - u0), dim3(256), h->wg_early_lds, h->side_stream, h->wg_desc_dev, h->wg_unit_dev + u0,
+                                           gm, h->tr_slabs, h->slab_stride, tiles, h->tr_chunks);
+                    ++next_part;
+                }
             } else {
                 launch_res_bwd(r.N, r.sclin, a, s);
             }
@@ -1746,10 +1806,13 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
                        h->slab_stride, tiles, h->tr_chunks, B, h->tr_gmax_t, h->gmax_ld);
     hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, s, h->tr_gmax_t, h->gmax_ld, h->tr_gmax);
     mark(3);
-    if (h->use_split)
-        hipLaunchKernelGGL(k_wgrad_h, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_gmax, h->tr_slabs,
+    if (h->use_split) {
+        const int u0 = next_part ? h->wg_part_end[next_part - 1] : 0;
+        if (next_part) HIPCK(hipEventRecord(h->ev_join, h->side_stream));
+        hipLaunchKernelGGL(k_wgrad_h, dim3(h->wg_units - u0), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev + u0, h->tr_gmax, h->tr_slabs,
                            h->slab_stride, tiles, h->tr_chunks);
-    else
+        if (next_part) HIPCK(hipStreamWaitEvent(s, h->ev_join, 0));
+    } else
         hipLaunchKernelGGL(k_wgrad, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_slabs, h->slab_stride, tiles,
                            h->tr_chunks);
     mark(4);

@@ -565,10 +565,11 @@ def test_train_step_exact_f32_mode(name, B):
     assert_grads({k: q.grad for k, q in ddpm.model.named_parameters()}, ref, ref64, f"f32 mode {name}/{B}")
 
 
-@pytest.mark.parametrize("name,B", [("msr3", 512), ("msr80", 96)])
+@pytest.mark.parametrize("name,B", [("msr3", 512), ("msr80", 96), ("msr80", 32768 + 17)])
 def test_train_step_is_run_to_run_deterministic(name, B):
     """Same inputs -> bit-identical loss and gradients, 12 times (every reduction has a fixed order; this also guards the
-    build flags: SLP-vectorised packed-f32 code made k_wgrad_h differ from run to run on gfx950)."""
+    build flags: SLP-vectorised packed-f32 code made k_wgrad_h differ from run to run on gfx950).  The 1 025-tile case runs
+    the early weight-gradient parts on the side stream beside the activation-gradient chain (dsg_train_step): same bits."""
     plan, p = synth_params(name, 9)
     T = 20
     ddpm = make_ddpm(name, p, T)
