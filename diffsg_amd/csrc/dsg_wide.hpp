@@ -119,18 +119,22 @@ __device__ __forceinline__ int wide_event(WideRing& r) {
 __device__ __forceinline__ int ring_next(int s) { return (s + 1) & (kRingChunks - 1); }
 
 // 16 * silu(u) from u' = -log2(e) * u:  p = 2^u' = e^-u;  16 u / (1 + p) = u' / ((1 + p) * (-log2(e) / 16))
-__device__ __forceinline__ float silu_scaled_l2(float up) {
+__device__ __forceinline__ f32x2 silu_scaled_l2(f32x2 up) {
     constexpr float k = -1.44269504088896341f / kActScale;
-    const float p = __builtin_amdgcn_exp2f(up);
-    return up * __builtin_amdgcn_rcpf(fmaf(p, k, k));
+    const f32x2 p = {__builtin_amdgcn_exp2f(up.x), __builtin_amdgcn_exp2f(up.y)};
+    const f32x2 q = __builtin_elementwise_fma(p, pk2(k), pk2(k));
+    const f32x2 r = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+    return up * r;
 }
-// gv / bv: gamma' and beta' of the 8 features (already times -log2 e)
+// gv / bv: gamma' and beta' of the 8 features (already times -log2 e); packed-f32 arithmetic (dsg_split.hpp: same bits)
 __device__ __forceinline__ void act8_l2(float (&v)[8], const float (&x)[8], float c, float d, const float4 g0, const float4 b0, const float4 g1,
                                         const float4 b1) {
-    v[0] = silu_scaled_l2(fmaf(fmaf(x[0], c, d), g0.x, b0.x)); v[1] = silu_scaled_l2(fmaf(fmaf(x[1], c, d), g0.y, b0.y));
-    v[2] = silu_scaled_l2(fmaf(fmaf(x[2], c, d), g0.z, b0.z)); v[3] = silu_scaled_l2(fmaf(fmaf(x[3], c, d), g0.w, b0.w));
-    v[4] = silu_scaled_l2(fmaf(fmaf(x[4], c, d), g1.x, b1.x)); v[5] = silu_scaled_l2(fmaf(fmaf(x[5], c, d), g1.y, b1.y));
-    v[6] = silu_scaled_l2(fmaf(fmaf(x[6], c, d), g1.z, b1.z)); v[7] = silu_scaled_l2(fmaf(fmaf(x[7], c, d), g1.w, b1.w));
+    const f32x2 cc = pk2(c), dd = pk2(d);
+    const f32x2 r0 = silu_scaled_l2(__builtin_elementwise_fma(__builtin_elementwise_fma(f32x2{x[0], x[1]}, cc, dd), f32x2{g0.x, g0.y}, f32x2{b0.x, b0.y}));
+    const f32x2 r1 = silu_scaled_l2(__builtin_elementwise_fma(__builtin_elementwise_fma(f32x2{x[2], x[3]}, cc, dd), f32x2{g0.z, g0.w}, f32x2{b0.z, b0.w}));
+    const f32x2 r2 = silu_scaled_l2(__builtin_elementwise_fma(__builtin_elementwise_fma(f32x2{x[4], x[5]}, cc, dd), f32x2{g1.x, g1.y}, f32x2{b1.x, b1.y}));
+    const f32x2 r3 = silu_scaled_l2(__builtin_elementwise_fma(__builtin_elementwise_fma(f32x2{x[6], x[7]}, cc, dd), f32x2{g1.z, g1.w}, f32x2{b1.z, b1.w}));
+    v[0] = r0.x; v[1] = r0.y; v[2] = r1.x; v[3] = r1.y; v[4] = r2.x; v[5] = r2.y; v[6] = r3.x; v[7] = r3.y;
 }
 
 template <int NT>
@@ -158,7 +162,7 @@ __device__ __forceinline__ BOp wide_prep(const float (&x)[8], const float* gamma
         act8_l2(v, x, c, d, g0, b0, g1, b1);
     } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = kRawScale * x[q];
+        for (int q = 0; q < 8; q += 2) { const f32x2 t = f32x2{x[q], x[q + 1]} * pk2(kRawScale); v[q] = t.x; v[q + 1] = t.y; }
     }
     BOp b;
     split8(v, b.hi, b.lo);
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
                     act8_l2(v, x, c, d, g0, b0, g1, b1);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = kRawScale * x[q];
+                    for (int q = 0; q < 8; q += 2) { const f32x2 t = f32x2{x[q], x[q + 1]} * pk2(kRawScale); v[q] = t.x; v[q + 1] = t.y; }
                 }
                 h8 bhi, blo;
                 split8(v, bhi, blo);
