@@ -222,6 +222,7 @@ struct dsg_handle {
     std::vector<int> wg_fork_ops;      // operator index after whose backward kernel part k starts
     int wg_early_lds = 40960;
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    FusedBwdOpH* fbwd_dev = nullptr; int fbwd_n = 0;   // operator table of the fused narrow backward (split path), cached with the descriptors
     ColsumDesc* cs_desc_dev = nullptr; ColsumUnit* cs_unit_dev = nullptr; int cs_units = 0;
     // the descriptor tables depend only on (rows, T, precision mode) and the workspace addresses: built once, reused every step
     bool td_valid = false; int td_B = 0, td_T = 0, td_rows = 0; bool td_split = false; const void* td_key[6] = {};
@@ -983,6 +984,50 @@ int ensure_train_workspace(dsg_handle* h, int rows, int T) {
 
 // Descriptors depend on the batch size of THIS call (tile counts, row masks) and on T: rebuilt per call (host only,
 // one upload); cheap next to the step.
+// Arguments of one operator's activation-gradient kernel (dsg_train_step, and the fused narrow backward's table)
+void fill_res_bwd_args(const dsg_handle* h, const Op& op, int tiles, BlockBwdArgs& a, BlockBwdArgsH& ah) {
+    const float* A = h->arena;
+    const ResP& r = h->res[op.p];
+    memset(&a, 0, sizeof a);
+    a.in0 = seg_of(h, op.in0);
+    if (op.in1 >= 0) a.in1 = seg_of(h, op.in1);
+    a.h1 = trp(h, r.h1); a.h2 = trp(h, r.h2);
+    a.gout_a = trp(h, h->tensors[op.out].ga);
+    a.gout_b = h->tensors[op.out].is_skip ? trp(h, h->tensors[op.out].gb) : nullptr;
+    a.W3T = A + r.W3T; a.W2T = A + r.W2T; a.W1T = A + r.W1T; a.WscT = r.sclin ? A + r.WscT : nullptr;
+    a.gamma1 = A + r.g1p; a.beta1 = A + r.b1p; a.gamma2 = A + r.g2p; a.beta2 = A + r.b2p; a.gamma3 = A + r.g3p; a.beta3 = A + r.b3p;
+    a.gin0 = trp(h, h->tensors[op.in0].ga);
+    a.gin1 = op.in1 >= 0 ? trp(h, h->tensors[op.in1].gb) : nullptr;
+    a.du1 = trp(h, r.du1); a.dh1 = trp(h, r.dh1); a.dh2 = trp(h, r.dh2);
+    a.cs = h->tr_cs + r.cs_off; a.cs_stride = r.cs_stride;
+    a.rs1 = trp(h, r.rs1); a.rs2 = trp(h, r.rs2); a.rs3 = trp(h, r.rs3);
+    a.ntiles = tiles;
+    ah.b = a;
+    ah.W3Th = reinterpret_cast<const uint4*>(A + r.W3Th); ah.W2Th = reinterpret_cast<const uint4*>(A + r.W2Th);
+    ah.W1Th = reinterpret_cast<const uint4*>(A + r.W1Th);
+    ah.WscTh = r.sclin ? reinterpret_cast<const uint4*>(A + r.WscTh) : nullptr;
+    ah.m1 = h->maxabs + r.l1.w; ah.m2 = h->maxabs + r.l2.w; ah.m3 = h->maxabs + r.l3.w;
+    ah.msc = r.sclin ? h->maxabs + r.sc.w : nullptr;
+    ah.gmax_t = h->tr_gmax_t; ah.gmax_ld = h->gmax_ld; ah.slot_out = r.gslot_out; ah.slot_h2 = r.gslot_h2; ah.slot_h1 = r.gslot_h1;
+}
+void fill_lin_bwd_args(const dsg_handle* h, const Op& op, int tiles, LinBwdArgs& a) {
+    const float* A = h->arena;
+    const LinOpP& l = h->lin[op.p];
+    memset(&a, 0, sizeof a);
+    if (op.kind == OP_FINAL) {
+        a.gout_a = trp(h, h->tr_deps);
+        a.gamma = A + l.gp; a.beta = A + l.betap; a.du = trp(h, l.du); a.rs = trp(h, l.rs);
+    } else {
+        a.gout_a = trp(h, h->tensors[op.out].ga);
+        a.gout_b = h->tensors[op.out].is_skip ? trp(h, h->tensors[op.out].gb) : nullptr;
+    }
+    a.out_groups = groups_of(l.l.N);
+    a.WT = A + l.WT;
+    a.in = seg_of(h, op.in0);
+    a.gin = trp(h, h->tensors[op.in0].ga);
+    a.ntiles = tiles;
+}
+
 int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
     // Rebuilding and uploading the tables costs four pageable host-to-device copies and a stream synchronise - a pipeline
     // drain in front of every step (the enqueue of a step's ~85 launches then no longer hides behind the previous step)
@@ -1129,6 +1174,34 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
             }
             if (part < nparts) h->wg_part_end.push_back((int)wu.size());
         }
+    }
+    // fused narrow backward: the operators of the forward's narrow run, last first
+    std::vector<FusedBwdOpH> fb;
+    if (h->use_split && h->fuse_hi - h->fuse_lo >= 2) {
+        bool ok = true;
+        for (int oi = h->fuse_hi - 1; oi >= h->fuse_lo && ok; --oi) {
+            const Op& op = h->ops[oi];
+            FusedBwdOpH f;
+            memset(&f, 0, sizeof f);
+            if (op.kind == OP_RES) {
+                const ResP& r = h->res[op.p];
+                BlockBwdArgs a;
+                f.kind = 0; f.N = r.N; f.sclin = r.sclin ? 1 : 0;
+                fill_res_bwd_args(h, op, tiles, a, f.b);
+                ok = r.N <= 32;
+            } else if (op.kind == OP_LIN) {
+                f.kind = 1; f.ot = cdiv(h->lin[op.p].l.K, 32);
+                fill_lin_bwd_args(h, op, tiles, f.l);
+                ok = f.ot <= 2;
+            } else ok = false;
+            fb.push_back(f);
+        }
+        if (!ok) fb.clear();
+    }
+    h->fbwd_n = (int)fb.size();
+    if (h->fbwd_n) {
+        if (!h->fbwd_dev) HIPCK(hipMalloc(&h->fbwd_dev, (h->ops.size() + 1) * sizeof(FusedBwdOpH)));
+        HIPCK(hipMemcpyAsync(h->fbwd_dev, fb.data(), fb.size() * sizeof(FusedBwdOpH), hipMemcpyHostToDevice, s));
     }
     std::vector<ColsumUnit> cu;
     // chunk-major, group-minor: neighbouring waves stream neighbouring 1 KiB fragments of the same row tiles
@@ -1330,6 +1403,7 @@ void dsg_destroy(dsg_handle* h) {
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->fbwd_dev) (void)hipFree(h->fbwd_dev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
@@ -1732,69 +1806,48 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
         HIPCK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     }
+    // the G and A operands of a part are final once the backward kernel of its last block is enqueued: its weight gradients run
+    // on the side stream from there, beside the remaining chain kernels (one wave per SIMD below 65 536 rows: latency-bound,
+    // half the CU idle).  Extra dynamic LDS keeps them to one workgroup per CU so that a chain kernel's workgroup always finds room.
+    auto fork_parts = [&](int done_op) -> int {
+        while (next_part < (int)h->wg_fork_ops.size() && h->wg_fork_ops[next_part] >= done_op) {
+            const int u0 = next_part ? h->wg_part_end[next_part - 1] : 0, u1 = h->wg_part_end[next_part];
+            unsigned* gm = h->tr_gmax + (size_t)(1 + next_part) * kMaxGmax;
+            HIPCK(hipEventRecord(h->ev_fork, s));
+            HIPCK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+            hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, h->side_stream, h->tr_gmax_t, h->gmax_ld, gm);
+            if (u1 > u0)
+                hipLaunchKernelGGL(k_wgrad_h, dim3(u1 - u0), dim3(256), h->wg_early_lds, h->side_stream, h->wg_desc_dev, h->wg_unit_dev + u0,
+                                   gm, h->tr_slabs, h->slab_stride, tiles, h->tr_chunks);
+            ++next_part;
+        }
+        return 0;
+    };
     for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
         const Op& op = h->ops[oi];
         if (op.kind == OP_PROJ) continue;
+        if (h->use_split && h->fbwd_n > 0 && oi == h->fuse_hi - 1) {
+            // the narrow run: one launch walks its operators in reverse (k_fused_narrow_bwd_h)
+            hipLaunchKernelGGL(k_fused_narrow_bwd_h, dim3(cdiv(tiles, kWavesPerBlock)), dim3(256), 0, s, h->fbwd_dev, h->fbwd_n, tiles);
+            oi = h->fuse_lo;
+            if (fork_parts(oi)) return 1;
+            continue;
+        }
         if (op.kind == OP_RES) {
             const ResP& r = h->res[op.p];
             BlockBwdArgs a;
-            memset(&a, 0, sizeof a);
-            a.in0 = seg_of(h, op.in0);
-            if (op.in1 >= 0) a.in1 = seg_of(h, op.in1);
-            a.h1 = trp(h, r.h1); a.h2 = trp(h, r.h2);
-            a.gout_a = trp(h, h->tensors[op.out].ga);
-            a.gout_b = h->tensors[op.out].is_skip ? trp(h, h->tensors[op.out].gb) : nullptr;
-            a.W3T = A + r.W3T; a.W2T = A + r.W2T; a.W1T = A + r.W1T; a.WscT = r.sclin ? A + r.WscT : nullptr;
-            a.gamma1 = A + r.g1p; a.beta1 = A + r.b1p; a.gamma2 = A + r.g2p; a.beta2 = A + r.b2p; a.gamma3 = A + r.g3p; a.beta3 = A + r.b3p;
-            a.gin0 = trp(h, h->tensors[op.in0].ga);
-            a.gin1 = op.in1 >= 0 ? trp(h, h->tensors[op.in1].gb) : nullptr;
-            a.du1 = trp(h, r.du1); a.dh1 = trp(h, r.dh1); a.dh2 = trp(h, r.dh2);
-            a.cs = h->tr_cs + r.cs_off; a.cs_stride = r.cs_stride;
-            a.rs1 = trp(h, r.rs1); a.rs2 = trp(h, r.rs2); a.rs3 = trp(h, r.rs3);
-            a.ntiles = tiles;
+            BlockBwdArgsH ah;
+            fill_res_bwd_args(h, op, tiles, a, ah);
             if (h->use_split) {
-                BlockBwdArgsH ah;
-                ah.b = a;
-                ah.W3Th = reinterpret_cast<const uint4*>(A + r.W3Th); ah.W2Th = reinterpret_cast<const uint4*>(A + r.W2Th);
-                ah.W1Th = reinterpret_cast<const uint4*>(A + r.W1Th);
-                ah.WscTh = r.sclin ? reinterpret_cast<const uint4*>(A + r.WscTh) : nullptr;
-                ah.m1 = h->maxabs + r.l1.w; ah.m2 = h->maxabs + r.l2.w; ah.m3 = h->maxabs + r.l3.w;
-                ah.msc = r.sclin ? h->maxabs + r.sc.w : nullptr;
-                ah.gmax_t = h->tr_gmax_t; ah.gmax_ld = h->gmax_ld; ah.slot_out = r.gslot_out; ah.slot_h2 = r.gslot_h2; ah.slot_h1 = r.gslot_h1;
                 launch_res_bwd_h(r.N, r.sclin, ah, s);
-                if (next_part < (int)h->wg_fork_ops.size() && oi == h->wg_fork_ops[next_part]) {
-                    // the G and A operands of this part are final: its weight gradients run on the side stream from here,
-                    // beside the remaining chain kernels (one wave per SIMD below 65 536 rows: latency-bound, half the CU idle).
-                    // Extra dynamic LDS keeps it to one workgroup per CU so that a chain kernel's workgroup always finds room.
-                    const int u0 = next_part ? h->wg_part_end[next_part - 1] : 0, u1 = h->wg_part_end[next_part];
-                    unsigned* gm = h->tr_gmax + (size_t)(1 + next_part) * kMaxGmax;
-                    HIPCK(hipEventRecord(h->ev_fork, s));
-                    HIPCK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-                    hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, h->side_stream, h->tr_gmax_t, h->gmax_ld, gm);
-                    if (u1 > u0)
-                        hipLaunchKernelGGL(k_wgrad_h, dim3(u1 - u0), dim3(256), h->wg_early_lds, h->side_stream, h->wg_desc_dev, h->wg_unit_dev + u0,
-                                           gm, h->tr_slabs, h->slab_stride, tiles, h->tr_chunks);
-                    ++next_part;
-                }
+                if (fork_parts(oi)) return 1;
             } else {
                 launch_res_bwd(r.N, r.sclin, a, s);
             }
         } else {
             const LinOpP& l = h->lin[op.p];
             LinBwdArgs a;
-            memset(&a, 0, sizeof a);
-            if (op.kind == OP_FINAL) {
-                a.gout_a = trp(h, h->tr_deps);
-                a.gamma = A + l.gp; a.beta = A + l.betap; a.du = trp(h, l.du); a.rs = trp(h, l.rs);
-            } else {
-                a.gout_a = trp(h, h->tensors[op.out].ga);
-                a.gout_b = h->tensors[op.out].is_skip ? trp(h, h->tensors[op.out].gb) : nullptr;
-            }
-            a.out_groups = groups_of(l.l.N);
-            a.WT = A + l.WT;
-            a.in = seg_of(h, op.in0);
-            a.gin = trp(h, h->tensors[op.in0].ga);
-            a.ntiles = tiles;
+            fill_lin_bwd_args(h, op, tiles, a);
             launch_lin_bwd(l.l.K, op.kind == OP_FINAL, a, s);
         }
     }

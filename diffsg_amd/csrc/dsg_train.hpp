@@ -559,10 +559,7 @@ struct LinBwdArgs {
 };
 
 template <int OT, bool LNBWD>
-__global__ __launch_bounds__(256) void k_linear_bwd(const LinBwdArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
-    if (tile >= a.ntiles) return;
+__device__ __forceinline__ void linear_bwd_body(const LinBwdArgs& a, int tile, int lane) {
     const int h = lane >> 5, j = lane & 31;
     const int NGo = a.out_groups, KG = a.in.groups;
     f32x16 dx[OT];
@@ -642,6 +639,14 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const LinBwdArgs a) {
         if (G < KG)
             st4(a.gin + ((size_t)tile * KG + G) * 256 + lane * 4,
                 make_float4(dx[G >> 2][4 * (G & 3)], dx[G >> 2][4 * (G & 3) + 1], dx[G >> 2][4 * (G & 3) + 2], dx[G >> 2][4 * (G & 3) + 3]));
+}
+
+template <int OT, bool LNBWD>
+__global__ __launch_bounds__(256) void k_linear_bwd(const LinBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
+    if (tile >= a.ntiles) return;
+    linear_bwd_body<OT, LNBWD>(a, tile, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

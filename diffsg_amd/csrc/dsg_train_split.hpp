@@ -361,4 +361,52 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_h(const BlockBwdArgsH a
     resblock_bwd_body<N, SCLIN>(b, BwdGemmSplit{a, lane, SCLIN, tile}, tile, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The narrow run of the backward pass in ONE launch (mirror of k_fused_narrow_h): a wave walks the run's operators in
+// reverse order for its row tile.  Every gradient tensor is still stored (it is the G operand of a weight gradient) and
+// the next operator reads it back from memory - written and read by the same wave, never read before it was written,
+// so `s_waitcnt vmcnt(0)` between operators is all the ordering needed.  What goes away is a launch boundary per
+// operator (27 of them in MSR-80c, each a drain, a launch and a cold start for ~10 us of latency-bound work).
+// LayerNorm vectors come from global memory (the per-operator kernels stage them in LDS; here the operators of one
+// workgroup's waves are not in step).
+// ---------------------------------------------------------------------------------------------
+struct FusedBwdOpH {
+    int kind;        // 0 = residual block, 1 = plain Linear
+    int N;           // block width
+    int sclin;
+    int ot;          // Linear: 32-feature tiles of its input gradient
+    BlockBwdArgsH b;
+    LinBwdArgs l;
+};
+
+__global__ __launch_bounds__(256, 2) void k_fused_narrow_bwd_h(const FusedBwdOpH* __restrict__ ops, int nops, int ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (tile >= ntiles) return;
+    for (int i = 0; i < nops; ++i) {
+        const FusedBwdOpH& op = ops[i];
+        if (i) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous operator's stores (this wave's own) have landed
+        if (op.kind == 0) {
+            if (op.sclin) {
+                switch (op.N) {
+                    case 4: resblock_bwd_body<4, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
+                    case 8: resblock_bwd_body<8, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
+                    case 16: resblock_bwd_body<16, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
+                    default: resblock_bwd_body<32, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
+                }
+            } else {
+                switch (op.N) {
+                    case 4: resblock_bwd_body<4, false>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
+                    case 8: resblock_bwd_body<8, false>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
+                    case 16: resblock_bwd_body<16, false>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
+                    default: resblock_bwd_body<32, false>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
+                }
+            }
+        } else {
+            if (op.ot <= 1) linear_bwd_body<1, false>(op.l, tile, lane);
+            else linear_bwd_body<2, false>(op.l, tile, lane);
+        }
+    }
+}
+
 }  // namespace dsg
