@@ -96,6 +96,11 @@ _SIGS = {
     "dsg_param_total": (ctypes.c_longlong, [ctypes.c_void_p]),
     "dsg_train_step": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_void_p]),
+    "dsg_train_draws": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "dsg_train_step_seeded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_ulonglong,
+                                             ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_int, ctypes.c_void_p]),
     "dsg_bind_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
     "dsg_set_precision": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "dsg_set_launch_policy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),

@@ -149,6 +149,32 @@ def load_test_co(ckpt_path, dataset_path=DEFAULT_DATASET, T=20, omega=500.0, bat
     return out
 
 
+@torch.no_grad()
+def load_test_co_debug(ckpt_path, dataset_path=DEFAULT_DATASET, T=400, omega=150.0, batch_size=512, want2look=tuple(range(10)), log=print):
+    """classifier_free_CO.py:358-413: the first test batch with the de-noising path recorded; prints, for the wanted rows, the
+    condition, the label and every step's (decoded y_t, guided eps).  Returns (Y_pred, y_record, eps_record) of that batch."""
+    X_train, Y_train, X_test, Y_test, custom_config = co_data_load(dataset_path)
+    node_num = Y_train.shape[1]
+    device = _device()
+    diffusion_model = build_model(node_num, custom_config['sfn'] * node_num, device, T, custom_config)
+    diffusion_model.load_state_dict(torch.load(ckpt_path, map_location="cpu"))
+    diffusion_model.to(device)
+    x = torch.tensor(X_test[:batch_size], dtype=torch.float32, device=device)
+    diffusion_model.record_denoise_path = True
+    Y_pred = diffusion_model.sample_checked(x, omega)
+    diffusion_model.record_denoise_path = False
+    ys = diffusion_model.y_i_record.reshape(x.shape[0], T, -1)
+    es = diffusion_model.eps_i_record.reshape(x.shape[0], T, -1)
+    for i in want2look:
+        if i >= x.shape[0]:
+            break
+        log("%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%")
+        log(x[i], Y_test[i])
+        for j in range(T):
+            log(ys[i, j, :], es[i, j, :])
+    return Y_pred, ys, es
+
+
 # ------------------------------------------------------------------ self-check harness (classifier_free_CO.py:416-558)
 def validation_data_gen():
     """classifier_free_CO.py:416-449: 3 x 1000 rows whose label is the one-hot index of the node block that got +1; same

@@ -116,3 +116,29 @@ def load_test_msr(ckpt_path, dataset_path=DEFAULT_DATASET, T=20, omega=500, batc
     log(f"less ratio: {out['less_ratio']}")
     log(f"avg rate diff:\n {out['avg_rate_diff']}")
     return out
+
+
+@torch.no_grad()
+def load_test_msr_debug(ckpt_path, dataset_path=DEFAULT_DATASET, T=20, omega=150, want2look=tuple(range(10)), log=print):
+    """classifier_free_MSR.py:301-344: sample a handful of test rows with the de-noising path recorded and print, per row, the
+    condition, the prediction and every step's (decoded y_t, guided eps).  The reference indexes its records `[step, row]`; here
+    they are `(rows, T*D)` (MSR.py:153-154), so the loop reshapes.  Returns (Y_pred, y_record, eps_record)."""
+    _, _, X_test, _, custom_config = msr_data_load(dataset_path)
+    M, W = custom_config['M'], custom_config['W']
+    device = _device()
+    diffusion_model = build_model(M, custom_config['sfn'] * M, device, T, custom_config, W)
+    diffusion_model.load_state_dict(torch.load(ckpt_path, map_location="cpu"))
+    diffusion_model.to(device)
+    X = torch.tensor(X_test, dtype=torch.float32, device=device)[list(want2look)]
+    diffusion_model.record_denoise_path = True
+    Y_pred = diffusion_model.sample_checked(X, omega)
+    diffusion_model.record_denoise_path = False
+    ys = diffusion_model.y_i_record.reshape(X.shape[0], T, -1)
+    es = diffusion_model.eps_i_record.reshape(X.shape[0], T, -1)
+    for i in range(X.shape[0]):
+        log("%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%%")
+        log(X[i], Y_pred[i])
+        for j in range(T):
+            log(ys[i, j, :], es[i, j, :])
+    return Y_pred, ys, es
+

@@ -210,6 +210,7 @@ struct dsg_handle {
     int n_gmax = 0;
     size_t slab_stride = 0;
     int* tr_ts = nullptr;        // [rows]
+    float* tr_noise = nullptr; float* tr_mask = nullptr;   // [rows][D], [rows]: device-side draws (dsg_train_step_seeded), allocated on first use
     float* tr_yt_rm = nullptr;   // [rows][D]
     float* tr_tsave = nullptr;   // emb | h1pre | h1s | tpre | d_st | d_h1s
     long long* tw_dst_dev = nullptr; const float** tw_src_dev = nullptr; int tw_rows = 0;  // time_emb.weight rows of all blocks
@@ -365,12 +366,12 @@ void free_graphs(dsg_handle* h) {
 constexpr int kMaxGmax = 256;   // distinct gradient tensors whose max|G| is tracked (3 per block + 1 per Linear)
 
 void free_train_workspace(dsg_handle* h) {
-    void* ptrs[] = {h->tr_ws, h->tr_slabs, h->tr_gsum, h->tr_ts, h->tr_yt_rm, h->tr_tsave, h->wg_desc_dev, h->wg_unit_dev,
+    void* ptrs[] = {h->tr_ws, h->tr_slabs, h->tr_gsum, h->tr_ts, h->tr_noise, h->tr_mask, h->tr_yt_rm, h->tr_tsave, h->wg_desc_dev, h->wg_unit_dev,
                     h->cs_desc_dev, h->cs_unit_dev, h->tr_gmax, h->tr_gmax_t, h->tr_cs, h->cs_map_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->tr_ws = h->tr_slabs = h->tr_gsum = h->tr_yt_rm = h->tr_tsave = nullptr;
-    h->tr_ts = nullptr; h->tr_gmax = nullptr; h->tr_gmax_t = nullptr; h->tr_cs = nullptr; h->cs_map_dev = nullptr;
+    h->tr_ts = nullptr; h->tr_noise = nullptr; h->tr_mask = nullptr; h->tr_gmax = nullptr; h->tr_gmax_t = nullptr; h->tr_cs = nullptr; h->cs_map_dev = nullptr;
     h->wg_desc_dev = nullptr; h->wg_unit_dev = nullptr; h->cs_desc_dev = nullptr; h->cs_unit_dev = nullptr;
     h->wg_units = h->cs_units = 0;
     h->tr_rows = h->tr_T = 0;
@@ -1765,6 +1766,11 @@ int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const flo
 // ------------------------------------------------------------------------------------------------------
 // training step
 // ------------------------------------------------------------------------------------------------------
+namespace {
+int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int* ts, const float* noise, const float* cond_mask,
+                    const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat, float* loss_out, int B, hipStream_t s);
+}
+
 int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* ts, const float* noise, const float* cond_mask,
                    const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat, float* loss_out, int B, void* stream) {
     if (check_bound(h)) return 1;
@@ -1772,7 +1778,40 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     if (!y || !cond || !ts || !noise || !sqrt_acp || !sqrt_1m_acp || !grads_flat || !loss_out)
         return fail("dsg_train_step: null pointer argument");
     if (ensure_train_workspace(h, B, T)) return 1;
-    hipStream_t s = (hipStream_t)stream;
+    return train_step_impl(h, y, cond, ts, noise, cond_mask, sqrt_acp, sqrt_1m_acp, T, grads_flat, loss_out, B, (hipStream_t)stream);
+}
+
+int dsg_train_draws(unsigned long long seed, unsigned long long call, int T, float keep_prob, int B, int D, int* ts, float* noise,
+                    float* cond_mask, void* stream) {
+    if (B < 1 || D < 1 || T < 1) return fail("dsg_train_draws: B, D and T must be >= 1");
+    if (call >> 30) return fail("dsg_train_draws: call counter out of range (2^30)");
+    const size_t blocks = (((size_t)B * D + 3) / 4 + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+    hipLaunchKernelGGL(k_train_draws, dim3(grid), dim3(256), 0, (hipStream_t)stream, ts, noise, cond_mask, B, D, T, keep_prob, seed, (unsigned)call);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int dsg_train_step_seeded(dsg_handle* h, const float* y, const float* cond, unsigned long long seed, unsigned long long call,
+                          float keep_prob, const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat, float* loss_out,
+                          int B, void* stream) {
+    if (check_bound(h)) return 1;
+    if (B < 1 || T < 1) return fail("B and T must be >= 1");
+    if (!y || !cond || !sqrt_acp || !sqrt_1m_acp || !grads_flat || !loss_out) return fail("dsg_train_step_seeded: null pointer argument");
+    if (ensure_train_workspace(h, B, T)) return 1;
+    const int D = h->d.input_dim;
+    if (!h->tr_noise) {
+        HIPCK(hipMalloc(&h->tr_noise, (size_t)h->tr_rows * D * sizeof(float)));
+        HIPCK(hipMalloc(&h->tr_mask, (size_t)h->tr_rows * sizeof(float)));
+    }
+    // ts goes straight into the workspace copy the step reads (train_step_impl skips its own copy when handed that pointer)
+    if (dsg_train_draws(seed, call, T, keep_prob, B, D, h->tr_ts, h->tr_noise, h->tr_mask, stream)) return 1;
+    return train_step_impl(h, y, cond, h->tr_ts, h->tr_noise, h->tr_mask, sqrt_acp, sqrt_1m_acp, T, grads_flat, loss_out, B, (hipStream_t)stream);
+}
+
+namespace {
+int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int* ts, const float* noise, const float* cond_mask,
+                    const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat, float* loss_out, int B, hipStream_t s) {
     if (build_train_descs(h, B, T, s)) return 1;
     const int D = h->d.input_dim, C = h->d.cond_dim, CG = groups_of(C), DG = groups_of(D), tiles = cdiv(B, 32);
     const int td = h->td, half = h->d.proj_dim / 2;
@@ -1782,7 +1821,7 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     // ---- forward
     auto mark = [&](int i) { if (h->train_prof) (void)hipEventRecord(h->tev[i], s); };
     mark(0);
-    HIPCK(hipMemcpyAsync(h->tr_ts, ts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (ts != h->tr_ts) HIPCK(hipMemcpyAsync(h->tr_ts, ts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_linspace_t, dim3(cdiv(T, 256)), dim3(256), 0, s, h->tvals, T);
     run_time_path(h, T, s, true);
     hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tiles * CG * 256, 256)), dim3(256), 0, s, cond, cond_mask, B, C, CG, h->condfrag, tiles);
@@ -1901,6 +1940,7 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
     HIPCK(hipGetLastError());
     return 0;
 }
+}  // namespace
 
 int dsg_train_profile_enable(dsg_handle* h, int on) {
     if (!h) return fail("null handle");

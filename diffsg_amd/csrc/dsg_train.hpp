@@ -40,6 +40,33 @@ __global__ void k_qsample(const float* __restrict__ y, const float* __restrict__
     }
 }
 
+// The step's three draws on the device (dsg_train_draws): Philox4x32-10 keyed by seed, counter word 2 = 4*call + kind so that the
+// three kinds and successive calls never share a counter.  noise: normal4 (Box-Muller, as the sampling loop's);
+// ts = floor(u * T), u on a 24-bit grid;  mask = u < keep_prob.
+__global__ void k_train_draws(int* __restrict__ ts, float* __restrict__ noise, float* __restrict__ mask, int B, int D, int T, float keep,
+                              unsigned long long seed, unsigned call) {
+    const size_t n = (size_t)B * D, n4 = (n + 3) / 4, b4 = ((size_t)B + 3) / 4;
+    for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
+        if (noise) {
+            float zz[4];
+            normal4(seed, 4u * call, i4, zz);
+            for (int p = 0; p < 4; ++p)
+                if (i4 * 4 + p < n) noise[i4 * 4 + p] = zz[p];
+        }
+        if (i4 < b4) {
+            uint32_t r[4], q[4];
+            philox4x32_10((uint32_t)i4, (uint32_t)(i4 >> 32), 4u * call + 1u, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            philox4x32_10((uint32_t)i4, (uint32_t)(i4 >> 32), 4u * call + 2u, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), q);
+            for (int p = 0; p < 4; ++p) {
+                const size_t row = i4 * 4 + p;
+                if (row >= (size_t)B) break;
+                if (ts) { const int t = (int)(((r[p] >> 8) * (1.0f / 16777216.0f)) * (float)T); ts[row] = t < T ? t : T - 1; }
+                if (mask) mask[row] = ((q[p] >> 8) * (1.0f / 16777216.0f)) < keep ? 1.0f : 0.0f;
+            }
+        }
+    }
+}
+
 // loss = mean((noise - eps_hat)^2) (F.mse_loss, MSR.py:112); d_eps = 2 (eps_hat - noise) / (B*D) in fragment layout.
 // Per-block float64 partial sums; k_loss_final reduces them in a fixed order.
 __global__ __launch_bounds__(256) void k_loss_grad(const float* __restrict__ eps, const float* __restrict__ noise, int nrows, int D,

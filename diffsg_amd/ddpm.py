@@ -49,6 +49,8 @@ class DDPMCore(nn.Module):
         self.ema_update_rate = ema_update_rate
 
         self.record_denoise_path = False
+        self.device_draws = None       # int seed: training draws on the device (see _forward_device_draws); None: torch's generator
+        self._draw_calls = 0
         self.y_i_record = None
         self.eps_i_record = None
 
@@ -172,6 +174,8 @@ class DDPMCore(nn.Module):
             raise RuntimeError("DDPM.forward: inputs are not on a HIP device; libdiffsg_hip has no CPU path")
         hd = self.model.native_handle()
         B, dev = y.shape[0], y.device
+        if self.device_draws is not None and ts is None and noise is None and cond_mask is None:
+            return self._forward_device_draws(hd, y, cond)
         if ts is None:
             ts = torch.randint(low=0, high=self.T, size=(1, B), device=dev)
         if noise is None:
@@ -186,21 +190,47 @@ class DDPMCore(nn.Module):
         if ts32.numel() != B or mk.numel() != B or nz.shape != y32.shape:
             raise ValueError("ts / noise / cond_mask do not match the batch")
         L = _lib.lib()
-        total = L.dsg_param_total(hd)
-        if getattr(self, "_grad_bucket", None) is None or self._grad_bucket.device != dev or self._grad_bucket.numel() != total:
-            self._grad_pool = []
-            self._grad_bucket = torch.zeros(total, device=dev, dtype=torch.float32)
-            self._loss_anchor = torch.zeros((), device=dev, requires_grad=True)
         # the step's gradients land in a buffer that belongs to THIS call until its backward() publishes them: two forward
         # calls before one backward ((m(a, c) + m(b, c)).backward()) must not share it.  Buffers return to the pool in _publish
         # (the common one-forward-one-backward loop reuses a single buffer); a call whose graph is dropped just loses its buffer
-        work = self._grad_pool.pop() if self._grad_pool else torch.empty(total, device=dev, dtype=torch.float32)
+        work = self._grad_buffers(L, hd, dev)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             _lib.check(L.dsg_train_step(hd, _lib.ptr(y32), _lib.ptr(c32), _lib.ptr(ts32), _lib.ptr(nz), _lib.ptr(mk),
                                         _lib.ptr(self.sqrt_alphas_cumprod), _lib.ptr(self.sqrt_one_minus_alphas_cumprod),
                                         self.T, _lib.ptr(work), _lib.ptr(loss), B, _lib.stream_ptr()))
         self._keepalive = (y32, c32, ts32, nz, mk)
+        if not torch.is_grad_enabled():
+            self._grad_pool.append(work)
+            return loss
+        return _PublishGrads.apply(self._loss_anchor, loss, self, work)
+
+    def _grad_buffers(self, L, hd, dev):
+        total = L.dsg_param_total(hd)
+        if getattr(self, "_grad_bucket", None) is None or self._grad_bucket.device != dev or self._grad_bucket.numel() != total:
+            self._grad_pool = []
+            self._grad_bucket = torch.zeros(total, device=dev, dtype=torch.float32)
+            self._loss_anchor = torch.zeros((), device=dev, requires_grad=True)
+        return self._grad_pool.pop() if self._grad_pool else torch.empty(total, device=dev, dtype=torch.float32)
+
+    def _forward_device_draws(self, hd, y, cond):
+        """`device_draws = seed`: ts, noise and the condition mask are drawn inside the library (Philox keyed by (seed, call
+        number); dsg_train_step_seeded) - same distributions as MSR.py:101-107, not torch's generator.  For throughput runs; the
+        default (None) keeps the reference's draws and order."""
+        B, dev = y.shape[0], y.device
+        y32 = y.detach().to(torch.float32).contiguous()
+        c32 = cond.detach().to(dev, torch.float32).contiguous()
+        L = _lib.lib()
+        work = self._grad_buffers(L, hd, dev)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        call = self._draw_calls
+        self._draw_calls += 1
+        with torch.cuda.device(dev):
+            _lib.check(L.dsg_train_step_seeded(hd, _lib.ptr(y32), _lib.ptr(c32), int(self.device_draws) & (2 ** 64 - 1), call,
+                                               float(1.0 - self.uncond_prob), _lib.ptr(self.sqrt_alphas_cumprod),
+                                               _lib.ptr(self.sqrt_one_minus_alphas_cumprod), self.T, _lib.ptr(work), _lib.ptr(loss), B,
+                                               _lib.stream_ptr()))
+        self._keepalive = (y32, c32)
         if not torch.is_grad_enabled():
             self._grad_pool.append(work)
             return loss

@@ -123,6 +123,19 @@ int dsg_train_step(dsg_handle* h, const float* y, const float* cond, const int* 
                    const float* cond_mask, const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat,
                    float* loss_out, int B, void* stream);
 
+/* The three random draws of a training step on the device (`ts|null, noise|null, mask|null, seed`): Philox4x32-10
+ * keyed by (seed, call), independent streams for  ts [B] ~ U{0..T-1}  (MSR.py:101),  noise [B][D] ~ N(0,1)  (MSR.py:102, Box-Muller)
+ * and  cond_mask [B] ~ Bernoulli(keep_prob)  (MSR.py:107, keep_prob = 1 - uncond_prob).  Not torch's generator: a run that
+ * must reproduce the reference's draws keeps drawing on the caller's side and passes them to dsg_train_step.
+ * dsg_train_draws writes them to caller buffers (any may be NULL); dsg_train_step_seeded draws into the handle's workspace and
+ * runs the step on them -- identical to dsg_train_draws followed by dsg_train_step, without the three generator launches and the
+ * layout/dtype conversion passes in front of the fused step. */
+int dsg_train_draws(unsigned long long seed, unsigned long long call, int T, float keep_prob, int B, int D, int* ts,
+                    float* noise, float* cond_mask, void* stream);
+int dsg_train_step_seeded(dsg_handle* h, const float* y, const float* cond, unsigned long long seed, unsigned long long call,
+                          float keep_prob, const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat,
+                          float* loss_out, int B, void* stream);
+
 /* Measurement hook for bench.py's train leg: with the profile enabled every dsg_train_step records HIP events on `stream`
  * at its phase boundaries (no synchronisation); dsg_train_profile waits for the last profiled step and returns the times in
  * ms of { forward (+ q_sample, loss), activation backward, column sums, grouped weight-gradient launch, reduce + time path }. */

@@ -595,6 +595,79 @@ def test_train_step_is_run_to_run_deterministic(name, B):
             assert torch.equal(a, b), (rep, k)
 
 
+def _device_draws(seed, call, T, keep, B, D):
+    import ctypes
+    from diffsg_amd import _lib
+    ts = torch.empty(B, dtype=torch.int32, device="cuda")
+    noise = torch.empty(B, D, device="cuda")
+    mask = torch.empty(B, device="cuda")
+    _lib.check(_lib.lib().dsg_train_draws(seed, call, T, ctypes.c_float(keep), B, D, _lib.ptr(ts), _lib.ptr(noise), _lib.ptr(mask),
+                                          _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return ts, noise, mask
+
+
+def test_device_training_draws_have_the_reference_distributions():
+    """dsg_train_draws (SURVEY 8(b) seed form): ts ~ U{0..T-1} (MSR.py:101), noise ~ N(0,1) (MSR.py:102), mask ~ Bernoulli(0.9)
+    (MSR.py:107); a function of (seed, call) only; the three streams and successive calls are independent."""
+    T, B, D, keep = 20, 1 << 16, 80, 0.9
+    ts, noise, mask = _device_draws(123, 0, T, keep, B, D)
+    ts2, noise2, mask2 = _device_draws(123, 0, T, keep, B, D)
+    assert torch.equal(ts, ts2) and torch.equal(noise, noise2) and torch.equal(mask, mask2)
+    ts3, noise3, mask3 = _device_draws(123, 1, T, keep, B, D)
+    assert not torch.equal(ts, ts3) and not torch.equal(noise, noise3) and not torch.equal(mask, mask3)
+    assert int(ts.min()) == 0 and int(ts.max()) == T - 1
+    counts = torch.bincount(ts.long().cpu(), minlength=T).double()
+    chi2 = float(((counts - B / T) ** 2 / (B / T)).sum())
+    assert chi2 < 60.0, chi2                                   # 19 degrees of freedom: P(chi2 > 60) ~ 4e-6
+    m = set(mask.unique().tolist())
+    assert m <= {0.0, 1.0} and abs(float(mask.mean()) - keep) < 5 * (keep * (1 - keep) / B) ** 0.5
+    z = noise.double().flatten()
+    n = z.numel()
+    assert abs(float(z.mean())) < 5 / n ** 0.5 and abs(float(z.var()) - 1.0) < 5 * (2.0 / n) ** 0.5
+    assert abs(float((z ** 3).mean())) < 5 * (15.0 / n) ** 0.5 and abs(float((z ** 4).mean()) - 3.0) < 5 * (96.0 / n) ** 0.5
+    assert float(z.abs().max()) < 7.0 and torch.isfinite(z).all()
+    # independence across the streams and calls (sample correlation of 5e6 / 65536 pairs)
+    assert abs(float(torch.corrcoef(torch.stack((z, noise3.double().flatten())))[0, 1])) < 5 / n ** 0.5
+    assert abs(float(torch.corrcoef(torch.stack((ts.double(), mask.double())))[0, 1])) < 5 / B ** 0.5
+    # ragged sizes write exactly B rows
+    ts4, noise4, mask4 = _device_draws(5, 3, 7, 0.5, 33, 3)
+    assert ts4.shape == (33,) and int(ts4.max()) <= 6 and torch.isfinite(noise4).all()
+
+
+@pytest.mark.parametrize("name,B", [("msr80", 100), ("co3", 32768 + 5)])
+def test_seeded_train_step_is_the_explicit_step_on_the_same_draws(name, B):
+    """DDPM.device_draws = seed (dsg_train_step_seeded) == dsg_train_draws + dsg_train_step, bit for bit: loss and every gradient;
+    and the call counter advances the draws."""
+    T = 20
+    plan, p = synth_params(name, 5)
+    ddpm = make_ddpm(name, p, T)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(B)
+    y = (torch.rand(B, cfg["input_dim"], generator=g) * 0.25).cuda()
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    ddpm.device_draws = 77
+    losses = []
+    for call in range(2):
+        for q in ddpm.model.parameters():
+            q.grad = None
+        ddpm.device_draws = 77
+        loss = ddpm(y, cond)
+        loss.backward()
+        got = (float(loss.detach()), [q.grad.detach().clone() for q in ddpm.model.parameters()])
+        ts, noise, mask = _device_draws(77, call, T, 1.0 - ddpm.uncond_prob, B, cfg["input_dim"])
+        for q in ddpm.model.parameters():
+            q.grad = None
+        ddpm.device_draws = None
+        ref = ddpm(y, cond, ts=ts[None, :].long(), noise=noise, cond_mask=mask[:, None])
+        ref.backward()
+        assert float(ref.detach()) == got[0], call
+        for (k, q), a in zip(ddpm.model.named_parameters(), got[1]):
+            assert torch.equal(q.grad, a), (call, k)
+        losses.append(got[0])
+    assert losses[0] != losses[1]
+
+
 def test_sampling_is_run_to_run_deterministic():
     """Same seed -> bit-identical samples (device Philox noise, fixed-order renorm reductions)."""
     name, T, B = "msr80", 20, 4096
@@ -729,6 +802,13 @@ def test_entry_points_train_save_load_eval(tmp_path):
                             "reciprocal_sqrt_alphas", "remove_noise_coeff", "sqrt_betas"] and len(sd) == 985
     out = MSR.load_test_msr(ck, os.path.join(dd, "3c_10w_200samples.csv"), omega=1.0, log=logs.append)
     assert np.isfinite(out["less_ratio"]) and 0.0 < out["less_ratio"] < 1.5
+    # the debug loader (classifier_free_MSR.py:301-344): 4 rows, every step's decoded state and guided eps; the last recorded
+    # state is the returned sample through the MSR decoder (MSR.py:149-151)
+    printed = []
+    yp, ys, es = MSR.load_test_msr_debug(ck, os.path.join(dd, "3c_10w_200samples.csv"), omega=1.0, want2look=(0, 1, 2, 3),
+                                         log=lambda *a: printed.append(a))
+    assert ys.shape == (4, 20, 3) and es.shape == (4, 20, 3) and len(printed) == 4 * (2 + 20)
+    assert np.allclose(ys[:, -1, :], MSR.custom_decoder(yp).cpu().numpy(), atol=1e-6) and np.isfinite(es).all()
     m = NU.train_ddpm_nu(os.path.join(dd, "3u_18mW_200samples.csv"), epochs=1, batch_size=70, log=logs.append)
     assert np.isfinite(float(logs[-1].split("Loss:")[1]))
     ck = str(tmp_path / "ddpm_nu.pt")
@@ -739,6 +819,10 @@ def test_entry_points_train_save_load_eval(tmp_path):
     ck = str(tmp_path / "ddpm_co.pt")
     torch.save(m.state_dict(), ck)
     assert np.isfinite(CO.load_test_co(ck, os.path.join(dd, "3nodes_200samples_ood.csv"), omega=1.0, log=logs.append)["exceeded_ratio"])
+    printed = []
+    yp, ys, es = CO.load_test_co_debug(ck, os.path.join(dd, "3nodes_200samples_ood.csv"), T=20, omega=1.0, want2look=(0, 5),
+                                       log=lambda *a: printed.append(a))
+    assert ys.shape[1:] == (20, 3) and ys.shape[0] == yp.shape[0] and len(printed) == 2 * (2 + 20) and np.isfinite(ys).all()
 
 
 def test_record_denoise_path(gold):

@@ -13,6 +13,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 cond = torch.rand(B, 80, device=dev); y = torch.rand(B, 80, device=dev) * 0.25
 if os.environ.get('POLICY'):          # "coop_max_tiles,narrow_small_max_tiles" (dsg_set_launch_policy), e.g. POLICY=1024,1024
     ddpm.model.set_launch_policy(*[int(v) for v in os.environ['POLICY'].split(',')])
+if os.environ.get('DEVICE_DRAWS'):     # ts / noise / mask drawn inside the library (dsg_train_step_seeded)
+    ddpm.device_draws = 1
 def one():
     loss = ddpm(y, cond); loss.backward(); opt.step(); opt.zero_grad(); return loss
 for _ in range(3): one()
