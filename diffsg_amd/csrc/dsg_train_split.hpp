@@ -362,6 +362,328 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_h(const BlockBwdArgsH a
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cooperative backward of the 64- and 128-wide blocks (mirror of k_resblock_c): the N/32 waves of a row tile each own one
+// 32-feature slice of every gradient tensor.  One wave per tile (k_resblock_bwd_h) is a serial walk of ~600 MFMAs, ~12 000 VALU
+// and a dozen exposed memory round trips: 70-105 us whatever the batch, 60 % of it waiting.  Here a wave does a quarter of
+// the arithmetic, requests every saved tensor it will need at the start, and the row-wide quantities cross the slices
+// through LDS:
+//   row max of a gradient (the per-row power-of-two operand scale of the split GEMMs), LayerNorm statistics of h2 / h1
+//   (per-slice (mean, M2), Chan merge), the two row sums of a LayerNorm backward, and the B-operand image itself (each
+//   wave splits its slice into hi/lo halves, every wave reads all of it and multiplies by its own out tile of W^T).
+// Same packed planes, scales, column-sum and max|G| outputs as k_resblock_bwd_h; only the order of the additions inside a
+// row sum / statistic differs.  Requires in0 (and in1 for the concat blocks) exactly N wide.
+// Workgroup = 4 waves = one 128-wide tile or two 64-wide tiles.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned slice_rowmax(const f32x16& v) {
+    unsigned m = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned a = __float_as_uint(v[r]) & 0x7fffffffu;
+        m = m > a ? m : a;
+    }
+    const unsigned o = (unsigned)__shfl_xor((int)m, 32);
+    return m > o ? m : o;
+}
+// (mean, M2) of the 32 features of a slice per row
+__device__ __forceinline__ void slice_stats(const f32x16& v, int h, float& mean, float& m2) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += v[r];
+    mean = xhalf_sum(s) * (1.0f / 32);
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; q = fmaf(d, d, q); }
+    m2 = xhalf_sum(q);
+}
+__device__ __forceinline__ void rowscale_of(unsigned mbits, float& s, float& sinv) {
+    const int be = (int)(mbits >> 23);
+    int e = be == 0 ? 0 : 11 - (be - 127);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    s = __int_as_float((127 + e) << 23);
+    sinv = __int_as_float((127 - e) << 23);
+}
+__device__ __forceinline__ void slice_load(f32x16& v, const float* __restrict__ p) {
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        const float4 t = ld4(p + (size_t)G * 256);
+        v[4 * G] = t.x; v[4 * G + 1] = t.y; v[4 * G + 2] = t.z; v[4 * G + 3] = t.w;
+    }
+}
+__device__ __forceinline__ void slice_store(const f32x16& v, float* __restrict__ p) {
+#pragma unroll
+    for (int G = 0; G < 4; ++G) st4(p + (size_t)G * 256, make_float4(v[4 * G], v[4 * G + 1], v[4 * G + 2], v[4 * G + 3]));
+}
+__device__ __forceinline__ void slice_colsum(const f32x16& v, float* __restrict__ dst, int lane, int h) {
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = v[r];
+    colsum_store<16>(dst, 0, tile_colsum<16>(t, lane), lane, h);
+}
+// this wave's two k16-steps of the operand image: split(s * v)
+__device__ __forceinline__ void slice_publish(uint4* __restrict__ img, int w, int lane, const f32x16& v, float s) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float q[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) q[p] = s * v[8 * half + p];
+        h8 hi, lo;
+        split8(q, hi, lo);
+        coop_publish(img, 2 * w + half, lane, hi, lo);
+    }
+}
+// LayerNorm + SiLU backward, first pass, on a 32-feature slice: d <- du * gamma; column sums of du and du * xhat; the slice's
+// share of the two row sums.  gamma / beta point at the slice's first feature.
+__device__ __forceinline__ void slice_ln_bwd1(f32x16& d, const f32x16& x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              float mean, float rstd, int lane, int h, float* __restrict__ cs_beta, float* __restrict__ cs_gamma,
+                                              bool live, float& s1, float& s2) {
+    float db[16], dg[16];
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        const float4 gm = ld4(gamma + 8 * G + 4 * h), bt = ld4(beta + 8 * G + 4 * h);
+        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float xh = (x[4 * G + p] - mean) * rstd;
+            const float u = fmaf(xh, gmv[p], btv[p]);
+            const float du = d[4 * G + p] * silu_grad(u);
+            db[4 * G + p] = du;
+            dg[4 * G + p] = du * xh;
+            const float t = du * gmv[p];
+            d[4 * G + p] = t;
+            s1 += t;
+            s2 = fmaf(t, xh, s2);
+        }
+    }
+    const float cb = tile_colsum<16>(db, lane), cg = tile_colsum<16>(dg, lane);
+    if (live) { colsum_store<16>(cs_beta, 0, cb, lane, h); colsum_store<16>(cs_gamma, 0, cg, lane, h); }
+}
+__device__ __forceinline__ void slice_ln_bwd2(f32x16& d, const f32x16& x, float mean, float rstd, float s1, float s2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float xh = (x[r] - mean) * rstd;
+        d[r] = rstd * (d[r] - s1 - xh * s2);
+    }
+}
+
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH ah) {
+    constexpr int NG = N / 8, NT = N / 32, TPW = 4 / NT, KS = NG / 2, DT = SCLIN ? 2 : 1;
+    constexpr int NP = N, KP = DT * N;
+    constexpr int kSlotU4 = 1024 / TPW;
+    __shared__ uint4 img[1024];
+    __shared__ unsigned rmax[4 * 32];
+    __shared__ float2 rsum[4 * 32];
+    __shared__ float2 lnst[2 * 4 * 32];
+    const BlockBwdArgs& a = ah.b;
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = wave / NT, w = wave % NT;
+    const int tile_raw = blockIdx.x * TPW + slot;
+    const bool live = tile_raw < a.ntiles;            // idle slots of the last workgroup still meet the barriers
+    const int tile = live ? tile_raw : a.ntiles - 1;
+    uint4* const Bimg = img + slot * kSlotU4;
+    unsigned* const rm = rmax + slot * NT * 32;
+    float2* const rs = rsum + slot * NT * 32;
+    float2* const st2 = lnst + slot * NT * 32;
+    float2* const st1 = lnst + 128 + slot * NT * 32;
+    float* const csb = a.cs + (size_t)tile * a.cs_stride;
+    const size_t tS = ((size_t)tile * NG + 4 * w) * 256 + lane * 4;   // this wave's four groups of an N-wide tensor
+    const float inv_n = 1.0f / N;
+
+    // ---- every tensor this wave reads from HBM, requested up front
+    f32x16 g, x2, x1, xin[DT];
+    slice_load(g, a.gout_a + tS);
+    slice_load(x2, a.h2 + tS);
+    slice_load(x1, a.h1 + tS);
+    slice_load(xin[0], a.in0.data + tS);
+    if (SCLIN) slice_load(xin[DT - 1], a.in1.data + tS);
+    if (a.gout_b) {
+        f32x16 gb;
+        slice_load(gb, a.gout_b + tS);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] += gb[r];
+    }
+    // LN1 statistics from the producers' per-row (mean, M2), combined over the concat (Chan), as k_resblock_bwd_h
+    float mean1, rstd1, wtot;
+    {
+        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
+        float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
+        if (SCLIN) {
+            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
+            const float n1 = (float)a.in1.width, nt_ = n + n1;
+            const float dd = s1.x - mean;
+            m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
+            mean = mean + dd * (n1 / nt_);
+            n = nt_;
+        }
+        mean1 = mean; wtot = n;
+        rstd1 = rsqrtf(m2 / n + kLnEps);
+        if (w == 0 && h == 0 && live) reinterpret_cast<float2*>(a.rs1)[(size_t)tile * 32 + j] = make_float2(mean1, rstd1);
+    }
+    // weight scales (bind-time maxima)
+    const int e3 = SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3), e2 = scale_exp(*ah.m2), e1 = scale_exp(*ah.m1);
+    const float winv3 = __int_as_float((127 - e3) << 23), winv2 = __int_as_float((127 - e2) << 23), winv1 = __int_as_float((127 - e1) << 23);
+
+    // ---- dL/d(out): column sums, slice statistics of h2 / h1, row max
+    if (live) slice_colsum(g, csb + 32 * w, lane, h);
+    {
+        float m, q;
+        slice_stats(x2, h, m, q);
+        if (h == 0) st2[w * 32 + j] = make_float2(m, q);
+        slice_stats(x1, h, m, q);
+        if (h == 0) st1[w * 32 + j] = make_float2(m, q);
+        const unsigned mb = slice_rowmax(g);
+        if (h == 0) rm[w * 32 + j] = mb;
+    }
+    HFrag<1> wf[KS];
+    coop_load_w<KS>(wf, ah.W3Th + (size_t)w * KS * 128 + lane, KS);
+    __syncthreads();                                                     // B0
+
+    auto merged_rowmax = [&](int slot_g) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) { const unsigned v = rm[q * 32 + j]; m = m > v ? m : v; }
+        if (w == 0) {      // the same rows are the G operand of this block's weight gradients: the tile's maximum sets their scale
+            unsigned t = m;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { const unsigned u = (unsigned)__shfl_xor((int)t, o); t = t > u ? t : u; }
+            if (lane == 0 && live) ah.gmax_t[(size_t)slot_g * ah.gmax_ld + tile] = t;
+        }
+        return m;
+    };
+    float mean3, rstd3, mean2, rstd2;
+    {
+        float m2v;
+        coop_merge_stats<NT>(st2, j, mean3, m2v);
+        rstd3 = rsqrtf(m2v * inv_n + kLnEps);
+        coop_merge_stats<NT>(st1, j, mean2, m2v);
+        rstd2 = rsqrtf(m2v * inv_n + kLnEps);
+        if (w == 0 && h == 0 && live) {
+            reinterpret_cast<float2*>(a.rs3)[(size_t)tile * 32 + j] = make_float2(mean3, rstd3);
+            reinterpret_cast<float2*>(a.rs2)[(size_t)tile * 32 + j] = make_float2(mean2, rstd2);
+        }
+    }
+    float sg, sginv;
+    rowscale_of(merged_rowmax(ah.slot_out), sg, sginv);
+    slice_publish(Bimg, w, lane, g, sg);
+    __syncthreads();                                                     // C0
+
+    // ---- stage 3: d a3 = W3^T g (this wave's 32 features), LN3 / SiLU backward with h2
+    f32x16 d[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[0][r] = 0.f;
+    coop_mma<KS>(d, Bimg, wf, KS, lane);
+    coop_load_w<KS>(wf, ah.W2Th + (size_t)w * KS * 128 + lane, KS);      // next stage's planes: requested now, used after three barriers
+    {
+        const float post = sginv * winv3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[0][r] *= post;
+        float s1 = 0.f, s2 = 0.f;
+        slice_ln_bwd1(d[0], x2, a.gamma3 + 32 * w, a.beta3 + 32 * w, mean3, rstd3, lane, h, csb + 3 * NP + 32 * w, csb + 4 * NP + 32 * w, live, s1, s2);
+        s1 = xhalf_sum(s1); s2 = xhalf_sum(s2);
+        if (h == 0) rs[w * 32 + j] = make_float2(s1, s2);
+    }
+    __syncthreads();                                                     // A1
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) { const float2 v = rs[q * 32 + j]; s1 += v.x; s2 += v.y; }
+        slice_ln_bwd2(d[0], x2, mean3, rstd3, s1 * inv_n, s2 * inv_n);
+        if (live) { slice_store(d[0], a.dh2 + tS); slice_colsum(d[0], csb + NP + 32 * w, lane, h); }
+        const unsigned mb = slice_rowmax(d[0]);
+        if (h == 0) rm[w * 32 + j] = mb;
+    }
+    __syncthreads();                                                     // B1
+    float sd, sdinv;
+    rowscale_of(merged_rowmax(ah.slot_h2), sd, sdinv);
+    slice_publish(Bimg, w, lane, d[0], sd);
+    __syncthreads();                                                     // C1
+
+    // ---- stage 2: d a2 = W2^T dh2, LN2 / SiLU backward with h1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[0][r] = 0.f;
+    coop_mma<KS>(d, Bimg, wf, KS, lane);
+    coop_load_w<KS>(wf, ah.W1Th + (size_t)w * KS * 128 + lane, KS);      // stage 1, first out tile (the in0 slice)
+    {
+        const float post = sdinv * winv2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[0][r] *= post;
+        float s1 = 0.f, s2 = 0.f;
+        slice_ln_bwd1(d[0], x1, a.gamma2 + 32 * w, a.beta2 + 32 * w, mean2, rstd2, lane, h, csb + 5 * NP + 32 * w, csb + 6 * NP + 32 * w, live, s1, s2);
+        s1 = xhalf_sum(s1); s2 = xhalf_sum(s2);
+        if (h == 0) rs[w * 32 + j] = make_float2(s1, s2);
+    }
+    __syncthreads();                                                     // A2
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) { const float2 v = rs[q * 32 + j]; s1 += v.x; s2 += v.y; }
+        slice_ln_bwd2(d[0], x1, mean2, rstd2, s1 * inv_n, s2 * inv_n);
+        if (live) { slice_store(d[0], a.dh1 + tS); slice_colsum(d[0], csb + 2 * NP + 32 * w, lane, h); }
+        const unsigned mb = slice_rowmax(d[0]);
+        if (h == 0) rm[w * 32 + j] = mb;
+    }
+    __syncthreads();                                                     // B2
+    rowscale_of(merged_rowmax(ah.slot_h1), sd, sdinv);
+    slice_publish(Bimg, w, lane, d[0], sd);
+    __syncthreads();                                                     // C2
+
+    // ---- stage 1: d a1 = W1^T dh1 over the (concat) input: this wave's slice of in0 and, for an up block, of in1
+    f32x16 dx[DT][1];
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int T = t * NT + w;                                    // 32-feature out tile of dL/dx
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[t][0][r] = 0.f;
+            coop_mma<KS>(dx[t], Bimg, wf, KS, lane);
+            if (t + 1 < DT) coop_load_w<KS>(wf, ah.W1Th + (size_t)(T + NT) * KS * 128 + lane, KS);
+            else if (SCLIN) coop_load_w<KS>(wf, ah.WscTh + (size_t)w * KS * 128 + lane, KS);
+            const float post = sdinv * winv1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[t][0][r] *= post;
+            slice_ln_bwd1(dx[t][0], xin[t], a.gamma1 + 32 * T, a.beta1 + 32 * T, mean1, rstd1, lane, h, csb + 7 * NP + 32 * T,
+                          csb + 7 * NP + KP + 32 * T, live, s1, s2);
+        }
+        s1 = xhalf_sum(s1); s2 = xhalf_sum(s2);
+        if (h == 0) rs[w * 32 + j] = make_float2(s1, s2);
+    }
+    __syncthreads();                                                     // A3: sums published; every wave is done with the dh1 image
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) { const float2 v = rs[q * 32 + j]; s1 += v.x; s2 += v.y; }
+        const float iw = 1.0f / wtot;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) slice_ln_bwd2(dx[t][0], xin[t], mean1, rstd1, s1 * iw, s2 * iw);
+    }
+    // ---- shortcut: + Wsc^T g (Linear, the operand image of g once more) or + g (identity)
+    if (SCLIN) {
+        slice_publish(Bimg, w, lane, g, sg);
+        __syncthreads();                                                 // C3
+        const int e0 = scale_exp_lin3(*ah.m3, *ah.msc) + 4;
+        const float pre = sg * __int_as_float((127 + e0) << 23), post = sginv * __int_as_float((127 - e0) << 23);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[t][0][r] *= pre;
+            coop_mma<KS>(dx[t], Bimg, wf, KS, lane);
+            if (t + 1 < DT) coop_load_w<KS>(wf, ah.WscTh + (size_t)(NT + w) * KS * 128 + lane, KS);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[t][0][r] *= post;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[0][0][r] += g[r];
+    }
+    if (live) {
+        slice_store(dx[0][0], a.gin0 + tS);
+        if (SCLIN) slice_store(dx[DT - 1][0], a.gin1 + tS);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The narrow run of the backward pass in ONE launch (mirror of k_fused_narrow_h): a wave walks the run's operators in
 // reverse order for its row tile.  Every gradient tensor is still stored (it is the G operand of a weight gradient) and
 // the next operator reads it back from memory - written and read by the same wave, never read before it was written,
