@@ -319,7 +319,10 @@ struct BwdGemmF32 {
 };
 
 // SCLIN <=> the block has a concat input (up blocks): the stage-1 data gradient then spans 2*NG groups.
-template <int N, bool SCLIN, class Gemm>
+// HOIST (narrow blocks inside the fused backward run, one wave per tile and nothing else on the SIMD): every saved tensor the block
+// reads -- h2, h1, the forward input, dL/d(out) for the shortcut -- is requested at the top and kept in registers, instead of
+// a dependent memory round trip in front of each stage.
+template <int N, bool SCLIN, class Gemm, bool HOIST = false>
 __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const Gemm& gemm, int tile, int lane) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
     constexpr int KGT = SCLIN ? (2 * NG + 3) / 4 : NT;  // 32-feature output tiles of dL/dx
@@ -333,16 +336,43 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     float* const csb = a.cs + (size_t)tile * a.cs_stride;
 
     // ---- dL/d(out)
+    static_assert(!HOIST || (NT == 1 && KGT <= 2), "HOIST: narrow blocks only");
     f32x16 g[NT];
     acc_load<NG, NT>(g, a.gout_a + tN);
+    constexpr int HN = HOIST ? NT : 1, HK = HOIST ? KGT : 1;
+    f32x16 xh2[HN], xh1[HN], xin[HK], gk[HN];
+    if constexpr (HOIST) {
+        acc_load<NG, NT>(xh2, a.h2 + tN);
+        acc_load<NG, NT>(xh1, a.h1 + tN);
+#pragma unroll
+        for (int G = 0; G < KGT * 4; ++G) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (G < KG) {
+                const bool first = G < a.in0.groups;
+                const Seg& sg = first ? a.in0 : a.in1;
+                const int gl = first ? G : G - a.in0.groups;
+                v = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+            }
+            xin[G >> 2][4 * (G & 3)] = v.x; xin[G >> 2][4 * (G & 3) + 1] = v.y; xin[G >> 2][4 * (G & 3) + 2] = v.z; xin[G >> 2][4 * (G & 3) + 3] = v.w;
+        }
+    }
     if (a.gout_b) acc_load_add<NG, NT>(g, a.gout_b + tN);
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) gk[nt] = g[nt];
+    }
     acc_colsum_store<NG, NT>(g, csb, lane, h);
 
     // ---- stage 3: d a3 = W3^T g ; LN3/SiLU backward with h2
     f32x16 d[NT], x[NT];
     acc_zero<NT>(d);
     gemm.template run<NG, NT, NT>(d, g, 3, false);
-    acc_load<NG, NT>(x, a.h2 + tN);
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) x[nt] = xh2[nt];
+    } else {
+        acc_load<NG, NT>(x, a.h2 + tN);
+    }
     {
         float mean, m2;
         acc_stats<N, NT>(x, h, mean, m2);
@@ -357,7 +387,12 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     f32x16 (&d1)[NT] = g;  // reuse: g is re-read from memory for the shortcut
     acc_zero<NT>(d1);
     gemm.template run<NG, NT, NT>(d1, d, 2, false);
-    acc_load<NG, NT>(x, a.h1 + tN);
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) x[nt] = xh1[nt];
+    } else {
+        acc_load<NG, NT>(x, a.h1 + tN);
+    }
     {
         float mean, m2;
         acc_stats<N, NT>(x, h, mean, m2);
@@ -494,7 +529,9 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
                     const bool first = G < a.in0.groups;
                     const Seg& sg = first ? a.in0 : a.in1;
                     const int gl = first ? G : G - a.in0.groups;
-                    const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                    float4 xv;
+                    if constexpr (HOIST) xv = make_float4(xin[G >> 2][4 * (G & 3)], xin[G >> 2][4 * (G & 3) + 1], xin[G >> 2][4 * (G & 3) + 2], xin[G >> 2][4 * (G & 3) + 3]);
+                    else xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
                     const float4 gm = ld4(a.gamma1 + 8 * G + 4 * h), bt = ld4(a.beta1 + 8 * G + 4 * h);
                     const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
@@ -524,7 +561,9 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
                 const bool first = G < a.in0.groups;
                 const Seg& sg = first ? a.in0 : a.in1;
                 const int gl = first ? G : G - a.in0.groups;
-                const float4 xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
+                float4 xv;
+                if constexpr (HOIST) xv = make_float4(xin[G >> 2][4 * (G & 3)], xin[G >> 2][4 * (G & 3) + 1], xin[G >> 2][4 * (G & 3) + 2], xin[G >> 2][4 * (G & 3) + 3]);
+                else xv = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
                 const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -539,8 +578,13 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     // ---- shortcut: + Wsc^T g  (Linear) or + g (identity); g re-read from memory
     {
         f32x16 (&gg)[NT] = x;
-        acc_load<NG, NT>(gg, a.gout_a + tN);
-        if (a.gout_b) acc_load_add<NG, NT>(gg, a.gout_b + tN);
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) gg[nt] = gk[nt];
+        } else {
+            acc_load<NG, NT>(gg, a.gout_a + tN);
+            if (a.gout_b) acc_load_add<NG, NT>(gg, a.gout_b + tN);
+        }
         if (SCLIN) {
             gemm.template run<NG, NT, KGT>(dx, gg, 0, true);
         } else {

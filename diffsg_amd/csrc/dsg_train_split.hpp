@@ -711,17 +711,17 @@ __global__ __launch_bounds__(256, 2) void k_fused_narrow_bwd_h(const FusedBwdOpH
         if (op.kind == 0) {
             if (op.sclin) {
                 switch (op.N) {
-                    case 4: resblock_bwd_body<4, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
-                    case 8: resblock_bwd_body<8, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
-                    case 16: resblock_bwd_body<16, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
-                    default: resblock_bwd_body<32, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
+                    case 4: resblock_bwd_body<4, true, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
+                    case 8: resblock_bwd_body<8, true, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
+                    case 16: resblock_bwd_body<16, true, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
+                    default: resblock_bwd_body<32, true, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
                 }
             } else {
                 switch (op.N) {
-                    case 4: resblock_bwd_body<4, false>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
-                    case 8: resblock_bwd_body<8, false>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
-                    case 16: resblock_bwd_body<16, false>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
-                    default: resblock_bwd_body<32, false>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
+                    case 4: resblock_bwd_body<4, false, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
+                    case 8: resblock_bwd_body<8, false, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
+                    case 16: resblock_bwd_body<16, false, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
+                    default: resblock_bwd_body<32, false, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
                 }
             }
         } else {
