@@ -187,6 +187,14 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
         # gradient tensor (G operand) read once, float32
         blocks = [(128, 128, 0)] * 2 + [(64, 64, 0)] * 2 + [(32, 32, 0)] * 2 + [(16, 16, 0)] * 2 + [(8, 8, 0)] * 4 + \
                  [(8, 8, 8)] * 3 + [(16, 16, 16)] * 3 + [(32, 32, 32)] * 3 + [(64, 64, 64)] * 3 + [(128, 128, 128)] * 3
+        # From 1 024 row tiles on, the weight gradients of the last six residual blocks (3 x 128-wide, 3 x 64-wide up blocks) run as two
+        # early launches on a side stream beside the activation-gradient chain (dsg_train_step); the timed launch is the rest
+        early = 6 if (B + 31) // 32 >= 1024 else 0
+        if early:
+            blocks = blocks[:-early]
+            roof["kernel"] = ("k_wgrad_h, final launch: dW = G^T A of every Linear except the last six residual blocks' "
+                              "(those run on a side stream beside the activation-gradient chain) + the time-table one-hot GEMM")
+            roof["algorithmic_tflops"] = None
         per_row = 0
         for n, i0, i1 in blocks:
             per_row += 4 * ((i0 + i1) + 2 * n + 3 * n + 80)        # A: x, h1, h2, cond ; G: dh1, dh2, dout
