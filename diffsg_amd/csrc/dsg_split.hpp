@@ -200,12 +200,48 @@ __device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f3
 
 // Memory-fed stage over one fragment tensor (runtime k16-step loop, prefetch distance 1).  `groups` may be odd: the
 // missing group of the last step reads as zero (its packed weights are zero too).
-template <int NT, bool LNACT>
+// MAXS > 0 (narrow blocks: a segment has at most MAXS k16-steps): the step loop is unrolled, so the prefetched operands are
+// renamed instead of rotated through v_mov (52 copies per iteration of the runtime loop - a tenth of a narrow block's VALU).
+template <int NT, bool LNACT, int MAXS = 0>
 __device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float* __restrict__ xp, int groups, const uint4* __restrict__ wp,
                                                  size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float mean, float rstd, const HFrag<NT>* w0 = nullptr) {
     const int steps = (groups + 1) >> 1;
     if (steps <= 0) return;
+    if constexpr (MAXS > 0) {
+        if (steps > MAXS) __builtin_trap();             // a narrow block's segments are at most 32 features wide (plan builder)
+        const float c = rstd, d = -mean * rstd;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        HFrag<NT> w[MAXS];
+        float4 x0[MAXS], x1[MAXS], g0[MAXS], b0[MAXS], g1[MAXS], b1[MAXS];
+#pragma unroll
+        for (int S = 0; S < MAXS; ++S) {                   // every load of the segment first
+            x0[S] = z4; x1[S] = z4; g0[S] = z4; b0[S] = z4; g1[S] = z4; b1[S] = z4;
+            if (S < steps) {
+                if (S == 0 && w0) w[0] = *w0;
+                else load_hfrag<NT>(w[S], wp + (size_t)S * 128, nt_stride);
+                x0[S] = ld4(xp + (size_t)(2 * S) * 256);
+                if (2 * S + 1 < groups) x1[S] = ld4(xp + (size_t)(2 * S + 1) * 256);
+                if (LNACT) { g0[S] = ld4(gamma + 16 * S); b0[S] = ld4(beta + 16 * S); g1[S] = ld4(gamma + 16 * S + 8); b1[S] = ld4(beta + 16 * S + 8); }
+            }
+        }
+#pragma unroll
+        for (int S = 0; S < MAXS; ++S) {
+            if (S < steps) {
+                float v[8];
+                if (LNACT) {
+                    act8(v, x0[S], x1[S], c, d, g0[S], b0[S], g1[S], b1[S]);
+                } else {
+                    v[0] = kRawScale * x0[S].x; v[1] = kRawScale * x0[S].y; v[2] = kRawScale * x0[S].z; v[3] = kRawScale * x0[S].w;
+                    v[4] = kRawScale * x1[S].x; v[5] = kRawScale * x1[S].y; v[6] = kRawScale * x1[S].z; v[7] = kRawScale * x1[S].w;
+                }
+                h8 bhi, blo;
+                split8(v, bhi, blo);
+                mfma_step_h<NT>(acc, w[S], bhi, blo);
+            }
+        }
+        return;
+    }
     const float c = rstd, d = -mean * rstd;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     HFrag<NT> wn;
@@ -341,10 +377,10 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         if (XIN)    // in0 has the block's own width N here (down / middle: in = N; up: cat(N, N))
             chain_from_acc_h<N, NT, NT, true>(acc1, *xr, ah.W1h, gamma1, beta1, mean1, rstd1, lane, h, nt_stride, PRE ? &p1a : nullptr);
         else
-            chain_from_mem_h<NT, true>(acc1, a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
+            chain_from_mem_h<NT, true, (N <= 32 ? 2 : 0)>(acc1, a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
                                        gamma1 + 4 * h, beta1 + 4 * h, mean1, rstd1);
         if (a.in1.groups)
-            chain_from_mem_h<NT, true>(acc1, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
+            chain_from_mem_h<NT, true, (N <= 32 ? 2 : 0)>(acc1, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                        ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, gamma1 + 8 * a.in0.groups + 4 * h,
                                        beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr);
         int entry = 0;
@@ -404,10 +440,10 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         if (XIN)
             chain_raw_from_reg_h<NT>(acc3, *xr, a.in0.groups, ah.Wsch, nt_stride, lane, PRE ? &psa : nullptr);
         else
-            chain_from_mem_h<NT, false>(acc3, a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
+            chain_from_mem_h<NT, false, (N <= 32 ? 2 : 0)>(acc3, a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
                                         nullptr, nullptr, 0.f, 1.f);
         if (a.in1.groups)
-            chain_from_mem_h<NT, false>(acc3, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
+            chain_from_mem_h<NT, false, (N <= 32 ? 2 : 0)>(acc3, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                         ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f, PRE ? &psb : nullptr);
         acc_unscale_add<NT, NG>(acc3, inv3, a.c3, h);
     } else {
