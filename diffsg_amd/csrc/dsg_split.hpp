@@ -215,13 +215,12 @@ __device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float*
         HFrag<NT> w[MAXS];
         float4 x0[MAXS], x1[MAXS], g0[MAXS], b0[MAXS], g1[MAXS], b1[MAXS];
 #pragma unroll
-        for (int S = 0; S < MAXS; ++S) {                   // every load of the segment first
-            x0[S] = z4; x1[S] = z4; g0[S] = z4; b0[S] = z4; g1[S] = z4; b1[S] = z4;
+        for (int S = 0; S < MAXS; ++S) {                   // every load of the segment first (a step beyond `steps` is never read)
             if (S < steps) {
                 if (S == 0 && w0) w[0] = *w0;
                 else load_hfrag<NT>(w[S], wp + (size_t)S * 128, nt_stride);
                 x0[S] = ld4(xp + (size_t)(2 * S) * 256);
-                if (2 * S + 1 < groups) x1[S] = ld4(xp + (size_t)(2 * S + 1) * 256);
+                x1[S] = (2 * S + 1 < groups) ? ld4(xp + (size_t)(2 * S + 1) * 256) : z4;
                 if (LNACT) { g0[S] = ld4(gamma + 16 * S); b0[S] = ld4(beta + 16 * S); g1[S] = ld4(gamma + 16 * S + 8); b1[S] = ld4(beta + 16 * S + 8); }
             }
         }
