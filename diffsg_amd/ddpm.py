@@ -244,13 +244,13 @@ class DDPMCore(nn.Module):
 
     def _publish(self, grad_out, work):
         bucket = self._grad_bucket
-        work.mul_(grad_out.to(work.dtype))
+        g = grad_out.to(work.dtype)
         params = self.model.param_list()
         installed = params[0].grad is not None and params[-1].grad is not None and params[0].grad.data_ptr() == bucket.data_ptr()
         if installed:
-            bucket.add_(work)          # gradient accumulation across calls, as autograd would
+            bucket.addcmul_(work, g)   # gradient accumulation across calls, as autograd would: bucket += work * grad_out, one pass
         else:
-            bucket.copy_(work)
+            torch.mul(work, g, out=bucket)
             views = getattr(self, "_grad_views", None)
             if views is None or views[0] is not bucket or len(views[1]) != len(params):
                 off, vs = 0, []
