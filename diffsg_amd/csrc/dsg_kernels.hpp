@@ -204,6 +204,10 @@ __device__ __forceinline__ void chain_from_acc(f32x16 (&out)[NT], const f32x16 (
 }
 
 // A fragment-layout tensor in HBM.
+// hi / lo half planes of NT out tiles of one k16-step of a packed split-f16 weight matrix (dsg_split.hpp, dsg_train_split.hpp)
+template <int NT>
+struct HFrag { uint4 hi[NT], lo[NT]; };
+
 struct Seg {
     const float* data;   // [tiles][groups][64][4]
     const float* stats;  // [tiles*32][2] = (mean, M2) per row, may be null when unused

@@ -47,8 +47,6 @@ __device__ __forceinline__ int scale_exp_lin3(float m3, float msc) {
 
 #define DSG_MFMA_H(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (acc), 0, 0, 0)
 
-template <int NT>
-struct HFrag { uint4 hi[NT], lo[NT]; };
 
 // wp: packed planes of this k16-step for out tile 0, + lane; tile stride in uint4
 template <int NT>

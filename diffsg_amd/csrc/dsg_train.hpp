@@ -356,6 +356,15 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
             xin[G >> 2][4 * (G & 3)] = v.x; xin[G >> 2][4 * (G & 3) + 1] = v.y; xin[G >> 2][4 * (G & 3) + 2] = v.z; xin[G >> 2][4 * (G & 3) + 3] = v.w;
         }
     }
+    constexpr int KSB = (NG + 1) / 2;                 // k16-steps of the four transposed GEMMs (K = N)
+    HFrag<HN> w3p[HOIST ? KSB : 1], w2p[HOIST ? KSB : 1];
+    HFrag<HK> w1p[HOIST ? KSB : 1], wscp[HOIST ? KSB : 1];
+    if constexpr (HOIST) {
+        gemm.template preload<NG, NT>(w3p, 3);
+        gemm.template preload<NG, NT>(w2p, 2);
+        gemm.template preload<NG, KGT>(w1p, 1);
+        if (SCLIN) gemm.template preload<NG, KGT>(wscp, 0);
+    }
     if (a.gout_b) acc_load_add<NG, NT>(g, a.gout_b + tN);
     if constexpr (HOIST) {
 #pragma unroll
@@ -366,7 +375,8 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     // ---- stage 3: d a3 = W3^T g ; LN3/SiLU backward with h2
     f32x16 d[NT], x[NT];
     acc_zero<NT>(d);
-    gemm.template run<NG, NT, NT>(d, g, 3, false);
+    if constexpr (HOIST) gemm.template run<NG, NT, NT>(d, g, 3, false, 0, w3p);
+    else gemm.template run<NG, NT, NT>(d, g, 3, false);
     if constexpr (HOIST) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) x[nt] = xh2[nt];
@@ -386,7 +396,8 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     // ---- stage 2: d a2 = W2^T dh2 ; LN2/SiLU backward with h1
     f32x16 (&d1)[NT] = g;  // reuse: g is re-read from memory for the shortcut
     acc_zero<NT>(d1);
-    gemm.template run<NG, NT, NT>(d1, d, 2, false);
+    if constexpr (HOIST) gemm.template run<NG, NT, NT>(d1, d, 2, false, 0, w2p);
+    else gemm.template run<NG, NT, NT>(d1, d, 2, false);
     if constexpr (HOIST) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) x[nt] = xh1[nt];
@@ -511,7 +522,8 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     } else {
     f32x16 dx[KGT];
     acc_zero<KGT>(dx);
-    gemm.template run<NG, NT, KGT>(dx, d1, 1, false);
+    if constexpr (HOIST) gemm.template run<NG, NT, KGT>(dx, d1, 1, false, 0, w1p);
+    else gemm.template run<NG, NT, KGT>(dx, d1, 1, false);
     {
         // pass 1: du, t = du*gamma, row sums (x streamed from memory, group by group); column sums of du and du*xhat per
         // block of groups
@@ -586,7 +598,8 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
             if (a.gout_b) acc_load_add<NG, NT>(gg, a.gout_b + tN);
         }
         if (SCLIN) {
-            gemm.template run<NG, NT, KGT>(dx, gg, 0, true);
+            if constexpr (HOIST) gemm.template run<NG, NT, KGT>(dx, gg, 0, true, 0, wscp);
+            else gemm.template run<NG, NT, KGT>(dx, gg, 0, true);
         } else {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) dx[nt] += gg[nt];

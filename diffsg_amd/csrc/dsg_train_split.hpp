@@ -272,17 +272,23 @@ __device__ __forceinline__ void row_scale(const f32x16 (&g)[NT], float& s, float
 }
 
 // out[CH tiles] += planes x split(s * in): k over NG groups held in accumulator order, weight planes prefetched one step ahead
+// `pre` (narrow blocks of the fused run): the planes of ALL k16-steps, requested at the top of the block -- with one or two steps per
+// GEMM a prefetch distance of one step hides nothing, and four GEMMs per block each paid an L2 round trip (or two) of a lone wave
 template <int NG, int NTI, int CH>
 __device__ __forceinline__ void chain_scaled_chunk_h(f32x16* __restrict__ out, const f32x16 (&in)[NTI], const uint4* __restrict__ wp,
-                                                     size_t nt_stride, int lane, float s) {
+                                                     size_t nt_stride, int lane, float s, const HFrag<CH>* pre = nullptr) {
     constexpr int KS = (NG + 1) / 2;
     f32x16 (&o)[CH] = *reinterpret_cast<f32x16 (*)[CH]>(out);
     HFrag<CH> wn;
-    load_hfrag<CH>(wn, wp + lane, nt_stride);
+    if (pre) wn = pre[0];
+    else load_hfrag<CH>(wn, wp + lane, nt_stride);
 #pragma unroll
     for (int S = 0; S < KS; ++S) {
         HFrag<CH> wc = wn;
-        if (S + 1 < KS) load_hfrag<CH>(wn, wp + (size_t)(S + 1) * 128 + lane, nt_stride);
+        if (S + 1 < KS) {
+            if (pre) wn = pre[S + 1];
+            else load_hfrag<CH>(wn, wp + (size_t)(S + 1) * 128 + lane, nt_stride);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const int t = S >> 1, r0 = 8 * (S & 1);
         float v[8];
@@ -299,8 +305,17 @@ struct BwdGemmSplit {
     int lane;
     bool sclin;
     int tile;
+    // all planes of GEMM `which` (NTout <= 4 out tiles, KS steps) into registers
+    template <int NGin, int NTout>
+    __device__ __forceinline__ void preload(HFrag<NTout> (&w)[(NGin + 1) / 2], int which) const {
+        constexpr int KS = (NGin + 1) / 2;
+        const uint4* wp = which == 3 ? a.W3Th : (which == 2 ? a.W2Th : (which == 1 ? a.W1Th : a.WscTh));
+#pragma unroll
+        for (int S = 0; S < KS; ++S) load_hfrag<NTout>(w[S], wp + (size_t)S * 128 + lane, (size_t)KS * 128);
+    }
     template <int NGin, int NTin, int NTout>
-    __device__ __forceinline__ void run(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], int which, bool accumulate, int o0 = 0) const {
+    __device__ __forceinline__ void run(f32x16 (&out)[NTout], const f32x16 (&in)[NTin], int which, bool accumulate, int o0 = 0,
+                                        const HFrag<(NTout < 4 ? NTout : 4)>* pre = nullptr) const {
         constexpr int CH = NTout < 4 ? NTout : 4;
         constexpr int KS = (NGin + 1) / 2;
         const uint4* wp = (which == 3 ? a.W3Th : (which == 2 ? a.W2Th : (which == 1 ? a.W1Th : a.WscTh))) + (size_t)o0 * KS * 128;
@@ -330,7 +345,7 @@ struct BwdGemmSplit {
         }
 #pragma unroll
         for (int c0 = 0; c0 < NTout; c0 += CH)
-            chain_scaled_chunk_h<NGin, NTin, CH>(&out[c0], in, wp + (size_t)c0 * KS * 128, (size_t)KS * 128, lane, s);
+            chain_scaled_chunk_h<NGin, NTin, CH>(&out[c0], in, wp + (size_t)c0 * KS * 128, (size_t)KS * 128, lane, s, (NTout <= 4 && c0 == 0) ? pre : nullptr);
         const float post = sinv * winv;
 #pragma unroll
         for (int nt = 0; nt < NTout; ++nt)
