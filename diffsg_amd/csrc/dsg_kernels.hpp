@@ -47,7 +47,24 @@ __device__ __forceinline__ float fast_exp_neg(float v) {
 }
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + fast_exp_neg(v)); }
 
-__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+// v[lane] + v[lane ^ 32] in every lane.  gfx950's v_permlane32_swap exchanges the upper half of one register with the lower half of
+// another at VALU speed; the shuffle it replaces is a ds_bpermute through the LDS crossbar (~150 cycles behind an lgkmcnt wait, and
+// every LayerNorm statistic of every stage sits on it).  Same two addends in every lane: same bits.
+__device__ __forceinline__ unsigned xhalf_swap_lo(unsigned v, unsigned& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    hi = r[1];
+    return r[0];
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    unsigned hi;
+    const unsigned lo = xhalf_swap_lo(__float_as_uint(v), hi);
+    return __uint_as_float(lo) + __uint_as_float(hi);
+}
+__device__ __forceinline__ unsigned xhalf_max(unsigned m) {
+    unsigned hi;
+    const unsigned lo = xhalf_swap_lo(m, hi);
+    return lo > hi ? lo : hi;
+}
 
 #define DSG_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
 

@@ -261,8 +261,7 @@ __device__ __forceinline__ void row_scale(const f32x16 (&g)[NT], float& s, float
             const unsigned a = __float_as_uint(g[nt][r]) & 0x7fffffffu;
             m = m > a ? m : a;
         }
-    const unsigned o = (unsigned)__shfl_xor((int)m, 32);
-    m = m > o ? m : o;
+    m = xhalf_max(m);
     mbits = m;
     const int be = (int)(m >> 23);
     int e = be == 0 ? 0 : 11 - (be - 127);
@@ -396,8 +395,7 @@ __device__ __forceinline__ unsigned slice_rowmax(const f32x16& v) {
         const unsigned a = __float_as_uint(v[r]) & 0x7fffffffu;
         m = m > a ? m : a;
     }
-    const unsigned o = (unsigned)__shfl_xor((int)m, 32);
-    return m > o ? m : o;
+    return xhalf_max(m);
 }
 // (mean, M2) of the 32 features of a slice per row
 __device__ __forceinline__ void slice_stats(const f32x16& v, int h, float& mean, float& m2) {
