@@ -106,17 +106,47 @@ __global__ __launch_bounds__(256) void k_loss_final(const double* __restrict__ p
 // v[r], r < R (R a power of two <= 32), holds one value per row (lane & 31) for R different columns.  Afterwards lane l
 // returns the sum over the 32 lanes of its half of column l & (R - 1).  Butterfly: each level halves the registers -- the
 // lane keeps the half selected by one lane bit and adds its partner's copy of that half -- so the whole reduction costs
-// about 3R VALU instead of 5R shuffles.  xor 1, 2: DPP quad_perm; xor 4, 8, 16: ds_swizzle (crossbar only, no LDS memory).
+// about 3R VALU instead of 5R shuffles.
 // ---------------------------------------------------------------------------------------------
+// Everything at VALU speed (a lone wave waits ~100+ cycles on each ds_swizzle / ds_bpermute through the LDS crossbar, and a block's
+// backward has ~40 of them in dependent chains):  xor 1, 2: DPP quad_perm;  xor 4: row_half_mirror then quad reverse (7 - i, then
+// i ^ 3: together i ^ 4);  xor 8: row_ror 8;  xor 16 / 32: gfx950's v_permlane16_swap / v_permlane32_swap.
 template <int X>
-__device__ __forceinline__ float lane_xor(float v) {
-    if constexpr (X == 1) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
-    else if constexpr (X == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
-    else return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x1f | (X << 10)));
+__device__ __forceinline__ int lane_xor_i(int v) {
+    static_assert(X == 1 || X == 2 || X == 4 || X == 8, "lane_xor: DPP forms");
+    if constexpr (X == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);
+    else if constexpr (X == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);
+    else if constexpr (X == 4) return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true), 0x1B, 0xf, 0xf, true);
+    else return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);
+}
+template <int X>
+__device__ __forceinline__ float lane_xor(float v) { return __int_as_float(lane_xor_i<X>(__float_as_int(v))); }
+// max over the 32 lanes of each half-wave (every lane gets it)
+__device__ __forceinline__ unsigned half_wave_max(unsigned m) {
+    unsigned t;
+    t = (unsigned)lane_xor_i<1>((int)m); m = m > t ? m : t;
+    t = (unsigned)lane_xor_i<2>((int)m); m = m > t ? m : t;
+    t = (unsigned)lane_xor_i<4>((int)m); m = m > t ? m : t;
+    t = (unsigned)lane_xor_i<8>((int)m); m = m > t ? m : t;
+    const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
 }
 template <int CNT, int X>
 __device__ __forceinline__ void colsum_level(float* v, int lane) {
-    if constexpr (CNT >= 2) {
+    if constexpr (X == 16) {
+        // one swap does the whole level: odd 16-lane rows of `lo` trade places with even rows of `hi`, after which every lane holds
+        // its own kept half in one register and its partner's copy of that half in the other (same two addends as the select form)
+        if constexpr (CNT >= 2) {
+#pragma unroll
+            for (int i = 0; i < CNT / 2; ++i) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[2 * i]), __float_as_uint(v[2 * i + 1]), false, false);
+                v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+        } else {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[0]), false, false);
+            v[0] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+    } else if constexpr (CNT >= 2) {
         const bool b = lane & X;
 #pragma unroll
         for (int i = 0; i < CNT / 2; ++i) {

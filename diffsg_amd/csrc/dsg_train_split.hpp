@@ -327,11 +327,7 @@ struct BwdGemmSplit {
         unsigned m;
         row_scale<NTin>(in, s, sinv, m);
         if (which != 0) {       // the same rows are the G operand of this block's weight gradients: track the tensor maximum
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                const unsigned t = (unsigned)__shfl_xor((int)m, o);
-                m = m > t ? m : t;
-            }
+            m = half_wave_max(m);
             if (lane == 0) a.gmax_t[(size_t)(which == 3 ? a.slot_out : (which == 2 ? a.slot_h2 : a.slot_h1)) * a.gmax_ld + tile] = m;
         }
         const float winv = __int_as_float((127 - e) << 23), wsc = __int_as_float((127 + e) << 23);
@@ -557,9 +553,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
 #pragma unroll
         for (int q = 0; q < NT; ++q) { const unsigned v = rm[q * 32 + j]; m = m > v ? m : v; }
         if (w == 0) {      // the same rows are the G operand of this block's weight gradients: the tile's maximum sets their scale
-            unsigned t = m;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { const unsigned u = (unsigned)__shfl_xor((int)t, o); t = t > u ? t : u; }
+            const unsigned t = half_wave_max(m);
             if (lane == 0 && live) ah.gmax_t[(size_t)slot_g * ah.gmax_ld + tile] = t;
         }
         return m;
