@@ -290,6 +290,26 @@ __device__ __forceinline__ void acc_unscale_add(f32x16 (&acc)[NT], float inv, co
         }
 }
 
+// the same with the vector already in registers (requested at the top of a narrow block: dsg_split.hpp resblock_body_h, PRE)
+template <int NT, int NQ = NT * 4>
+__device__ __forceinline__ void acc_unscale_add_reg(f32x16 (&acc)[NT], float inv, const float4 (&b)[NT * 4]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (4 * nt + q >= NQ) continue;
+            const float4 v = b[4 * nt + q];
+            acc[nt][4 * q + 0] = fmaf(acc[nt][4 * q + 0], inv, v.x); acc[nt][4 * q + 1] = fmaf(acc[nt][4 * q + 1], inv, v.y);
+            acc[nt][4 * q + 2] = fmaf(acc[nt][4 * q + 2], inv, v.z); acc[nt][4 * q + 3] = fmaf(acc[nt][4 * q + 3], inv, v.w);
+        }
+}
+template <int NT, int NQ = NT * 4>
+__device__ __forceinline__ void load_vec4(float4 (&b)[NT * 4], const float* __restrict__ vec, int h) {
+#pragma unroll
+    for (int q = 0; q < NT * 4; ++q)
+        if (q < NQ) b[q] = ld4(vec + 8 * q + 4 * h);
+}
+
 struct BlockArgsH {
     BlockArgs b;             // tensors, biases, LayerNorm parameters, time table, cond_pre: as the f32 kernel
     const uint4* W1h;        // packed planes [NT][KS1][2][64], KS1 = ceil(g0/2) + ceil(g1/2)
@@ -313,7 +333,7 @@ constexpr int kLnLdsW1 = 272, kLnLdsN = 128;   // LDS copy of the LayerNorm vect
 template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN, bool PRE = false, bool LDSLN = false>
 __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane, f32x16 (*xr)[(N + 31) / 32] = nullptr,
                                                 float* xr_mean = nullptr, float* xr_m2 = nullptr, bool store_out = true,
-                                                const float* lnp = nullptr) {
+                                                const float* lnp = nullptr, int entry_pre = -1) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
     const BlockArgs& a = ah.b;
     const int h = lane >> 5, j = lane & 31;
@@ -348,8 +368,31 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     // Narrow run, small launches (PRE): a stage is one or two k16-steps, so the first step of every chain is an exposed L2
     // round trip unless its planes are requested before the previous stage's arithmetic: request all six of them now.  (Costs
     // ~40 VGPRs: the large-launch form of the narrow kernel keeps four waves per SIMD instead.)
+    // entry of the time table: the step index (sampling) or ts[row] (training) -- the same for every block of a run: the fused
+    // narrow kernel reads it once (entry_pre); otherwise two DEPENDENT round trips (index, then the row) sit behind stage 1
+    int entry = entry_pre;
+    if (entry < 0) {
+        entry = 0;
+        if (a.ts) {
+            int row = ptile * 32 + j;
+            row = row < a.nrows ? row : a.nrows - 1;
+            entry = a.ts[row];
+        } else if (a.step_ptr) {
+            entry = *a.step_ptr;
+        }
+    }
     HFrag<NT> p1a, p1b, p2, p3, psa, psb;
+    float4 vtb[NT * 4], vc2[NT * 4], vc3[NT * 4], vcp[NT * 4];
     if (PRE) {
+        // the per-feature vectors and the condition embedding as well: each was a round trip of its own right where it is added
+        load_vec4<NT, NG>(vtb, a.tbias + (size_t)entry * a.tb_stride, h);
+        load_vec4<NT, NG>(vc2, a.c2, h);
+        load_vec4<NT, NG>(vc3, a.c3, h);
+        if (tile >= a.uncond_tiles) {
+            const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
+#pragma unroll
+            for (int G = 0; G < NG; ++G) vcp[G] = ld4(cp + (size_t)G * 256);
+        }
         const size_t s1 = (size_t)KS1 * 128, s2 = (size_t)(((N + 7) / 8 + 1) / 2) * 128;
         load_hfrag<NT>(p1a, ah.W1h + lane, s1);
         if (a.in1.groups) load_hfrag<NT>(p1b, ah.W1h + (size_t)ks0 * 128 + lane, s1);
@@ -380,15 +423,8 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
             chain_from_mem_h<NT, true, (N <= 32 ? 2 : 0)>(acc1, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                        ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, gamma1 + 8 * a.in0.groups + 4 * h,
                                        beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr);
-        int entry = 0;
-        if (a.ts) {
-            int row = ptile * 32 + j;
-            row = row < a.nrows ? row : a.nrows - 1;
-            entry = a.ts[row];
-        } else if (a.step_ptr) {
-            entry = *a.step_ptr;
-        }
-        acc_unscale_add<NT, NG>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
+        if (PRE) acc_unscale_add_reg<NT, NG>(acc1, inv1, vtb);
+        else acc_unscale_add<NT, NG>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
     }
     if (a.save_h1) {
 #pragma unroll
@@ -405,13 +441,14 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         acc_stats<N, NT>(acc1, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
         chain_from_acc_h<N, NT, NT, true>(acc2, acc1, ah.W2h, gamma2, beta2, mean, rstd, lane, h, 0, PRE ? &p2 : nullptr);
-        acc_unscale_add<NT, NG>(acc2, inv2, a.c2, h);
+        if (PRE) acc_unscale_add_reg<NT, NG>(acc2, inv2, vc2);
+        else acc_unscale_add<NT, NG>(acc2, inv2, a.c2, h);
     }
     if (tile >= a.uncond_tiles) {
         const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
-            const float4 cv = ld4(cp + (size_t)G * 256);
+            const float4 cv = PRE ? vcp[G] : ld4(cp + (size_t)G * 256);
             acc2[G >> 2][4 * (G & 3) + 0] += cv.x; acc2[G >> 2][4 * (G & 3) + 1] += cv.y;
             acc2[G >> 2][4 * (G & 3) + 2] += cv.z; acc2[G >> 2][4 * (G & 3) + 3] += cv.w;
         }
@@ -442,9 +479,11 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         if (a.in1.groups)
             chain_from_mem_h<NT, false, (N <= 32 ? 2 : 0)>(acc3, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                         ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f, PRE ? &psb : nullptr);
-        acc_unscale_add<NT, NG>(acc3, inv3, a.c3, h);
+        if (PRE) acc_unscale_add_reg<NT, NG>(acc3, inv3, vc3);
+        else acc_unscale_add<NT, NG>(acc3, inv3, a.c3, h);
     } else {
-        acc_unscale_add<NT, NG>(acc3, inv3, a.c3, h);
+        if (PRE) acc_unscale_add_reg<NT, NG>(acc3, inv3, vc3);
+        else acc_unscale_add<NT, NG>(acc3, inv3, a.c3, h);
         if (XIN) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc3[nt] += (*xr)[nt];
@@ -1052,7 +1091,7 @@ __device__ __forceinline__ void linear_reg_h(const LinArgsH& ah, const int tile,
 }
 
 template <bool PRE>
-__global__ __launch_bounds__(256, PRE ? 3 : 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles) {
+__global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles) {
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (tile >= ntiles) return;
@@ -1060,8 +1099,20 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void k_fused_narrow_h(const Fused
     f32x16 x[1];
     float xmean = 0.f, xm2 = 0.f;
     bool have_x = false;
+    int entry = -1;                   // time-table entry of this wave's rows: read once, by the first block of the run
     for (int i = 0; i < nops; ++i) {
         const FusedOpH& op = ops[i];
+        if (entry < 0 && op.kind == 0) {
+            const BlockArgs& b0 = op.b.b;
+            entry = 0;
+            if (b0.ts) {
+                int row = (tile % b0.tiles_per_pass) * 32 + j;
+                row = row < b0.nrows ? row : b0.nrows - 1;
+                entry = b0.ts[row];
+            } else if (b0.step_ptr) {
+                entry = *b0.step_ptr;
+            }
+        }
         if (op.kind == 0) {
             if (!have_x) {  // first operator of the run: bring its (<= 32 wide) input into registers once
                 const Seg& s0 = op.b.b.in0;
@@ -1080,17 +1131,17 @@ __global__ __launch_bounds__(256, PRE ? 3 : 4) void k_fused_narrow_h(const Fused
             const bool st = op.store_out != 0;
             if (op.sclin) {
                 switch (op.N) {
-                    case 4: resblock_body_h<4, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    case 8: resblock_body_h<8, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    case 16: resblock_body_h<16, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    default: resblock_body_h<32, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 4: resblock_body_h<4, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 8: resblock_body_h<8, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 16: resblock_body_h<16, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    default: resblock_body_h<32, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                 }
             } else {
                 switch (op.N) {
-                    case 4: resblock_body_h<4, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    case 8: resblock_body_h<8, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    case 16: resblock_body_h<16, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
-                    default: resblock_body_h<32, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st); break;
+                    case 4: resblock_body_h<4, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 8: resblock_body_h<8, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 16: resblock_body_h<16, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    default: resblock_body_h<32, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                 }
             }
         } else if (!have_x || op.l.l.in_groups > 4) {
