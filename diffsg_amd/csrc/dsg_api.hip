@@ -2182,3 +2182,19 @@ int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* st
 }
 
 }  // extern "C"
+
+#ifdef DSG_CYCLE_STAMPS
+// measurement builds only (tools/cycle_stamps.sh): the stamps recorded since the last call, oldest first by slot
+extern "C" int dsg_stamps_fetch(unsigned long long* out, int n) {
+    int cnt = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(dsg::dsg_stamp_n), sizeof(int)) != hipSuccess) return -1;
+    if (cnt > 8192) cnt = 8192;
+    if (cnt > n) cnt = n;
+    if (cnt > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(dsg::dsg_stamp_buf), (size_t)cnt * sizeof(unsigned long long)) != hipSuccess) return -1;
+    const int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dsg::dsg_stamp_n), &zero, sizeof(int));
+    return cnt;
+}
+#endif
+

@@ -221,6 +221,25 @@ __device__ __forceinline__ void chain_from_acc(f32x16 (&out)[NT], const f32x16 (
 }
 
 // A fragment-layout tensor in HBM.
+// Cycle stamps for measurement builds (-DDSG_CYCLE_STAMPS, tools/cycle_stamps.sh): (cycle counter << 16 | tag) appended to a device array by
+// lane 0 of the selected wave; dsg_stamps_fetch (dsg_api.hip) reads and clears it.  Compiled out otherwise.
+#ifdef DSG_CYCLE_STAMPS
+__device__ unsigned long long dsg_stamp_buf[8192];
+__device__ int dsg_stamp_n;
+#define DSG_STAMP(cond, tag)                                                                      \
+    do {                                                                                          \
+        if (cond) {                                                                               \
+            const unsigned long long t_ = __builtin_readcyclecounter();                           \
+            if (lane == 0) {                                                                      \
+                const int k_ = atomicAdd(&dsg_stamp_n, 1);                                        \
+                if (k_ < 8192) dsg_stamp_buf[k_] = (t_ << 16) | (unsigned long long)(tag);        \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+#else
+#define DSG_STAMP(cond, tag) do {} while (0)
+#endif
+
 // hi / lo half planes of NT out tiles of one k16-step of a packed split-f16 weight matrix (dsg_split.hpp, dsg_train_split.hpp)
 template <int NT>
 struct HFrag { uint4 hi[NT], lo[NT]; };

@@ -348,6 +348,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     const int ptile = tile % a.tiles_per_pass;
     const int ks0 = (a.in0.groups + 1) >> 1, ks1 = (a.in1.groups + 1) >> 1, KS1 = ks0 + ks1;
 
+    DSG_STAMP(XIN && tile == 0, 0x11);
     // ---- LN1 statistics (Chan merge of the producers' (mean, M2))
     float mean1, rstd1;
     {
@@ -404,6 +405,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         }
     }
 
+    DSG_STAMP(XIN && tile == 0, 0x12);
     // ---- stage 1
     f32x16 acc1[NT];
     if (!XIN) {
@@ -423,9 +425,11 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
             chain_from_mem_h<NT, true, (N <= 32 ? 2 : 0)>(acc1, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                        ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, gamma1 + 8 * a.in0.groups + 4 * h,
                                        beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr);
+        DSG_STAMP(XIN && tile == 0, 0x13);
         if (PRE) acc_unscale_add_reg<NT, NG>(acc1, inv1, vtb);
         else acc_unscale_add<NT, NG>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
     }
+    DSG_STAMP(XIN && tile == 0, 0x14);
     if (a.save_h1) {
 #pragma unroll
         for (int G = 0; G < NG; ++G)
@@ -441,6 +445,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         acc_stats<N, NT>(acc1, h, mean, m2);
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
         chain_from_acc_h<N, NT, NT, true>(acc2, acc1, ah.W2h, gamma2, beta2, mean, rstd, lane, h, 0, PRE ? &p2 : nullptr);
+        DSG_STAMP(XIN && tile == 0, 0x15);
         if (PRE) acc_unscale_add_reg<NT, NG>(acc2, inv2, vc2);
         else acc_unscale_add<NT, NG>(acc2, inv2, a.c2, h);
     }
@@ -461,6 +466,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
                             acc2[G >> 2][4 * (G & 3) + 3]));
     }
 
+    DSG_STAMP(XIN && tile == 0, 0x16);
     // ---- stage 3 (+ shortcut in the same scaled accumulator)
     f32x16 (&acc3)[NT] = acc1;
     {
@@ -469,6 +475,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
         chain_from_acc_h<N, NT, NT, true>(acc3, acc2, ah.W3h, gamma3, beta3, mean, rstd, lane, h, 0, PRE ? &p3 : nullptr);
     }
+    DSG_STAMP(XIN && tile == 0, 0x17);
     if (SCLIN) {
         const size_t nt_stride = (size_t)KS1 * 128;
         if (XIN)
@@ -498,6 +505,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         }
     }
 
+    DSG_STAMP(XIN && tile == 0, 0x18);
     // ---- statistics + store (XREG: hand the tensor on in registers; store only if something else reads it)
     {
         float mean, m2;
@@ -507,6 +515,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
             for (int nt = 0; nt < NT; ++nt) (*xr)[nt] = acc3[nt];
             *xr_mean = mean; *xr_m2 = m2;
         }
+        DSG_STAMP(XIN && tile == 0, 0x19);
         if (!XOUT || store_out) {
             if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
 #pragma unroll

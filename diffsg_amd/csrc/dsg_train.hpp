@@ -364,6 +364,7 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     //   [dout | dh2 | dh1 | beta3 | gamma3 | beta2 | gamma2] x NP, then [beta1 | gamma1] x KP
     constexpr int NP = NT * 32, KP = KGT * 32;
     float* const csb = a.cs + (size_t)tile * a.cs_stride;
+    DSG_STAMP(HOIST && tile == 0, 0x21);
 
     // ---- dL/d(out)
     static_assert(!HOIST || (NT == 1 && KGT <= 2), "HOIST: narrow blocks only");
@@ -401,12 +402,14 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
         for (int nt = 0; nt < NT; ++nt) gk[nt] = g[nt];
     }
     acc_colsum_store<NG, NT>(g, csb, lane, h);
+    DSG_STAMP(HOIST && tile == 0, 0x22);
 
     // ---- stage 3: d a3 = W3^T g ; LN3/SiLU backward with h2
     f32x16 d[NT], x[NT];
     acc_zero<NT>(d);
     if constexpr (HOIST) gemm.template run<NG, NT, NT>(d, g, 3, false, 0, w3p);
     else gemm.template run<NG, NT, NT>(d, g, 3, false);
+    DSG_STAMP(HOIST && tile == 0, 0x23);
     if constexpr (HOIST) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) x[nt] = xh2[nt];
@@ -421,6 +424,7 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
         ln_silu_bwd_acc<NG, NT>(d, x, a.gamma3, a.beta3, mean, rstd, N, h, lane, csb + 3 * NP, csb + 4 * NP);
     }
     acc_store<NG, NT>(d, a.dh2 + tN);
+    DSG_STAMP(HOIST && tile == 0, 0x24);
     acc_colsum_store<NG, NT>(d, csb + NP, lane, h);
 
     // ---- stage 2: d a2 = W2^T dh2 ; LN2/SiLU backward with h1
@@ -428,6 +432,7 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     acc_zero<NT>(d1);
     if constexpr (HOIST) gemm.template run<NG, NT, NT>(d1, d, 2, false, 0, w2p);
     else gemm.template run<NG, NT, NT>(d1, d, 2, false);
+    DSG_STAMP(HOIST && tile == 0, 0x25);
     if constexpr (HOIST) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) x[nt] = xh1[nt];
@@ -442,6 +447,7 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
         ln_silu_bwd_acc<NG, NT>(d1, x, a.gamma2, a.beta2, mean, rstd, N, h, lane, csb + 5 * NP, csb + 6 * NP);
     }
     acc_store<NG, NT>(d1, a.dh1 + tN);
+    DSG_STAMP(HOIST && tile == 0, 0x26);
     acc_colsum_store<NG, NT>(d1, csb + 2 * NP, lane, h);
 
     // ---- stage 1: d a1 = W1^T dh1 over the concat width; LN1/SiLU backward with x = cat(in0, in1)
@@ -554,6 +560,7 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
     acc_zero<KGT>(dx);
     if constexpr (HOIST) gemm.template run<NG, NT, KGT>(dx, d1, 1, false, 0, w1p);
     else gemm.template run<NG, NT, KGT>(dx, d1, 1, false);
+    DSG_STAMP(HOIST && tile == 0, 0x27);
     {
         // pass 1: du, t = du*gamma, row sums (x streamed from memory, group by group); column sums of du and du*xhat per
         // block of groups
@@ -617,6 +624,7 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
             }
         }
     }
+    DSG_STAMP(HOIST && tile == 0, 0x28);
     // ---- shortcut: + Wsc^T g  (Linear) or + g (identity); g re-read from memory
     {
         f32x16 (&gg)[NT] = x;
@@ -635,6 +643,7 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
             for (int nt = 0; nt < NT; ++nt) dx[nt] += gg[nt];
         }
     }
+    DSG_STAMP(HOIST && tile == 0, 0x29);
     // ---- scatter dL/dx to the two input gradients
 #pragma unroll
     for (int G = 0; G < KGT * 4; ++G) {

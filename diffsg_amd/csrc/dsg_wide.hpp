@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     const int last_tile = blockIdx.x * 4 + 3 < a.ntiles ? blockIdx.x * 4 + 3 : a.ntiles - 1;
     const bool wg_cond = last_tile >= a.uncond_tiles, my_cond = tile >= a.uncond_tiles;
     constexpr float kL2 = -1.44269504088896341f;
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x31);
 
     // ---- per-feature vectors -> LDS (LayerNorm vectors times -log2 e)
     {
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
             if (EPI != 0) biasLv[i] = i < NTO * 32 ? A.l.l.bias[i] : 0.f;
         }
     }
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x32);
     // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as resblock_body_h
     float mean1, rstd1;
     {
@@ -326,13 +328,16 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     r.rd = lds + lane; r.gc = 0; r.pi = 0; r.total = p.cF; r.dbg = A.dbg & DSG_WIDE_DBG_ENABLE;
     r.lds_w = lds0 + (unsigned)wave * 2048u;
     r.lane16 = (unsigned long long)lane * 16ull;
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x33);
     {   // this wave's chunk-source table: one chunk per lane
         unsigned long long* tab = tab_all + wave * kWideMaxChunks;
         for (int c = lane; c < kWideMaxChunks; c += 64)
             tab[c] = reinterpret_cast<unsigned long long>(p.source(c < p.cF ? c : p.cF - 1));
         r.tab = tab;
     }
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x34);
     __syncthreads();                                        // the staged vectors and tables are visible; no DMA is in flight yet
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x35);
 #pragma unroll
     for (int i = 0; i < kRingDist; ++i) ring_issue(r, r.tab[i]);
     r.nsrc[0] = r.tab[kRingDist]; r.nsrc[1] = r.tab[kRingDist + 1];
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     // ---- stage 1
     f32x16 acc1[NT];
     wide_stage_mem<true, true>(acc1, KS1, r, wave, g1v, b1v, mean1, rstd1, h);
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x36);
     if (a.ts) acc_unscale_add<NT>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
     else acc_unscale_add_lds<NT>(acc1, inv1, tbv, h);
     if (a.save_h1 && live) {
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
         wide_stage_reg(acc2, acc1, r, g2v, b2v, mean, rsqrtf(m2 * (1.0f / N) + kLnEps), h);
         acc_unscale_add_lds<NT>(acc2, inv2, c2v, h);
     }
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x37);
     if (wg_cond) wide_add_private(acc2, r, wave, my_cond);
     if (a.save_h2 && live) {
 #pragma unroll
@@ -365,6 +372,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
                 make_float4(acc2[G >> 2][4 * (G & 3)], acc2[G >> 2][4 * (G & 3) + 1], acc2[G >> 2][4 * (G & 3) + 2], acc2[G >> 2][4 * (G & 3) + 3]));
     }
 
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x38);
     // ---- stage 3 (+ shortcut in the same scaled accumulator)
     f32x16 (&acc3)[NT] = acc1;
     {
@@ -372,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
         acc_stats<N, NT>(acc2, h, mean, m2);
         wide_stage_reg(acc3, acc2, r, g3v, b3v, mean, rsqrtf(m2 * (1.0f / N) + kLnEps), h);
     }
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x39);
     if (SCLIN) {
         wide_stage_mem<false, false>(acc3, KS1, r, wave, nullptr, nullptr, 0.f, 1.f, h);
         acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
@@ -380,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
         wide_add_private(acc3, r, wave, true);
     }
 
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x3a);
     // ---- statistics + store
     float xmean, xm2;
     acc_stats<N, NT>(acc3, h, xmean, xm2);
@@ -390,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
             st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
                 make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2], acc3[G >> 2][4 * (G & 3) + 3]));
     }
+    DSG_STAMP(SCLIN && EPI == 0 && wave == 0 && blockIdx.x == 0, 0x3b);
     if (EPI == 0) return;
     if (EPI == 1) range_check(a.range_flag, xmean, xm2);
 
