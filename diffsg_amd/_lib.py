@@ -23,14 +23,18 @@ def _headers():
 _ID_MARK = b"DSG_BUILD_ID="
 
 
-def source_id() -> str:
-    """sha256 over the sources the library is built from (file names + contents): compiled into the library as its build id."""
+def source_id(extra_flags: str = "") -> str:
+    """sha256 over the sources the library is built from (file names + contents) and any extra compiler flags: compiled into
+    the library as its build id.  A measurement binary (DSG_EXTRA_CXXFLAGS=-DDSG_CYCLE_STAMPS ...) therefore never carries the
+    id of the production build of the same tree: `_stale()` compares with the flag-less id and rebuilds over it."""
     import hashlib
     h = hashlib.sha256()
     for p in SOURCES + _headers():
         h.update(os.path.basename(p).encode() + b"\0")
         with open(p, "rb") as f:
             h.update(f.read())
+    if extra_flags.split():
+        h.update(b"flags\0" + " ".join(extra_flags.split()).encode())
     return h.hexdigest()
 
 
@@ -54,7 +58,7 @@ class UNetDesc(ctypes.Structure):
 def _stale() -> bool:
     """The library is missing, or was built from other sources than the ones in the tree (content hash, not mtimes: the
     binary travels to the GPU box as a file copy)."""
-    return built_id() != source_id()
+    return built_id() != source_id(os.environ.get("DSG_EXTRA_CXXFLAGS", ""))   # a process without the flags refuses a measurement build
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -72,8 +76,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             # -fno-slp-vectorize: with the SLP vectoriser on, the packed-f32 code it forms in k_wgrad_h gave run-to-run
             # different results on gfx950 ("Build flags"); without it the library is deterministic and 2-5 % faster.
             tmp = LIB_PATH + f".{os.getpid()}.tmp"
+            extra = os.environ.get("DSG_EXTRA_CXXFLAGS", "")
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-fno-slp-vectorize",
-                   f'-DDSG_BUILD_ID_STR="{source_id()}"', "-o", tmp] + os.environ.get("DSG_EXTRA_CXXFLAGS", "").split() + SOURCES
+                   f'-DDSG_BUILD_ID_STR="{source_id(extra)}"', "-o", tmp] + extra.split() + SOURCES
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)

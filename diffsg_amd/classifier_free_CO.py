@@ -210,11 +210,12 @@ def validate_ddpm_co(epochs=500, T=500, use_ema=False, warmup_epoch=5, batch_siz
     device, rank, world = dp_context()      # one process per GPU when launched under torch.distributed.run; else cuda:0
     loader = make_loader(dataset, batch_size, rank, world)
     node_num = Y_train.shape[1]
-    device = _device()
+    if device is None:
+        device = _device()
     diffusion_model = _validation_model(node_num, custom_config['sfn'] * node_num, device, T, custom_config, 0.0)
     diffusion_model.apply(init_weights)
     diffusion_model.to(device)
-    from .train import FlatAdam, run_epochs
+    sync_replicas(diffusion_model)          # every replica starts from rank 0's draw (as train_ddpm_co)
     optimizer = FlatAdam(diffusion_model, lr=lr)
     scheduler = optim.lr_scheduler.MultiStepLR(optimizer, list(milestones))
     run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log)

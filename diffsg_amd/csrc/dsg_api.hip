@@ -668,7 +668,6 @@ void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStr
         BlockLinArgsH w;
         memset(&w, 0, sizeof w);
         w.b = a; w.store_block_out = 1;
-        if (const char* e = getenv("DSG_WIDE_DBG")) w.dbg = atoi(e);   // measurement only (dsg_wide.hpp)
         const dim3 grid(cdiv(a.b.ntiles, 4)), block(256);
         if (r.sclin) hipLaunchKernelGGL((k_wide128_h<true, 0, 1>), grid, block, 0, s, w);
         else hipLaunchKernelGGL((k_wide128_h<false, 0, 1>), grid, block, 0, s, w);
@@ -1377,7 +1376,6 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         }
         h->fuse_lo = best_lo; h->fuse_hi = best_hi;
     }
-    if (const char* e = getenv("DSG_PRECISION")) h->use_split = strcmp(e, "f32") != 0;
     bool ok = hipMalloc(&h->ce_dev, (h->res.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
               hipMalloc(&h->fusedh_dev, (h->ops.size() + 1) * sizeof(FusedOpH)) == hipSuccess &&
               hipMalloc(&h->maxabs, (h->params.size() + 1) * sizeof(float)) == hipSuccess &&
@@ -1606,6 +1604,10 @@ int dsg_set_precision(dsg_handle* h, int mode) {
 int dsg_set_renorm_hook(dsg_handle* h, double* stats3, void (*reduce)(void*), void* user) {
     if (!h) return fail("null handle");
     if (reduce && !stats3) return fail("dsg_set_renorm_hook: a reduce function needs the 3-double device buffer");
+    // the cached step graphs never contain the hook branch (enqueue_step, use_hook), but drop them anyway so that nothing captured
+    // under another hook state can be replayed
+    (void)hipDeviceSynchronize();
+    free_graphs(h);
     h->renorm_stats = stats3; h->renorm_fn = reduce; h->renorm_user = user;
     return 0;
 }
@@ -1646,15 +1648,21 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
     const int tpp = cdiv(B, 32), CG = groups_of(h->d.cond_dim);
     hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tpp * CG * 256, 256)), dim3(256), 0, s, cond, cond_mask, B, h->d.cond_dim, CG,
                        h->condfrag, tpp);
-    RunCtx c{B, 1, 0, x, out, nullptr, h->ts_ident, false, false};
+    // the handle's precision mode applies here as in dsg_sample / dsg_train_step: the split kernels take the condition embedding
+    // Wc silu(cond * mask) precomputed (a masked row contributes exactly 0), the exact-f32 kernels compute it in the block
+    if (h->use_split) run_cond_embed(h, B, s);
+    RunCtx c{B, 1, 0, x, out, nullptr, h->ts_ident, false, h->use_split};
     if (prepare_fused(h, c, s)) return 1;
     run_unet(h, c, s);
     HIPCK(hipGetLastError());
     return 0;
 }
 
+// use_hook: take the renorm hook's host callback on this step.  Never while capturing: the callback enqueues a real collective
+// (a rank whose graphs are already cached would not issue it: the all-reduces would pair up wrongly or hang) and the caller's
+// `renorm_stats` pointer would be baked into the cached graph and outlive the hook.
 static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, bool renorm, hipStream_t s,
-                        hipEvent_t* ev = nullptr) {
+                        hipEvent_t* ev = nullptr, bool use_hook = true) {
     if (ev) {  // DSG_SAMPLE_PROFILE: one event pair per operator launch
         const bool fuse = h->fuse_hi - h->fuse_lo >= 2;
         bool skip_next = false;
@@ -1675,7 +1683,7 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
     UpdateArgs ua = u;
     ua.record_y = renorm ? 0 : 1;
     hipLaunchKernelGGL(k_update, dim3(ublocks), dim3(256), 0, s, ua);
-    if (renorm && h->renorm_fn) {
+    if (renorm && h->renorm_fn && use_hook) {
         // sharded call that standardises with the statistics of the WHOLE batch (MSR.py:136-137 on the concatenation of all
         // ranks' rows): local moments -> the caller's all-reduce of 3 doubles (enqueued on this stream) -> apply
         hipLaunchKernelGGL(k_renorm_moments, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
@@ -1762,7 +1770,7 @@ int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const flo
             for (int variant = 0; variant < 2; ++variant) {  // 0: with renorm, 1: without
                 hipGraph_t g = nullptr;
                 HIPCK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-                const int rc = enqueue_step(h, c, u, variant == 0, h->cap_stream);
+                const int rc = enqueue_step(h, c, u, variant == 0, h->cap_stream, nullptr, /*use_hook=*/false);
                 hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
                 if (rc) return 1;
                 if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));

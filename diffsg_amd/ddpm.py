@@ -225,8 +225,11 @@ class DDPMCore(nn.Module):
         loss = torch.empty((), device=dev, dtype=torch.float32)
         call = self._draw_calls
         self._draw_calls += 1
+        # data parallel: every rank must draw DIFFERENT ts / noise / mask for its rows (dp_context only de-correlates torch's
+        # generator): the rank is folded into the Philox key, rank 0 keeps the plain seed
+        seed = (int(self.device_draws) ^ (_dp_rank() * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
         with torch.cuda.device(dev):
-            _lib.check(L.dsg_train_step_seeded(hd, _lib.ptr(y32), _lib.ptr(c32), int(self.device_draws) & (2 ** 64 - 1), call,
+            _lib.check(L.dsg_train_step_seeded(hd, _lib.ptr(y32), _lib.ptr(c32), seed, call,
                                                float(1.0 - self.uncond_prob), _lib.ptr(self.sqrt_alphas_cumprod),
                                                _lib.ptr(self.sqrt_one_minus_alphas_cumprod), self.T, _lib.ptr(work), _lib.ptr(loss), B,
                                                _lib.stream_ptr()))
@@ -269,8 +272,16 @@ class DDPMCore(nn.Module):
         """Data parallel: ONE all-reduce of the flat bucket, mean over ranks (mse_loss is a mean over local rows)."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self.grad_bucket is not None:
-            dist.all_reduce(self._grad_bucket, op=dist.ReduceOp.SUM)
-            self._grad_bucket.div_(dist.get_world_size())
+            if dist.get_backend() == "nccl":       # RCCL averages inside the collective: no second pass over the bucket
+                dist.all_reduce(self._grad_bucket, op=dist.ReduceOp.AVG)
+            else:                                   # gloo has no AVG
+                dist.all_reduce(self._grad_bucket, op=dist.ReduceOp.SUM)
+                self._grad_bucket.div_(dist.get_world_size())
+
+
+def _dp_rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 class _PublishGrads(torch.autograd.Function):

@@ -33,12 +33,34 @@ class global_renorm:
         from . import _lib
         self.ddpm, self._lib = ddpm, _lib
         self.reduce = reduce if reduce is not None else (lambda t: dist.all_reduce(t))
+        self.error = None
+
+    def _callback(self, _user):
+        # ctypes swallows an exception raised inside a callback: the rank would silently standardise with its local moments
+        # while the others wait in the collective.  Keep it and re-raise once the library call has returned (`check`).
+        try:
+            self.reduce(self.stats)
+        except BaseException as e:  # noqa: BLE001 - re-raised in check()
+            if self.error is None:
+                self.error = e
+
+    def check(self):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise RuntimeError("global_renorm: the moment reduction failed inside dsg_sample") from e
+
+    def contribute_nothing(self):
+        """A rank whose shard is empty launches nothing, but the other ranks wait in the renorm all-reduces: issue the same
+        number of reductions (min(T, 4), MSR.py:136) with zero moments."""
+        for _ in range(min(self.ddpm.T, 4)):
+            self.stats.zero_()
+            self.reduce(self.stats)
 
     def __enter__(self):
         import ctypes
         dev = next(self.ddpm.model.parameters()).device
         self.stats = torch.zeros(3, device=dev, dtype=torch.float64)
-        self.cb = self._lib.RENORM_REDUCE_FN(lambda _user: self.reduce(self.stats))
+        self.cb = self._lib.RENORM_REDUCE_FN(self._callback)
         hd = self.ddpm.model.native_handle()
         self._lib.check(self._lib.lib().dsg_set_renorm_hook(hd, self._lib.ptr(self.stats), ctypes.cast(self.cb, ctypes.c_void_p), None))
         return self
@@ -46,6 +68,8 @@ class global_renorm:
     def __exit__(self, *exc):
         torch.cuda.synchronize()          # the hook's buffer and callback must outlive the enqueued steps
         self._lib.check(self._lib.lib().dsg_set_renorm_hook(self.ddpm.model.native_handle(), None, None, None))
+        if exc[0] is None:
+            self.check()
         return False
 
 
@@ -57,8 +81,11 @@ def sample_sharded(ddpm, cond_all, omega=1.0, gather=False, global_renorm_stats=
     rank, ws = world()
     lo, hi = shard_rows(cond_all.shape[0], rank, ws)
     if global_renorm_stats and ws > 1:
-        with global_renorm(ddpm):
+        with global_renorm(ddpm) as gr:
             y = ddpm.sample(cond_all[lo:hi], omega, **kw)
+            if hi == lo:
+                gr.contribute_nothing()
+            gr.check()
     else:
         y = ddpm.sample(cond_all[lo:hi], omega, **kw)
     if not gather or ws == 1:

@@ -47,12 +47,12 @@ long long dsg_param_numel(const dsg_handle* h, int i);
 long long dsg_param_total(const dsg_handle* h);   /* sum of numel = length of the flat gradient bucket */
 int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* stream);
 
-/* Arithmetic of the wide (>= 64) ResidualBlocks inside dsg_sample:
+/* Arithmetic of every GEMM of the denoiser:
  *   DSG_PRECISION_SPLIT_F16 (default)  float32-accurate GEMMs as hi/lo fp16 splits on the f16 matrix cores, f32 accumulate
  *                                      (22 significant bits per operand);
- *   DSG_PRECISION_F32_MFMA             exact float32 v_mfma_f32_32x32x2_f32 (also selected by env DSG_PRECISION=f32).
- * The mode applies to dsg_sample and to dsg_train_step (forward, data gradients and weight gradients); dsg_unet_forward
- * always uses the exact float32 kernels. */
+ *   DSG_PRECISION_F32_MFMA             exact float32 v_mfma_f32_32x32x2_f32.
+ * The mode is per handle (no environment override) and applies to dsg_unet_forward, dsg_sample and dsg_train_step (forward,
+ * data gradients and weight gradients). */
 #define DSG_PRECISION_SPLIT_F16 0
 #define DSG_PRECISION_F32_MFMA 1
 int dsg_set_precision(dsg_handle* h, int mode);

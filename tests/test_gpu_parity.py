@@ -232,6 +232,50 @@ def test_sample_nu_checkpoint_known_answer(gold, policy):
     assert abs(ratio - 0.91359) < 2e-3, ratio
 
 
+@pytest.mark.parametrize("policy", POLICIES)
+def test_nu_known_answer_through_the_product_evaluators(gold, policy):
+    """The whole product path to the known answer, no oracle function in the scoring: NU checkpoint rows -> DDPM.sample
+    (omega = 500, classifier_free_NU.py:306-361) -> decode.nu_decode -> decode.nu_rate on the device -> less ratio
+    0.91359 +- 2e-3."""
+    from diffsg_amd import decode
+    g = gold("g4_sample_nu_ckpt.npz")
+    p = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    ddpm = make_ddpm("nu3", p, int(g["T"]), policy)
+    cond = torch.from_numpy(g["cond"]).cuda()
+    y0 = ddpm.sample_checked(cond, 500.0, y_T=torch.from_numpy(g["y_T"]), noise=torch.from_numpy(g["z"]))
+    P = float(g["P_sum"])
+    Xs = cond.clone(); Xs[:, 0::2] *= 400; Xs[:, 1::2] *= 400
+    Yt = torch.from_numpy(g["y_test"]).cuda().clone(); Yt[:, 0] *= 400; Yt[:, 1] *= 400; Yt[:, 2:] *= P
+    pred, true = decode.nu_rate(decode.nu_decode(y0, 400, 400, P), Xs), decode.nu_rate(Yt, Xs)
+    ratio = float(pred.sum() / true.sum())
+    assert abs(ratio - 0.91359) < 2e-3, ratio
+
+
+def test_msr_and_co_evaluators_on_sampled_outputs_match_the_oracle_scoring():
+    """MSR / CO: sample on the device, score with the product decoders and evaluators (classifier_free_MSR.py:283-291,
+    classifier_free_CO.py:344-366), and compare the task metric with the oracle's scoring of the same samples: the
+    decoders are exercised on real sampler outputs, not only on random rows."""
+    from diffsg_amd import decode
+    gen = torch.Generator().manual_seed(5)
+    # MSR-80c: power allocation W * softmax-decoded y, sum rate against the gains
+    plan, p = synth_params("msr80", 31)
+    d = make_ddpm("msr80", p, 6)
+    gains = torch.rand(600, 80, generator=gen) * 2.0 + 0.5
+    cond = ((gains - gains.min()) / (gains.max() - gains.min())).cuda()
+    y0 = d.sample(cond, 1.0, seed=11)
+    rate = decode.msr_rate(decode.msr_decode(y0) * 20.0, gains.cuda())
+    ref = O.msr_rate(O.msr_decode(y0.cpu()) * 20.0, gains)
+    assert rel(rate.sum(), ref.sum()) <= 1e-5
+    # CO-3n: offloading decision + allocation -> cost
+    plan, p = synth_params("co3", 31)
+    d = make_ddpm("co3", p, 6)
+    X = torch.rand(500, 9, generator=gen) + 0.1
+    y0 = d.sample(X.cuda(), 1.0, seed=12)
+    cost = decode.co_cost(X.cuda(), decode.co_decode(y0))
+    ref = O.co_cost(X, O.co_decode(y0.cpu()))
+    assert rel(cost.sum(), ref.sum()) <= 1e-5
+
+
 @pytest.mark.parametrize("name,B", [("msr80", 16384 + 33), ("co3", 16384 + 7)])
 def test_sample_large_launch_split_vs_exact_f32(name, B):
     """Above the cooperative-kernel threshold (> 512 row tiles per launch) the wide blocks run one wave per tile, the pair
@@ -343,6 +387,47 @@ def test_global_renorm_hook_matches_one_call_on_the_whole_batch():
     assert rel(both, whole) <= 1e-6
     separate = torch.cat([models[i].sample(cond[lo:hi], 1.0, y_T=y_T[lo:hi], noise=z[:, lo:hi]) for i, (lo, hi) in enumerate(shards)])
     assert rel(separate, whole) > 1e-4          # without the hook each shard standardises over its own rows (the default)
+
+
+def test_first_call_at_a_batch_size_under_the_renorm_hook_then_a_plain_call():
+    """the FIRST sample() at a new batch size captures the per-step graphs.  With a renorm hook installed the
+    capture must not run the host callback (an extra collective the other ranks do not issue) and must not bake the hook's
+    moment buffer into the cached graph: the hook is called exactly min(T, 4) times, and a plain sample() afterwards -- hook
+    removed, its buffer freed -- equals a call on a handle that never saw a hook, bit for bit."""
+    from diffsg_amd import parallel as par
+    name, T, B = "msr80", 7, 72              # a batch size no other test of this module uses on these handles
+    plan, p = synth_params(name, 33)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(9)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    fresh = make_ddpm(name, p, T)
+    calls = []
+    with par.global_renorm(fresh, reduce=lambda stats: calls.append(1)):        # one shard: the reduction is the identity
+        hooked = fresh.sample(cond, 1.0, y_T=y_T, noise=z)                      # first call at this B: captures the graphs
+    assert len(calls) == min(T, 4), calls
+    junk = [torch.full((3,), 7.0, device="cuda", dtype=torch.float64) for _ in range(64)]   # reuse the freed moment buffer
+    plain = fresh.sample(cond, 1.0, y_T=y_T, noise=z)                           # replays the cached graphs, no hook
+    torch.cuda.synchronize()
+    assert all(bool((j == 7.0).all()) for j in junk)                            # nothing wrote through a stale pointer
+    never = make_ddpm(name, p, T).sample(cond, 1.0, y_T=y_T, noise=z)
+    assert torch.equal(plain, never)
+    assert rel(hooked, never) <= 1e-6        # the hook path reduces float64 moments once more: same result to rounding
+
+
+def test_global_renorm_reraises_a_failed_reduction():
+    """An exception inside the ctypes callback is not swallowed: it is re-raised when the context is left."""
+    from diffsg_amd import parallel as par
+    plan, p = synth_params("tiny", 3)
+    d = make_ddpm("tiny", p, 5)
+    cond = torch.rand(40, CONFIGS["tiny"]["cond_dim"]).cuda()
+
+    def boom(stats):
+        raise ValueError("collective failed")
+    with pytest.raises(RuntimeError, match="moment reduction failed"):
+        with par.global_renorm(d, reduce=boom):
+            d.sample(cond, 1.0, seed=1)
 
 
 def test_sample_full_size_properties():
