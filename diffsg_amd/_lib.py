@@ -18,7 +18,8 @@ SOURCES = [os.path.join(_HERE, "csrc", "dsg_api.hip")]
 def _headers():
     """Everything dsg_api.hip includes: every header under csrc/ and the C-ABI declaration."""
     import glob
-    return sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp"))) + [os.path.join(os.path.dirname(_HERE), "include", "diffsg.h")]
+    return (sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) + glob.glob(os.path.join(_HERE, "csrc", "*.inc")))
+            + [os.path.join(os.path.dirname(_HERE), "include", "diffsg.h")])
 
 _ID_MARK = b"DSG_BUILD_ID="
 

@@ -5,6 +5,7 @@
 #include "dsg_train.hpp"
 #include "dsg_split.hpp"
 #include "dsg_wide.hpp"
+#include "dsg_panel.hpp"
 #include "dsg_train_split.hpp"
 #include "dsg_eval.hpp"
 #include "dsg_labelgen.hpp"
@@ -107,6 +108,7 @@ struct Op {
 
 // launches with fewer row tiles than this leave SIMDs idle with one wave per tile (dsg_set_launch_policy)
 constexpr int kCoopMaxTilesDefault = 512, kNarrowSmallMaxTilesDefault = 1024;
+constexpr int kPanelMinTilesDefault = 2048;    // 256 CUs x 8 tiles: below this the persistent panel kernels leave CUs idle
 
 }  // namespace
 
@@ -141,6 +143,10 @@ struct dsg_handle {
     // launch policy (dsg_set_launch_policy): launches of at most this many row tiles take the small-launch kernel forms
     int coop_max_tiles = kCoopMaxTilesDefault;          // wide blocks: k_resblock_c (N/32 waves per tile) and no pair kernels
     int narrow_small_max_tiles = kNarrowSmallMaxTilesDefault; // narrow run: k_fused_narrow_h<true> (first-step planes requested a stage ahead)
+    // 128-wide blocks of the reverse loop: launches of at least this many tiles run the persistent panel kernels (dsg_panel.hpp:
+    // one 8-wave workgroup per CU); coop_max_tiles == 0 ("every launch takes its large-launch form") lowers it to 0
+    int panel_min_tiles = kPanelMinTilesDefault;
+    int num_cus = 256;
     float* maxabs = nullptr;           // [params]: max|W| per tensor, refreshed at every bind
     const float** mx_ptrs_dev = nullptr; long long* mx_numel_dev = nullptr; int* mx_idx_dev = nullptr; int mx_n = 0;
     std::vector<int> mx_param;         // param index of each k_maxabs block
@@ -646,6 +652,18 @@ bool wide128_ok(const ResP& r, const BlockArgs& b) {
     return r.N == 128 && b.in0.groups == 16 && (b.in1.groups == 0 || b.in1.groups == 16) && (b.in1.groups != 0) == r.sclin && b.cond_pre;
 }
 
+// persistent panel kernels (dsg_panel.hpp): sampling launches only (the time bias is one row: no per-row `ts`)
+bool panel128_ok(const dsg_handle* h, const ResP& r, const BlockArgs& b) {
+    return wide128_ok(r, b) && !b.ts && !b.save_h1 && b.tiles_per_pass * 2 >= b.ntiles && b.ntiles >= h->panel_min_tiles &&
+           b.ntiles > h->coop_max_tiles;
+}
+template <bool SC, int EPI, int NTO>
+void launch_panel128(const dsg_handle* h, const BlockLinArgsH& w, hipStream_t s) {
+    const int ngroups = cdiv(w.b.b.ntiles, kPW);
+    const dim3 grid(ngroups < h->num_cus ? ngroups : h->num_cus), block(kPW * 64);
+    hipLaunchKernelGGL((k_panel128_h<SC, EPI, NTO>), grid, block, 0, s, w, ngroups);
+}
+
 void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStream_t s) {
     BlockArgsH a;
     fill_block_args_h(h, r, b, a);
@@ -661,6 +679,13 @@ void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStr
             if (r.sclin) hipLaunchKernelGGL((k_resblock_c<64, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_resblock_c<64, false>), grid, block, 0, s, a);
         }
+        return;
+    }
+    if (panel128_ok(h, r, a.b)) {
+        BlockLinArgsH w;
+        memset(&w, 0, sizeof w);
+        w.b = a; w.store_block_out = 1;
+        if (r.sclin) launch_panel128<true, 0, 1>(h, w, s); else launch_panel128<false, 0, 1>(h, w, s);
         return;
     }
     if (wide128_ok(r, a.b)) {
@@ -708,6 +733,15 @@ bool launch_res_lin_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, co
     a.dbg = 0;
     const dim3 grid(cdiv(b.ntiles, kWavesPerBlock)), block(256);
     const int NTO = cdiv(l.l.N, 32);
+    if (panel128_ok(h, r, b) && l.l.K == 128) {
+#define DSG_TRYP(SC_, EPI_, NTO_)                                                                            \
+    if (r.sclin == SC_ && (final_op ? 2 : 1) == EPI_ && NTO == NTO_) {                                       \
+        launch_panel128<SC_, EPI_, NTO_>(h, a, s);                                                           \
+        return true;                                                                                         \
+    }
+        DSG_TRYP(false, 1, 2) DSG_TRYP(false, 1, 1) DSG_TRYP(true, 2, 1) DSG_TRYP(true, 2, 3)
+#undef DSG_TRYP
+    }
     if (wide128_ok(r, b) && l.l.K == 128) {
 #define DSG_TRYW(SC_, EPI_, NTO_)                                                                            \
     if (r.sclin == SC_ && (final_op ? 2 : 1) == EPI_ && NTO == NTO_) {                                       \
@@ -1376,6 +1410,11 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         }
         h->fuse_lo = best_lo; h->fuse_hi = best_hi;
     }
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            h->num_cus = cus;
+    }
     bool ok = hipMalloc(&h->ce_dev, (h->res.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
               hipMalloc(&h->fusedh_dev, (h->ops.size() + 1) * sizeof(FusedOpH)) == hipSuccess &&
               hipMalloc(&h->maxabs, (h->params.size() + 1) * sizeof(float)) == hipSuccess &&
@@ -1628,6 +1667,7 @@ int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_ma
         (void)hipDeviceSynchronize();
         free_graphs(h);                 // the captured step graphs hold the kernel forms chosen at capture time
         h->coop_max_tiles = c; h->narrow_small_max_tiles = n;
+        h->panel_min_tiles = c == 0 ? 0 : kPanelMinTilesDefault;
     }
     return 0;
 }

@@ -1,0 +1,607 @@
+// 128-wide ResidualBlocks for LARGE launches, persistent form: one 8-wave workgroup per CU walks its tile groups, the weight
+// planes of a block pass through LDS in 32 KiB PANELS that all eight waves read (8 row tiles per weight fetch).
+//
+// Why (profiles/r02d_*): k_wide128_h (4 waves, an 8 KiB chunk ring, one barrier per two chunks) met its
+// workgroup at a barrier 44 times per block, paid a 12 000-cycle prologue and a 4 000-cycle store tail per 4 tiles (19 % of a
+// workgroup's life) and sat at 0.29 of the matrix-core peak with the matrix core busy a third of the time.  Here
+//   * a workgroup is PERSISTENT: per-feature vectors are staged once per launch, tile groups follow each other with the weight
+//     and operand streams running across the seam (no prologue, no drain per group);
+//   * a PANEL = 4 k16-steps x 4 out tiles x (hi, lo) = 32 KiB, two buffers: one barrier per panel (12 per up block instead of
+//     44), the next panel's LDS-DMA issued right behind the barrier and in flight for a whole panel time;
+//   * the PRIVATE operands of a wave (its tile's row statistics, input tensors, condition embedding) travel through per-wave
+//     LDS slots (4 x 2 KiB, three items ahead) and need no barrier at all: only the issuing wave reads them;
+//   * every wait on the vector-memory counter is counted from sequence numbers kept in SGPRs (ops issued so far vs. ops issued
+//     when the awaited DMA went out): no drain to zero anywhere in the loop.  Stores are not counted (an under-count only
+//     makes a wait stricter).
+// Arithmetic per element, packed planes, scales and accumulation order are those of k_wide128_h / resblock_body_h.
+#pragma once
+#include "dsg_wide.hpp"
+
+namespace dsg {
+
+constexpr int kPW = 8;                 // waves per workgroup (two per SIMD), ONE workgroup per CU
+constexpr int kPanelU4 = 2048;         // uint4 per weight panel (32 KiB)
+constexpr int kPrivU4 = 128;           // uint4 per private item (2 KiB = two 8-feature groups of one row tile)
+constexpr int kPrivSlots = 4;          // per wave
+constexpr int kPrivDist = 3;           // items in flight ahead of the consumer; the slot refilled is the one read a step earlier
+constexpr int kPanelLdsU4 = 2 * kPanelU4 + kPW * kPrivSlots * kPrivU4 + kWideVec / 4;
+
+// Measurement build (-DDSG_CYCLE_STAMPS): every wave of workgroup 0 keeps up to 128 (cycle, tag) stamps in LDS and dumps them at
+// the end of the launch (no global traffic inside the pipelined loop); tools/panel_stamps.py reads them.
+#ifdef DSG_CYCLE_STAMPS
+constexpr int kPanelStampU4 = kPW * 128 / 2;
+#define DSG_PSTAMP(tag)                                                                                               \
+    do {                                                                                                              \
+        if (STAMPED && blockIdx.x == 0 && stamp_k < 128) {                                                           \
+            const unsigned long long t_ = __builtin_readcyclecounter();                                               \
+            if (lane == 0) stamp_lds[wave * 128 + stamp_k] = (t_ << 16) | (unsigned long long)(tag);                  \
+            ++stamp_k;                                                                                                \
+        }                                                                                                             \
+    } while (0)
+#else
+constexpr int kPanelStampU4 = 0;
+#define DSG_PSTAMP(tag) do {} while (0)
+#endif
+
+// wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform and even).  Only DMA operations
+// are counted by the callers: at most kPrivDist items x 2 + one panel x 4 = 10 are ever in flight behind the awaited one.
+__device__ __forceinline__ void vm_wait_upto(int n) {
+    if (n >= 8) {
+        if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (n >= 4) {
+        if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// LDS-DMA with a scalar base and a per-lane byte offset; the instruction offset moves the global AND the LDS address
+// (tools/ubench/glds_check.hip).  4 x 1 KiB / 2 x 1 KiB / two 256-B rows (one dword per lane).
+__device__ __forceinline__ void glds_quad_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds_pair_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// row statistics of a tile: 32 x (mean, M2) = 256 B of each input tensor -> lds_dst, lds_dst + 256
+__device__ __forceinline__ void glds_stats_s(unsigned voff4, const void* s0, const void* s1, unsigned lds_dst) {
+    unsigned keep;
+    const void* s1m = reinterpret_cast<const char*>(s1) - 256;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, %2\n\t"
+                 "global_load_lds_dword %1, %3 offset:256\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff4), "s"(s0), "s"(s1m), "s"(lds_dst) : "memory");
+}
+
+// The private operand stream of ONE wave: per tile [row statistics | stage 1: KS1 items | condition embedding: 8 items on a
+// conditional tile | shortcut: KS1 items, or the residual re-read: 8 items].  The issue side runs kPrivDist items ahead of
+// the consumer, across tile groups.
+template <bool SCLIN>
+struct PrivIter {
+    static constexpr int KS1 = SCLIN ? 16 : 8, NE = SCLIN ? 16 : 8;
+    int g, pos, total, ncond;
+    const float *x0, *x1, *cp, *st0, *st1;
+
+    __device__ __forceinline__ void set_tile(const BlockArgs& a, int wave, int ngroups) {
+        if (g >= ngroups) return;
+        const int traw = g * kPW + wave;
+        const int tile = traw < a.ntiles ? traw : a.ntiles - 1;
+        const int ptile = tile >= a.tiles_per_pass ? tile - a.tiles_per_pass : tile;      // at most two passes
+        const int t0 = seg_tile(a.in0, tile), t1 = seg_tile(a.in1, tile);
+        x0 = a.in0.data + (size_t)t0 * 16 * 256; st0 = a.in0.stats + (size_t)t0 * 64;
+        x1 = SCLIN ? a.in1.data + (size_t)t1 * 16 * 256 : x0; st1 = SCLIN ? a.in1.stats + (size_t)t1 * 64 : st0;
+        cp = a.cond_pre + (size_t)ptile * 16 * 256;
+        ncond = tile >= a.uncond_tiles ? 8 : 0;
+        total = 1 + KS1 + ncond + NE;
+    }
+    __device__ __forceinline__ const float* source() const {        // pos >= 1
+        const int i = pos - 1, ic = i - KS1, ie = ic - ncond;
+        const int k = i < KS1 ? i : ie;                              // index into the concatenated input (stage 1 / shortcut)
+        const float* xin = SCLIN ? (k < 8 ? x0 + (size_t)k * 512 : x1 + (size_t)(k - 8) * 512) : x0 + (size_t)k * 512;
+        return (i >= KS1 && ic < ncond) ? cp + (size_t)ic * 512 : xin;
+    }
+};
+
+struct PanelCtx {
+    unsigned lane16, lane4;
+    unsigned w_lds;            // LDS byte address of this wave's 4 KiB piece of weight buffer 0 (buffer 1: + 32 KiB)
+    unsigned w_rd;             // LDS byte address of weight buffer 0 + lane * 16 (M phase)
+    unsigned p_lds;            // LDS byte address of this wave's private slot 0
+    const uint4* wrd;          // weight buffer 0 as ordinary LDS, + lane
+    const uint4* prd;          // this wave's private slot 0, + lane
+    int n_iss;                 // vector-memory DMA operations issued so far
+    int wseq;                  // n_iss right after the newest weight panel went out
+    int p0, p1, p2;            // ... after each of the (up to) three private items in flight, oldest first
+    int q;                     // weight panels consumed so far (buffer = q & 1)
+    int ci;                    // private items consumed so far (slot = ci & 3)
+};
+
+template <bool SCLIN>
+__device__ __forceinline__ void priv_issue(PanelCtx& c, PrivIter<SCLIN>& it, const BlockArgs& a, int wave, int ngroups, int stride) {
+    if (it.g < ngroups) {
+        const unsigned dst = c.p_lds + (unsigned)((c.ci + kPrivDist) & (kPrivSlots - 1)) * 2048u;
+        if (it.pos == 0) glds_stats_s(c.lane4, it.st0, it.st1, dst);
+        else glds_pair_s(c.lane16, it.source(), dst);
+        c.n_iss += 2;
+        if (++it.pos == it.total) { it.pos = 0; it.g += stride; it.set_tile(a, wave, ngroups); }
+    }
+}
+
+// Consume the next private item: wait for it (counted), hand back its slot, refill the slot read one step earlier.
+template <bool SCLIN>
+__device__ __forceinline__ const uint4* priv_consume(PanelCtx& c, PrivIter<SCLIN>& it, const BlockArgs& a, int wave, int ngroups, int stride) {
+    vm_wait_upto(c.n_iss - c.p0);
+    const uint4* rd = c.prd + (c.ci & (kPrivSlots - 1)) * kPrivU4;
+    priv_issue<SCLIN>(c, it, a, wave, ngroups, stride);
+    c.p0 = c.p1; c.p1 = c.p2; c.p2 = c.n_iss;
+    ++c.ci;
+    return rd;
+}
+
+template <int NT>
+__device__ __forceinline__ void panel_wfrag(HFrag<NT>& w, const uint4* panel /* + lane */, int steps_per_tile, int s) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { w.hi[nt] = panel[(nt * steps_per_tile + s) * 128]; w.lo[nt] = panel[(nt * steps_per_tile + s) * 128 + 64]; }
+}
+
+
+// Operand preparation WITHOUT packed-f32 instructions (same bits: v_pk_fma_f32 rounds each element like v_fma_f32).  Beside a
+// partner wave's MFMA stream the packed forms are an anti-lever (the guide's filler table; cycle stamps of this kernel).
+__device__ __forceinline__ float silu_scaled_l2s(float up) {
+    constexpr float k = -1.44269504088896341f / kActScale;
+    return up * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(up), k, k));
+}
+template <bool LNACT>
+__device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamma, const float* beta, int S, float c, float d, int h) {
+    float v[8];
+    if (LNACT) {
+        const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
+        const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = silu_scaled_l2s(fmaf(fmaf(x[q], c, d), g[q], b[q]));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x[q] * kRawScale;
+    }
+    BOp o;
+    split8(v, o.hi, o.lo);
+    return o;
+}
+
+// ---- V phase / M phase.  A panel's worth of work (4 k16-steps) is split into
+//   V: the four B operands are prepared (LayerNorm, SiLU, hi/lo split: pure VALU + the LayerNorm vectors from LDS), and
+//   M: 48 MFMAs over the panel with nothing but the panel's plane reads between them (the planes of step s+1 are requested
+//      under the MFMAs of step s).
+// Why: with the operand preparation of a step sitting between its LDS reads and its MFMAs, every step was a chain of exposed
+// latencies (LDS round trip -> dependent VALU chain -> 12 MFMAs each waiting for its just-requested plane): profiles/r03b,
+// 36 % of wave cycles in s_waitcnt and 30 % in issue stalls.  The M phase has no dependence on anything but LDS reads issued
+// a step ahead; the V phase no MFMA to wait for.  The operands of four steps are 32 registers.
+struct BOp4 { h8 hi[4], lo[4]; };
+
+// B operands of steps S0..S0+3 of a register-fed stage from the accumulators of the previous one
+__device__ __forceinline__ void v_phase_reg(BOp4& b, const f32x16 (&in)[4], int S0, const float* gamma, const float* beta, float cc, float dd, int h) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int S = S0 + s, t = S >> 1, r0 = 8 * (S & 1);
+        const float x[8] = {in[t][r0], in[t][r0 + 1], in[t][r0 + 2], in[t][r0 + 3], in[t][r0 + 4], in[t][r0 + 5], in[t][r0 + 6], in[t][r0 + 7]};
+        const BOp o = panel_prep<true>(x, gamma, beta, S, cc, dd, h);
+        b.hi[s] = o.hi; b.lo[s] = o.lo;
+    }
+}
+
+// 48 MFMAs: acc (+)= W[panel] * b, as ONE hand-ordered instruction stream (dsg_panel_mphase.inc, tools/gen/gen_mphase.py): two
+// plane register sets alternate by step, the eight plane reads of step s+1 go out one behind each of the first eight MFMAs of
+// step s, every MFMA waits (counted lgkmcnt: LDS returns in order) only for the plane it needs.  hipcc, given the same program
+// as C++ with sched_group_barrier requests, re-ordered the MFMAs and kept every plane read right in front of its use
+// (read -> wait -> MFMA, five exposed LDS round trips per step).
+#include "dsg_panel_mphase.inc"
+template <bool FIRST>
+__device__ __forceinline__ void m_phase(f32x16 (&acc)[4], unsigned panel_addr /* LDS byte address of the panel + lane * 16 */, const BOp4& b) {
+    uint4 pl[16];
+    if (FIRST)
+        asm volatile(DSG_MPHASE_ASM_FIRST
+                     : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3]),
+                       [pl0] "=&v"(pl[0]), [pl1] "=&v"(pl[1]), [pl2] "=&v"(pl[2]), [pl3] "=&v"(pl[3]), [pl4] "=&v"(pl[4]), [pl5] "=&v"(pl[5]),
+                       [pl6] "=&v"(pl[6]), [pl7] "=&v"(pl[7]), [pl8] "=&v"(pl[8]), [pl9] "=&v"(pl[9]), [pl10] "=&v"(pl[10]), [pl11] "=&v"(pl[11]),
+                       [pl12] "=&v"(pl[12]), [pl13] "=&v"(pl[13]), [pl14] "=&v"(pl[14]), [pl15] "=&v"(pl[15])
+                     : [ad] "v"(panel_addr), [bh0] "v"(b.hi[0]), [bh1] "v"(b.hi[1]), [bh2] "v"(b.hi[2]), [bh3] "v"(b.hi[3]),
+                       [bl0] "v"(b.lo[0]), [bl1] "v"(b.lo[1]), [bl2] "v"(b.lo[2]), [bl3] "v"(b.lo[3])
+                     : "memory");
+    else
+        asm volatile(DSG_MPHASE_ASM
+                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]),
+                       [pl0] "=&v"(pl[0]), [pl1] "=&v"(pl[1]), [pl2] "=&v"(pl[2]), [pl3] "=&v"(pl[3]), [pl4] "=&v"(pl[4]), [pl5] "=&v"(pl[5]),
+                       [pl6] "=&v"(pl[6]), [pl7] "=&v"(pl[7]), [pl8] "=&v"(pl[8]), [pl9] "=&v"(pl[9]), [pl10] "=&v"(pl[10]), [pl11] "=&v"(pl[11]),
+                       [pl12] "=&v"(pl[12]), [pl13] "=&v"(pl[13]), [pl14] "=&v"(pl[14]), [pl15] "=&v"(pl[15])
+                     : [ad] "v"(panel_addr), [bh0] "v"(b.hi[0]), [bh1] "v"(b.hi[1]), [bh2] "v"(b.hi[2]), [bh3] "v"(b.hi[3]),
+                       [bl0] "v"(b.lo[0]), [bl1] "v"(b.lo[1]), [bl2] "v"(b.lo[2]), [bl3] "v"(b.lo[3])
+                     : "memory");
+}
+
+// EPI: 0 = block only, 1 = + raw Linear (Down/Upsample), 2 = + final (LayerNorm + SiLU + Linear, row-major out)
+template <bool SCLIN, int EPI, int NTO>
+__global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, const int ngroups) {
+    constexpr int N = 128, NT = 4, NG = 16;
+    constexpr int KS1 = SCLIN ? 16 : 8, P1 = KS1 / 4;
+    constexpr int NTOP = NTO <= 1 ? 1 : (NTO == 2 ? 2 : 4), ESTEPS = 16 / NTOP;    // epilogue Linear: k16-steps per panel (8 needed)
+    constexpr int EPANELS = EPI == 0 ? 0 : (ESTEPS >= 8 ? 1 : 2);
+    constexpr int PA = P1, PB = PA + 2, PD = PB + 2, PE = PD + (SCLIN ? P1 : 0), NP = PE + EPANELS;
+    __shared__ uint4 lds[kPanelLdsU4 + kPanelStampU4];
+#ifdef DSG_CYCLE_STAMPS
+    unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + kPanelLdsU4);
+    int stamp_k = 0;
+    constexpr bool STAMPED = SCLIN && EPI == 0;
+#endif
+    float* const vec = reinterpret_cast<float*>(lds + 2 * kPanelU4 + kPW * kPrivSlots * kPrivU4);
+    float* const g1v = vec, * const b1v = vec + kLnLdsW1, * const v2 = vec + 2 * kLnLdsW1;
+    float* const g2v = v2, * const b2v = v2 + 128, * const g3v = v2 + 256, * const b3v = v2 + 384, * const tbv = v2 + 512, * const c2v = v2 + 640,
+         * const c3v = v2 + 768, * const gLv = v2 + 896, * const bLv = v2 + 1024, * const biasLv = v2 + 1152;
+    const BlockArgsH& ah = A.b;
+    const BlockArgs& a = ah.b;
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int stride = gridDim.x;
+    // Waves w and w + 4 share a SIMD.  Waves 0-3 ("lead") prepare a panel's operands BEFORE the panel's barrier and run their
+    // MFMAs right behind it; waves 4-7 prepare theirs BEHIND the barrier: while one wave of a SIMD streams MFMAs (at raised
+    // priority, dsg_panel_mphase.inc) its partner is in its VALU phase, then they swap.
+    const bool lead = wave < 4;
+    constexpr float kL2 = -1.44269504088896341f;
+
+    // ---- per-feature vectors -> LDS, once per launch (LayerNorm vectors times -log2 e)
+    {
+        const int n1 = ln1_extent(a);
+        for (int i = threadIdx.x; i < n1; i += 512) { g1v[i] = a.gamma1[i] * kL2; b1v[i] = a.beta1[i] * kL2; }
+        if (threadIdx.x < 128) {
+            const int i = threadIdx.x;
+            g2v[i] = a.gamma2[i] * kL2; b2v[i] = a.beta2[i] * kL2; g3v[i] = a.gamma3[i] * kL2; b3v[i] = a.beta3[i] * kL2;
+            c2v[i] = a.c2[i]; c3v[i] = a.c3[i];
+            tbv[i] = a.tbias[(size_t)(a.step_ptr ? *a.step_ptr : 0) * a.tb_stride + i];
+            if (EPI == 2) { gLv[i] = A.l.l.gamma[i] * kL2; bLv[i] = A.l.l.beta[i] * kL2; }
+            if (EPI != 0) biasLv[i] = i < NTO * 32 ? A.l.l.bias[i] : 0.f;
+        }
+    }
+    const float inv1 = ah.kc[0], inv2 = ah.kc[1], inv3 = ah.kc[2];
+    float invL = 0.f;
+    if (EPI != 0) invL = A.l.kc[EPI == 2 ? 1 : 0];
+    __syncthreads();                   // no DMA is in flight yet: a plain barrier
+
+    // ---- this wave's 4 KiB of every weight panel: (out tile, half of its four k16-steps)
+    const int wnt = wave >> 1, wsub = wave & 1;
+    const uint4* const w1p = ah.W1h + ((size_t)wnt * KS1) * 128 + wsub * 256;
+    const uint4* const w2p = ah.W2h + ((size_t)wnt * 8) * 128 + wsub * 256;
+    const uint4* const w3p = ah.W3h + ((size_t)wnt * 8) * 128 + wsub * 256;
+    const uint4* const wsp = SCLIN ? ah.Wsch + ((size_t)wnt * KS1) * 128 + wsub * 256 : w1p;
+    const uint4* wlp = w1p;
+    if (EPI != 0) {
+        // NTOP = 4: as the block's panels (tiles >= NTO reload tile 0); 2: (tile, quarter of its 8 steps); 1: quarter of tile 0
+        if (NTOP == 4) wlp = A.l.Wh + ((size_t)(wnt < NTO ? wnt : 0) * 8) * 128 + wsub * 256;
+        else if (NTOP == 2) wlp = A.l.Wh + ((size_t)(wave >> 2) * 8) * 128 + (wave & 3) * 256;
+        else wlp = A.l.Wh + (wave & 3) * 256;
+    }
+    auto panel_src = [&](int p) -> const uint4* {       // p in [0, NP), wave-uniform
+        const uint4* r = wlp + (NTOP == 4 ? (size_t)(p - PE) * 512 : 0);
+        r = p < PE ? wsp + (size_t)(p - PD) * 512 : r;
+        r = p < PD ? w3p + (size_t)(p - PB) * 512 : r;
+        r = p < PB ? w2p + (size_t)(p - PA) * 512 : r;
+        r = p < PA ? w1p + (size_t)p * 512 : r;
+        return r;
+    };
+
+    const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds;
+    PanelCtx c;
+    c.lane16 = (unsigned)lane * 16u; c.lane4 = (unsigned)lane * 4u;
+    c.w_lds = lds0 + (unsigned)wave * 4096u;
+    c.w_rd = lds0 + (unsigned)lane * 16u;
+    c.p_lds = lds0 + 2u * kPanelU4 * 16u + (unsigned)wave * (kPrivSlots * 2048u);
+    c.wrd = lds + lane;
+    c.prd = lds + 2 * kPanelU4 + wave * (kPrivSlots * kPrivU4) + lane;
+    c.n_iss = 0; c.q = 0; c.ci = 0;
+
+    PrivIter<SCLIN> it;
+    it.g = blockIdx.x; it.pos = 0;
+    it.set_tile(a, wave, ngroups);
+    // prologue: panel 0 of this workgroup's first group into buffer 0 and the first kPrivDist private items
+    int pp = 1;                        // position inside the block program of the NEXT panel to issue
+    int g_next_panel = blockIdx.x;     // ... and the tile group it belongs to
+    bool more_panels = blockIdx.x < ngroups;
+    if (more_panels) { glds_quad_s(c.lane16, panel_src(0), c.w_lds); c.n_iss += 4; }
+    c.wseq = c.n_iss;
+    // slots 0, 1, 2 <- items 0, 1, 2 (priv_issue fills slot (ci + kPrivDist) & 3: run ci from -kPrivDist)
+    c.ci = -kPrivDist;
+    priv_issue<SCLIN>(c, it, a, wave, ngroups, stride); c.p0 = c.n_iss; ++c.ci;
+    priv_issue<SCLIN>(c, it, a, wave, ngroups, stride); c.p1 = c.n_iss; ++c.ci;
+    priv_issue<SCLIN>(c, it, a, wave, ngroups, stride); c.p2 = c.n_iss; ++c.ci;
+    // Two barriers per panel.  X (before the V phase): my pieces of the panel have landed.  Y (before the M phase): everyone is
+    // done with the OTHER buffer -- refill it with the next panel -- and every wave's pieces of this panel have landed (each
+    // waited before its own X, which precedes this Y).  Waves 4-7 run ONE PHASE BEHIND waves 0-3 (they pass one extra barrier
+    // first, waves 0-3 one at the end): between two barriers one wave of every SIMD is in its M phase and its partner in its V
+    // phase, with the same code for both.  The buffer a lagging wave reads in its M phase is not refilled before the next Y of
+    // the leading waves, which the lagging waves reach only after that M phase.
+    auto panel_x = [&]() {
+        vm_wait_upto(c.n_iss - c.wseq);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto panel_y = [&]() -> int {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int rd = c.q & 1;
+        if (more_panels) {
+            glds_quad_s(c.lane16, panel_src(pp), c.w_lds + (unsigned)((c.q + 1) & 1) * (kPanelU4 * 16u));
+            c.n_iss += 4;
+            if (++pp == NP) { pp = 0; g_next_panel += stride; more_panels = g_next_panel < ngroups; }
+        }
+        c.wseq = c.n_iss;
+        ++c.q;
+        return rd;
+    };
+    if (!lead) __builtin_amdgcn_s_barrier();
+
+    for (int g = blockIdx.x; g < ngroups; g += stride) {
+        const int tile_raw = g * kPW + wave;
+        const bool live = tile_raw < a.ntiles;          // idle waves of the last group still move their pieces and meet the barriers
+        const int tile = live ? tile_raw : a.ntiles - 1;
+        const int ptile = tile >= a.tiles_per_pass ? tile - a.tiles_per_pass : tile;
+        const bool my_cond = tile >= a.uncond_tiles;
+        DSG_PSTAMP(0x01);
+
+        // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as resblock_body_h
+        float mean1, rstd1;
+        {
+            const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
+            const float2* sp = reinterpret_cast<const float2*>(rd - lane);     // slot base
+            const float2 s0 = sp[j];
+            float mean = s0.x, m2 = s0.y;
+            if (SCLIN) {
+                const float2 s1 = sp[32 + j];
+                const float dd = s1.x - mean;
+                m2 = m2 + s1.y + dd * dd * a.chan_w;
+                mean = mean + dd * a.chan_f;
+            }
+            mean1 = mean;
+            rstd1 = rsqrtf(m2 * a.inv_nin + kLnEps);
+            if (SCLIN) range_check(a.range_flag, mean, m2);
+        }
+
+        // ---- stage 1: memory-fed, LayerNorm + SiLU
+        f32x16 acc1[NT];
+        {
+            const float cc = rstd1, dd = -mean1 * rstd1;
+#pragma unroll 1
+            for (int p = 0; p < P1; ++p) {
+                BOp4 b;
+                auto vph = [&]() {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int S = 4 * p + s;
+                        const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
+                        const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
+                        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                        const BOp o = panel_prep<true>(x, g1v, b1v, S, cc, dd, h);
+                        b.hi[s] = o.hi; b.lo[s] = o.lo;
+                    }
+                };
+                panel_x();
+                DSG_PSTAMP(0x10);
+                vph();
+                DSG_PSTAMP(0x11);
+                const unsigned pa = c.w_rd + (unsigned)panel_y() * (kPanelU4 * 16u);
+                if (p == 0) m_phase<true>(acc1, pa, b); else m_phase<false>(acc1, pa, b);
+                DSG_PSTAMP(0x12);
+            }
+        }
+        acc_unscale_add_lds<NT>(acc1, inv1, tbv, h);
+        DSG_PSTAMP(0x13);
+
+        // ---- stage 2: register-fed
+        f32x16 acc2[NT];
+        {
+            float mean, m2;
+            acc_stats<N, NT>(acc1, h, mean, m2);
+            const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                BOp4 b;
+                panel_x();
+                DSG_PSTAMP(0x20);
+                v_phase_reg(b, acc1, 4 * p, g2v, b2v, cc, dd, h);
+                DSG_PSTAMP(0x21);
+                const unsigned pa = c.w_rd + (unsigned)panel_y() * (kPanelU4 * 16u);
+                if (p == 0) m_phase<true>(acc2, pa, b); else m_phase<false>(acc2, pa, b);
+                DSG_PSTAMP(0x22);
+            }
+            acc_unscale_add_lds<NT>(acc2, inv2, c2v, h);
+        }
+        if (my_cond) {                 // condition embedding of this tile: 8 private items, one accumulator tile per two
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const float4 cv = __builtin_bit_cast(float4, rd[qq * 64]);
+                        const int r0 = 4 * (2 * hf + qq);
+                        acc2[e][r0 + 0] += cv.x; acc2[e][r0 + 1] += cv.y; acc2[e][r0 + 2] += cv.z; acc2[e][r0 + 3] += cv.w;
+                    }
+                }
+            }
+        }
+
+        DSG_PSTAMP(0x23);
+        // ---- stage 3 (+ shortcut in the same scaled accumulator)
+        f32x16 (&acc3)[NT] = acc1;
+        {
+            float mean, m2;
+            acc_stats<N, NT>(acc2, h, mean, m2);
+            const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                BOp4 b;
+                panel_x();
+                DSG_PSTAMP(0x30);
+                v_phase_reg(b, acc2, 4 * p, g3v, b3v, cc, dd, h);
+                DSG_PSTAMP(0x31);
+                const unsigned pa = c.w_rd + (unsigned)panel_y() * (kPanelU4 * 16u);
+                if (p == 0) m_phase<true>(acc3, pa, b); else m_phase<false>(acc3, pa, b);
+                DSG_PSTAMP(0x32);
+            }
+        }
+        if (SCLIN) {
+#pragma unroll 1
+            for (int p = 0; p < P1; ++p) {
+                BOp4 b;
+                auto vph = [&]() {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
+                        const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
+                        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                        const BOp o = panel_prep<false>(x, nullptr, nullptr, 0, 0.f, 0.f, h);
+                        b.hi[s] = o.hi; b.lo[s] = o.lo;
+                    }
+                };
+                panel_x();
+                DSG_PSTAMP(0x40);
+                vph();
+                DSG_PSTAMP(0x41);
+                const unsigned pa = c.w_rd + (unsigned)panel_y() * (kPanelU4 * 16u);
+                m_phase<false>(acc3, pa, b);
+                DSG_PSTAMP(0x42);
+            }
+            acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
+        } else {
+            acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const float4 xv = __builtin_bit_cast(float4, rd[qq * 64]);
+                        const int r0 = 4 * (2 * hf + qq);
+                        acc3[e][r0 + 0] += xv.x; acc3[e][r0 + 1] += xv.y; acc3[e][r0 + 2] += xv.z; acc3[e][r0 + 3] += xv.w;
+                    }
+                }
+            }
+        }
+
+        DSG_PSTAMP(0x43);
+        // ---- statistics + store
+        float xmean, xm2;
+        acc_stats<N, NT>(acc3, h, xmean, xm2);
+        if ((EPI == 0 || A.store_block_out) && live) {
+            if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
+#pragma unroll
+            for (int G = 0; G < NG; ++G)
+                st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                    make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2], acc3[G >> 2][4 * (G & 3) + 3]));
+        }
+        DSG_PSTAMP(0x50);
+        if (EPI == 0) continue;
+        if (EPI == 1) range_check(a.range_flag, xmean, xm2);
+
+        // ---- epilogue Linear: a panel holds ESTEPS k16-steps x NTOP out tiles
+        const LinArgs& la = A.l.l;
+        f32x16 acc[NTO];
+        {
+            const float cc = EPI == 2 ? rsqrtf(xm2 * la.inv_in_w + kLnEps) : 1.f, dd = -xmean * cc;
+            const uint4* pn = nullptr;
+#pragma unroll
+            for (int S = 0; S < 8; ++S) {
+                if (S % ESTEPS == 0) { panel_x(); pn = c.wrd + panel_y() * kPanelU4; }
+                const int sl = S % ESTEPS, t = S >> 1, r0 = 8 * (S & 1);
+                HFrag<NTO> w;
+                panel_wfrag<NTO>(w, pn, ESTEPS, sl);
+                const float x[8] = {acc3[t][r0], acc3[t][r0 + 1], acc3[t][r0 + 2], acc3[t][r0 + 3], acc3[t][r0 + 4], acc3[t][r0 + 5], acc3[t][r0 + 6],
+                                    acc3[t][r0 + 7]};
+                float v[8];
+                if (EPI == 2) {
+                    const float4 g0 = ld4(gLv + 16 * S + 4 * h), b0 = ld4(bLv + 16 * S + 4 * h);
+                    const float4 g1 = ld4(gLv + 16 * S + 8 + 4 * h), b1 = ld4(bLv + 16 * S + 8 + 4 * h);
+                    act8_l2(v, x, cc, dd, g0, b0, g1, b1);
+                } else {
+#pragma unroll
+                    for (int qq = 0; qq < 8; qq += 2) { const f32x2 tt = f32x2{x[qq], x[qq + 1]} * pk2(kRawScale); v[qq] = tt.x; v[qq + 1] = tt.y; }
+                }
+                h8 bhi, blo;
+                split8(v, bhi, blo);
+                if (S == 0) mfma_step_h0<NTO>(acc, w, bhi, blo); else mfma_step_h<NTO>(acc, w, bhi, blo);
+            }
+        }
+        acc_unscale_add_lds<NTO>(acc, invL, biasLv, h);
+        if (!live) continue;
+        if (EPI == 1) {
+            const int NGo = (la.out_width + 7) / 8;
+            float s = 0.f;
+#pragma unroll
+            for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    if (8 * G + 4 * h + qq < la.out_width) s += acc[G >> 2][4 * (G & 3) + qq];
+            const float m = xhalf_sum(s) * la.inv_out_w;
+            float sq = 0.f;
+#pragma unroll
+            for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    if (8 * G + 4 * h + qq < la.out_width) { const float dv = acc[G >> 2][4 * (G & 3) + qq] - m; sq = fmaf(dv, dv, sq); }
+            sq = xhalf_sum(sq);
+            if (h == 0) reinterpret_cast<float2*>(la.out_stats)[(size_t)tile * 32 + j] = make_float2(m, sq);
+#pragma unroll
+            for (int G = 0; G < NTO * 4; ++G)
+                if (G < NGo)
+                    st4(la.out + ((size_t)tile * NGo + G) * 256 + lane * 4,
+                        make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
+        } else {
+            const int pass = tile >= la.tiles_per_pass ? 1 : 0, row = ptile * 32 + j;
+            if (row < la.nrows) {
+                float* o = la.out_rm + ((size_t)pass * la.nrows + row) * la.out_width;
+                if ((la.out_width & 3) == 0) {
+#pragma unroll
+                    for (int G = 0; G < NTO * 4; ++G) {
+                        const int f = 8 * G + 4 * h;
+                        if (f < la.out_width)
+                            st4(o + f, make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
+                    }
+                } else {
+#pragma unroll
+                    for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const int f = 8 * G + 4 * h + qq;
+                            if (f < la.out_width) o[f] = acc[G >> 2][4 * (G & 3) + qq];
+                        }
+                }
+            }
+        }
+    }
+    if (lead) __builtin_amdgcn_s_barrier();
+#ifdef DSG_CYCLE_STAMPS
+    if (STAMPED && blockIdx.x == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int k = lane; k < 128; k += 64) dsg_stamp_buf[wave * 128 + k] = k < stamp_k ? stamp_lds[wave * 128 + k] : 0ull;
+        if (threadIdx.x == 0) dsg_stamp_n = kPW * 128;
+    }
+#endif
+}
+
+}  // namespace dsg
