@@ -22,8 +22,9 @@ namespace dsg {
 constexpr int kPW = 8;                 // waves per workgroup (two per SIMD), ONE workgroup per CU
 constexpr int kPanelU4 = 2048;         // uint4 per weight panel (32 KiB)
 constexpr int kPrivU4 = 128;           // uint4 per private item (2 KiB = two 8-feature groups of one row tile)
-constexpr int kPrivSlots = 4;          // per wave
-constexpr int kPrivDist = 3;           // items in flight ahead of the consumer; the slot refilled is the one read a step earlier
+constexpr int kPrivSlots = 5;          // per wave
+constexpr int kPrivDist = 4;           // items in flight ahead of the consumer (a whole V phase: its four items are requested during
+                                       // the previous one); the slot refilled is the one read a step earlier
 constexpr int kPanelLdsU4 = 2 * kPanelU4 + kPW * kPrivSlots * kPrivU4 + kWideVec / 4;
 
 // Measurement build (-DDSG_CYCLE_STAMPS): every wave of workgroup 0 keeps up to 128 (cycle, tag) stamps in LDS and dumps them at
@@ -42,21 +43,6 @@ constexpr int kPanelStampU4 = kPW * 128 / 2;
 constexpr int kPanelStampU4 = 0;
 #define DSG_PSTAMP(tag) do {} while (0)
 #endif
-
-// wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform and even).  Only DMA operations
-// are counted by the callers: at most kPrivDist items x 2 + one panel x 4 = 10 are ever in flight behind the awaited one.
-__device__ __forceinline__ void vm_wait_upto(int n) {
-    if (n >= 8) {
-        if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (n >= 4) {
-        if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-}
 
 // LDS-DMA with a scalar base and a per-lane byte offset; the instruction offset moves the global AND the LDS address
 // (tools/ubench/glds_check.hip).  4 x 1 KiB / 2 x 1 KiB / two 256-B rows (one dword per lane).
@@ -90,33 +76,33 @@ __device__ __forceinline__ void glds_stats_s(unsigned voff4, const void* s0, con
 }
 
 // The private operand stream of ONE wave: per tile [row statistics | stage 1: KS1 items | condition embedding: 8 items on a
-// conditional tile | shortcut: KS1 items, or the residual re-read: 8 items].  The issue side runs kPrivDist items ahead of
-// the consumer, across tile groups.
-template <bool SCLIN>
-struct PrivIter {
-    static constexpr int KS1 = SCLIN ? 16 : 8, NE = SCLIN ? 16 : 8;
-    int g, pos, total, ncond;
-    const float *x0, *x1, *cp, *st0, *st1;
-
-    __device__ __forceinline__ void set_tile(const BlockArgs& a, int wave, int ngroups) {
-        if (g >= ngroups) return;
-        const int traw = g * kPW + wave;
-        const int tile = traw < a.ntiles ? traw : a.ntiles - 1;
-        const int ptile = tile >= a.tiles_per_pass ? tile - a.tiles_per_pass : tile;      // at most two passes
-        const int t0 = seg_tile(a.in0, tile), t1 = seg_tile(a.in1, tile);
-        x0 = a.in0.data + (size_t)t0 * 16 * 256; st0 = a.in0.stats + (size_t)t0 * 64;
-        x1 = SCLIN ? a.in1.data + (size_t)t1 * 16 * 256 : x0; st1 = SCLIN ? a.in1.stats + (size_t)t1 * 64 : st0;
-        cp = a.cond_pre + (size_t)ptile * 16 * 256;
-        ncond = tile >= a.uncond_tiles ? 8 : 0;
-        total = 1 + KS1 + ncond + NE;
-    }
-    __device__ __forceinline__ const float* source() const {        // pos >= 1
-        const int i = pos - 1, ic = i - KS1, ie = ic - ncond;
-        const int k = i < KS1 ? i : ie;                              // index into the concatenated input (stage 1 / shortcut)
-        const float* xin = SCLIN ? (k < 8 ? x0 + (size_t)k * 512 : x1 + (size_t)(k - 8) * 512) : x0 + (size_t)k * 512;
-        return (i >= KS1 && ic < ncond) ? cp + (size_t)ic * 512 : xin;
-    }
+// conditional tile | shortcut: KS1 items, or the residual re-read: 8 items], an item = 2 KiB (two 8-feature groups of the tile).
+// The consumer code is unrolled, so every consume site knows at compile time which item sits kPrivDist places further down
+// the stream: base pointer of the current (or, for a tile's last four sites, the next) tile + a constant.  The request for it
+// is issued right there -- no iterator, no address decode (the first version kept a position and derived every address from
+// it: ~230 scalar moves and ~100 branches per four items, more issue time than the arithmetic of the steps they feed).
+// A stream that has run out keeps requesting (the same tile again): the operation counts stay regular and nothing reads the
+// slots.
+struct TilePtrs {
+    const char *x0, *x1, *cp;      // this tile of in0, in1 (= in0 without a concat), the condition embedding
+    const char *st0, *st1;         // its row statistics
+    bool cond;
 };
+template <bool SCLIN>
+__device__ __forceinline__ TilePtrs tile_ptrs(const BlockArgs& a, int g, int wave) {
+    const int traw = g * kPW + wave;
+    const int tile = traw < a.ntiles ? traw : a.ntiles - 1;
+    const int ptile = tile >= a.tiles_per_pass ? tile - a.tiles_per_pass : tile;      // at most two passes
+    const int t0 = seg_tile(a.in0, tile), t1 = seg_tile(a.in1, tile);
+    TilePtrs t;
+    t.x0 = reinterpret_cast<const char*>(a.in0.data + (size_t)t0 * 16 * 256);
+    t.st0 = reinterpret_cast<const char*>(a.in0.stats + (size_t)t0 * 64);
+    t.x1 = SCLIN ? reinterpret_cast<const char*>(a.in1.data + (size_t)t1 * 16 * 256) : t.x0;
+    t.st1 = SCLIN ? reinterpret_cast<const char*>(a.in1.stats + (size_t)t1 * 64) : t.st0;
+    t.cp = reinterpret_cast<const char*>(a.cond_pre + (size_t)ptile * 16 * 256);
+    t.cond = tile >= a.uncond_tiles;
+    return t;
+}
 
 struct PanelCtx {
     unsigned lane16, lane4;
@@ -125,32 +111,29 @@ struct PanelCtx {
     unsigned p_lds;            // LDS byte address of this wave's private slot 0
     const uint4* wrd;          // weight buffer 0 as ordinary LDS, + lane
     const uint4* prd;          // this wave's private slot 0, + lane
-    int n_iss;                 // vector-memory DMA operations issued so far
-    int wseq;                  // n_iss right after the newest weight panel went out
-    int p0, p1, p2;            // ... after each of the (up to) three private items in flight, oldest first
     int q;                     // weight panels consumed so far (buffer = q & 1)
-    int ci;                    // private items consumed so far (slot = ci & 3)
+    int islot, cslot;          // private slot the next item goes into / the next item is read from (0 .. kPrivSlots - 1)
 };
 
-template <bool SCLIN>
-__device__ __forceinline__ void priv_issue(PanelCtx& c, PrivIter<SCLIN>& it, const BlockArgs& a, int wave, int ngroups, int stride) {
-    if (it.g < ngroups) {
-        const unsigned dst = c.p_lds + (unsigned)((c.ci + kPrivDist) & (kPrivSlots - 1)) * 2048u;
-        if (it.pos == 0) glds_stats_s(c.lane4, it.st0, it.st1, dst);
-        else glds_pair_s(c.lane16, it.source(), dst);
-        c.n_iss += 2;
-        if (++it.pos == it.total) { it.pos = 0; it.g += stride; it.set_tile(a, wave, ngroups); }
-    }
+// Counted waits.  The stream is regular: behind the item a consume site waits for, exactly kPrivDist - 1 = 3 younger items
+// (2 DMA operations each) have been requested, plus possibly weight panels (4 each).  Vector-memory operations complete in
+// order, so "at most 6 outstanding" implies the awaited item has landed -- and never waits for the three items behind it.
+// A panel's own wait (panel_x) finds nothing younger than the panel in flight in a memory-fed stage: vmcnt(0).
+// request one item (2 KiB at src, or the two statistics rows) into the next slot
+__device__ __forceinline__ void priv_issue(PanelCtx& c, const char* src) {
+    glds_pair_s(c.lane16, src, c.p_lds + (unsigned)c.islot * 2048u);
+    c.islot = c.islot == kPrivSlots - 1 ? 0 : c.islot + 1;
 }
-
-// Consume the next private item: wait for it (counted), hand back its slot, refill the slot read one step earlier.
-template <bool SCLIN>
-__device__ __forceinline__ const uint4* priv_consume(PanelCtx& c, PrivIter<SCLIN>& it, const BlockArgs& a, int wave, int ngroups, int stride) {
-    vm_wait_upto(c.n_iss - c.p0);
-    const uint4* rd = c.prd + (c.ci & (kPrivSlots - 1)) * kPrivU4;
-    priv_issue<SCLIN>(c, it, a, wave, ngroups, stride);
-    c.p0 = c.p1; c.p1 = c.p2; c.p2 = c.n_iss;
-    ++c.ci;
+__device__ __forceinline__ void priv_issue_stats(PanelCtx& c, const char* st0, const char* st1) {
+    glds_stats_s(c.lane4, st0, st1, c.p_lds + (unsigned)c.islot * 2048u);
+    c.islot = c.islot == kPrivSlots - 1 ? 0 : c.islot + 1;
+}
+// Consume the next private item: wait for it and hand back its slot.  The caller then requests the item kPrivDist places ahead
+// (it goes into the slot read one step earlier).
+__device__ __forceinline__ const uint4* priv_consume(PanelCtx& c) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    const uint4* rd = c.prd + c.cslot * kPrivU4;
+    c.cslot = c.cslot == kPrivSlots - 1 ? 0 : c.cslot + 1;
     return rd;
 }
 
@@ -167,20 +150,45 @@ __device__ __forceinline__ float silu_scaled_l2s(float up) {
     constexpr float k = -1.44269504088896341f / kActScale;
     return up * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(up), k, k));
 }
+#ifndef DSG_PANEL_VDBG
+#define DSG_PANEL_VDBG 0      // measurement only: 1 = operands are the raw bits of x (no VALU), 2 = no split, 4 = no transcendentals
+#endif
+// LayerNorm vectors of a step from LDS: `gl` / `bl` are this lane's address-space-3 pointers (vector + 4 h); with a compile-time S
+// the offset folds into the ds_read instruction (through generic pointers hipcc kept four address registers per step alive
+// across the whole tile loop and spilled them)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 template <bool LNACT>
 __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamma, const float* beta, int S, float c, float d, int h) {
     float v[8];
+    if (DSG_PANEL_VDBG & 1) {
+        BOp o;
+        const uint4 ua = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+        const uint4 ub = {__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+        o.hi = __builtin_bit_cast(h8, ua); o.lo = __builtin_bit_cast(h8, ub);
+        return o;
+    }
     if (LNACT) {
-        const float4 g0 = ld4(gamma + 16 * S + 4 * h), b0 = ld4(beta + 16 * S + 4 * h);
-        const float4 g1 = ld4(gamma + 16 * S + 8 + 4 * h), b1 = ld4(beta + 16 * S + 8 + 4 * h);
+        lds_cf4* const gl = (lds_cf4*)(gamma + 4 * h);
+        lds_cf4* const bl = (lds_cf4*)(beta + 4 * h);
+        const f32x4 g0 = gl[4 * S], b0 = bl[4 * S], g1 = gl[4 * S + 2], b1 = bl[4 * S + 2];
         const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = silu_scaled_l2s(fmaf(fmaf(x[q], c, d), g[q], b[q]));
+        for (int q = 0; q < 8; ++q) {
+            const float u = fmaf(fmaf(x[q], c, d), g[q], b[q]);
+            v[q] = (DSG_PANEL_VDBG & 4) ? u * fmaf(u, 0.25f, 0.5f) : silu_scaled_l2s(u);
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = x[q] * kRawScale;
     }
     BOp o;
+    if (DSG_PANEL_VDBG & 2) {
+        const uint4 ua = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        const uint4 ub = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+        o.hi = __builtin_bit_cast(h8, ua); o.lo = __builtin_bit_cast(h8, ub);
+        return o;
+    }
     split8(v, o.hi, o.lo);
     return o;
 }
@@ -194,6 +202,14 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
 // 36 % of wave cycles in s_waitcnt and 30 % in issue stalls.  The M phase has no dependence on anything but LDS reads issued
 // a step ahead; the V phase no MFMA to wait for.  The operands of four steps are 32 registers.
 struct BOp4 { h8 hi[4], lo[4]; };
+// The operands are COMPLETE here: without this the compiler sinks the whole preparation behind the panel's barrier, next to the
+// MFMA stream that consumes it (cycle stamps: the "M phase" of both SIMD partners then contained the V phase's arithmetic)
+// ... and the second half of a register-fed stage's input is "redefined" behind the first panel's MFMA stream, so that its
+// preparation cannot be hoisted above that stream (32 more live registers exactly where the plane registers are needed)
+__device__ __forceinline__ void v_phase_fence(f32x16& x0, f32x16& x1) { asm volatile("" : "+v"(x0), "+v"(x1)); }
+__device__ __forceinline__ void v_phase_done(BOp4& b) {
+    asm volatile("" : "+v"(b.hi[0]), "+v"(b.hi[1]), "+v"(b.hi[2]), "+v"(b.hi[3]), "+v"(b.lo[0]), "+v"(b.lo[1]), "+v"(b.lo[2]), "+v"(b.lo[3]));
+}
 
 // B operands of steps S0..S0+3 of a register-fed stage from the accumulators of the previous one
 __device__ __forceinline__ void v_phase_reg(BOp4& b, const f32x16 (&in)[4], int S0, const float* gamma, const float* beta, float cc, float dd, int h) {
@@ -239,7 +255,7 @@ __device__ __forceinline__ void m_phase(f32x16 (&acc)[4], unsigned panel_addr /*
 template <bool SCLIN, int EPI, int NTO>
 __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, const int ngroups) {
     constexpr int N = 128, NT = 4, NG = 16;
-    constexpr int KS1 = SCLIN ? 16 : 8, P1 = KS1 / 4;
+    constexpr int KS1 = SCLIN ? 16 : 8, P1 = KS1 / 4, NE = SCLIN ? 16 : 8;   // k16-steps of stage 1; items of the shortcut / residual read
     constexpr int NTOP = NTO <= 1 ? 1 : (NTO == 2 ? 2 : 4), ESTEPS = 16 / NTOP;    // epilogue Linear: k16-steps per panel (8 needed)
     constexpr int EPANELS = EPI == 0 ? 0 : (ESTEPS >= 8 ? 1 : 2);
     constexpr int PA = P1, PB = PA + 2, PD = PB + 2, PE = PD + (SCLIN ? P1 : 0), NP = PE + EPANELS;
@@ -295,13 +311,13 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
         else if (NTOP == 2) wlp = A.l.Wh + ((size_t)(wave >> 2) * 8) * 128 + (wave & 3) * 256;
         else wlp = A.l.Wh + (wave & 3) * 256;
     }
-    auto panel_src = [&](int p) -> const uint4* {       // p in [0, NP), wave-uniform
-        const uint4* r = wlp + (NTOP == 4 ? (size_t)(p - PE) * 512 : 0);
-        r = p < PE ? wsp + (size_t)(p - PD) * 512 : r;
-        r = p < PD ? w3p + (size_t)(p - PB) * 512 : r;
-        r = p < PB ? w2p + (size_t)(p - PA) * 512 : r;
-        r = p < PA ? w1p + (size_t)p * 512 : r;
-        return r;
+    // panel p of the block program (compile-time p at every call site): the weights do not depend on the tile
+    auto panel_src = [&](int p) -> const uint4* {
+        if (p < PA) return w1p + (size_t)p * 512;
+        if (p < PB) return w2p + (size_t)(p - PA) * 512;
+        if (p < PD) return w3p + (size_t)(p - PB) * 512;
+        if (p < PE) return wsp + (size_t)(p - PD) * 512;
+        return wlp + (NTOP == 4 ? (size_t)(p - PE) * 512 : 0);
     };
 
     const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds;
@@ -312,22 +328,18 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     c.p_lds = lds0 + 2u * kPanelU4 * 16u + (unsigned)wave * (kPrivSlots * 2048u);
     c.wrd = lds + lane;
     c.prd = lds + 2 * kPanelU4 + wave * (kPrivSlots * kPrivU4) + lane;
-    c.n_iss = 0; c.q = 0; c.ci = 0;
+    c.q = 0; c.islot = 0; c.cslot = 0;
 
-    PrivIter<SCLIN> it;
-    it.g = blockIdx.x; it.pos = 0;
-    it.set_tile(a, wave, ngroups);
-    // prologue: panel 0 of this workgroup's first group into buffer 0 and the first kPrivDist private items
-    int pp = 1;                        // position inside the block program of the NEXT panel to issue
-    int g_next_panel = blockIdx.x;     // ... and the tile group it belongs to
-    bool more_panels = blockIdx.x < ngroups;
-    if (more_panels) { glds_quad_s(c.lane16, panel_src(0), c.w_lds); c.n_iss += 4; }
-    c.wseq = c.n_iss;
-    // slots 0, 1, 2 <- items 0, 1, 2 (priv_issue fills slot (ci + kPrivDist) & 3: run ci from -kPrivDist)
-    c.ci = -kPrivDist;
-    priv_issue<SCLIN>(c, it, a, wave, ngroups, stride); c.p0 = c.n_iss; ++c.ci;
-    priv_issue<SCLIN>(c, it, a, wave, ngroups, stride); c.p1 = c.n_iss; ++c.ci;
-    priv_issue<SCLIN>(c, it, a, wave, ngroups, stride); c.p2 = c.n_iss; ++c.ci;
+    // prologue: panel 0 into buffer 0 and the first four private items of this wave's first tile
+    {
+        const TilePtrs cur = tile_ptrs<SCLIN>(a, blockIdx.x < ngroups ? blockIdx.x : 0, wave);
+        priv_issue_stats(c, cur.st0, cur.st1);
+        priv_issue(c, cur.x0);
+        priv_issue(c, cur.x0 + 2048);
+        priv_issue(c, cur.x0 + 4096);
+    }
+    glds_quad_s(c.lane16, panel_src(0), c.w_lds);
+
     // Two barriers per panel.  X (before the V phase): my pieces of the panel have landed.  Y (before the M phase): everyone is
     // done with the OTHER buffer -- refill it with the next panel -- and every wave's pieces of this panel have landed (each
     // waited before its own X, which precedes this Y).  Waves 4-7 run ONE PHASE BEHIND waves 0-3 (they pass one extra barrier
@@ -335,23 +347,21 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     // phase, with the same code for both.  The buffer a lagging wave reads in its M phase is not refilled before the next Y of
     // the leading waves, which the lagging waves reach only after that M phase.
     auto panel_x = [&]() {
-        vm_wait_upto(c.n_iss - c.wseq);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
-    auto panel_y = [&]() -> int {
+    // `next`: the panel of the block program that follows this one (the program repeats for the next tile group; the request
+    // after the very last panel of the launch is redundant and drained before the kernel ends)
+    auto panel_y = [&](int next) -> int {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int rd = c.q & 1;
-        if (more_panels) {
-            glds_quad_s(c.lane16, panel_src(pp), c.w_lds + (unsigned)((c.q + 1) & 1) * (kPanelU4 * 16u));
-            c.n_iss += 4;
-            if (++pp == NP) { pp = 0; g_next_panel += stride; more_panels = g_next_panel < ngroups; }
-        }
-        c.wseq = c.n_iss;
+        glds_quad_s(c.lane16, panel_src(next), c.w_lds + (unsigned)((c.q + 1) & 1) * (kPanelU4 * 16u));
         ++c.q;
         return rd;
     };
+    // sources of the concatenated input by k16-step (stage 1 and the shortcut / residual read the same tensors)
+    auto xin = [&](const TilePtrs& t, int S) -> const char* { return SCLIN && S >= 8 ? t.x1 + (size_t)(S - 8) * 2048 : t.x0 + (size_t)S * 2048; };
     if (!lead) __builtin_amdgcn_s_barrier();
 
     for (int g = blockIdx.x; g < ngroups; g += stride) {
@@ -359,13 +369,23 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
         const bool live = tile_raw < a.ntiles;          // idle waves of the last group still move their pieces and meet the barriers
         const int tile = live ? tile_raw : a.ntiles - 1;
         const int ptile = tile >= a.tiles_per_pass ? tile - a.tiles_per_pass : tile;
-        const bool my_cond = tile >= a.uncond_tiles;
+        const TilePtrs cur = tile_ptrs<SCLIN>(a, g, wave);
+        const bool my_cond = cur.cond;
+        const TilePtrs nxt = tile_ptrs<SCLIN>(a, g + stride < ngroups ? g + stride : g, wave);
         DSG_PSTAMP(0x01);
+        // the item four places behind position `T` of the part that follows stage 1: condition embedding (conditional tiles),
+        // then the shortcut / residual input, then the next tile's statistics and first steps
+        auto issue_tail = [&](int T) {            // T counts from the first shortcut / residual item
+            if (T < NE) priv_issue(c, xin(cur, T));
+            else if (T == NE) priv_issue_stats(c, nxt.st0, nxt.st1);
+            else priv_issue(c, nxt.x0 + (size_t)(T - NE - 1) * 2048);
+            
+        };
 
         // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as resblock_body_h
         float mean1, rstd1;
         {
-            const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
+            const uint4* rd = priv_consume(c);
             const float2* sp = reinterpret_cast<const float2*>(rd - lane);     // slot base
             const float2 s0 = sp[j];
             float mean = s0.x, m2 = s0.y;
@@ -375,6 +395,7 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
                 m2 = m2 + s1.y + dd * dd * a.chan_w;
                 mean = mean + dd * a.chan_f;
             }
+            priv_issue(c, cur.x0 + 3 * 2048); 
             mean1 = mean;
             rstd1 = rsqrtf(m2 * a.inv_nin + kLnEps);
             if (SCLIN) range_check(a.range_flag, mean, m2);
@@ -384,25 +405,27 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
         f32x16 acc1[NT];
         {
             const float cc = rstd1, dd = -mean1 * rstd1;
-#pragma unroll 1
+#pragma unroll
             for (int p = 0; p < P1; ++p) {
                 BOp4 b;
-                auto vph = [&]() {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int S = 4 * p + s;
-                        const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
-                        const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
-                        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                        const BOp o = panel_prep<true>(x, g1v, b1v, S, cc, dd, h);
-                        b.hi[s] = o.hi; b.lo[s] = o.lo;
-                    }
-                };
                 panel_x();
                 DSG_PSTAMP(0x10);
-                vph();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int S = 4 * p + s;
+                    const uint4* rd = priv_consume(c);
+                    const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
+                    if (S + 4 < KS1) { priv_issue(c, xin(cur, S + 4));  }
+                    else if (my_cond) { priv_issue(c, cur.cp + (size_t)(S + 4 - KS1) * 2048);  }
+                    else issue_tail(S + 4 - KS1);
+                    const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                    const BOp o = panel_prep<true>(x, g1v, b1v, S, cc, dd, h);
+                    b.hi[s] = o.hi; b.lo[s] = o.lo;
+                }
+                v_phase_done(b);
                 DSG_PSTAMP(0x11);
-                const unsigned pa = c.w_rd + (unsigned)panel_y() * (kPanelU4 * 16u);
+                const unsigned pa = c.w_rd + (unsigned)panel_y(p + 1) * (kPanelU4 * 16u);
+                DSG_PSTAMP(0x14);
                 if (p == 0) m_phase<true>(acc1, pa, b); else m_phase<false>(acc1, pa, b);
                 DSG_PSTAMP(0x12);
             }
@@ -422,9 +445,12 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
                 panel_x();
                 DSG_PSTAMP(0x20);
                 v_phase_reg(b, acc1, 4 * p, g2v, b2v, cc, dd, h);
+                v_phase_done(b);
                 DSG_PSTAMP(0x21);
-                const unsigned pa = c.w_rd + (unsigned)panel_y() * (kPanelU4 * 16u);
+                const unsigned pa = c.w_rd + (unsigned)panel_y(PA + p + 1) * (kPanelU4 * 16u);
+                DSG_PSTAMP(0x24);
                 if (p == 0) m_phase<true>(acc2, pa, b); else m_phase<false>(acc2, pa, b);
+                if (p == 0) v_phase_fence(acc1[2], acc1[3]);
                 DSG_PSTAMP(0x22);
             }
             acc_unscale_add_lds<NT>(acc2, inv2, c2v, h);
@@ -434,18 +460,19 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const float4 cv = __builtin_bit_cast(float4, rd[qq * 64]);
-                        const int r0 = 4 * (2 * hf + qq);
-                        acc2[e][r0 + 0] += cv.x; acc2[e][r0 + 1] += cv.y; acc2[e][r0 + 2] += cv.z; acc2[e][r0 + 3] += cv.w;
-                    }
+                    const int i = 2 * e + hf;
+                    const uint4* rd = priv_consume(c);
+                    const float4 cv0 = __builtin_bit_cast(float4, rd[0]), cv1 = __builtin_bit_cast(float4, rd[64]);
+                    if (i + 4 < 8) { priv_issue(c, cur.cp + (size_t)(i + 4) * 2048);  }
+                    else issue_tail(i + 4 - 8);
+                    const int r0 = 8 * hf;
+                    acc2[e][r0 + 0] += cv0.x; acc2[e][r0 + 1] += cv0.y; acc2[e][r0 + 2] += cv0.z; acc2[e][r0 + 3] += cv0.w;
+                    acc2[e][r0 + 4] += cv1.x; acc2[e][r0 + 5] += cv1.y; acc2[e][r0 + 6] += cv1.z; acc2[e][r0 + 7] += cv1.w;
                 }
             }
         }
-
         DSG_PSTAMP(0x23);
+
         // ---- stage 3 (+ shortcut in the same scaled accumulator)
         f32x16 (&acc3)[NT] = acc1;
         {
@@ -458,31 +485,35 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
                 panel_x();
                 DSG_PSTAMP(0x30);
                 v_phase_reg(b, acc2, 4 * p, g3v, b3v, cc, dd, h);
+                v_phase_done(b);
                 DSG_PSTAMP(0x31);
-                const unsigned pa = c.w_rd + (unsigned)panel_y() * (kPanelU4 * 16u);
+                const unsigned pa = c.w_rd + (unsigned)panel_y((PB + p + 1) % NP) * (kPanelU4 * 16u);
+                DSG_PSTAMP(0x34);
                 if (p == 0) m_phase<true>(acc3, pa, b); else m_phase<false>(acc3, pa, b);
+                if (p == 0) v_phase_fence(acc2[2], acc2[3]);
                 DSG_PSTAMP(0x32);
             }
         }
         if (SCLIN) {
-#pragma unroll 1
+#pragma unroll
             for (int p = 0; p < P1; ++p) {
                 BOp4 b;
-                auto vph = [&]() {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
-                        const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
-                        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                        const BOp o = panel_prep<false>(x, nullptr, nullptr, 0, 0.f, 0.f, h);
-                        b.hi[s] = o.hi; b.lo[s] = o.lo;
-                    }
-                };
                 panel_x();
                 DSG_PSTAMP(0x40);
-                vph();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int S = 4 * p + s;
+                    const uint4* rd = priv_consume(c);
+                    const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
+                    issue_tail(S + 4);
+                    const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                    const BOp o = panel_prep<false>(x, nullptr, nullptr, 0, 0.f, 0.f, h);
+                    b.hi[s] = o.hi; b.lo[s] = o.lo;
+                }
+                v_phase_done(b);
                 DSG_PSTAMP(0x41);
-                const unsigned pa = c.w_rd + (unsigned)panel_y() * (kPanelU4 * 16u);
+                const unsigned pa = c.w_rd + (unsigned)panel_y((PD + p + 1) % NP) * (kPanelU4 * 16u);
+                DSG_PSTAMP(0x44);
                 m_phase<false>(acc3, pa, b);
                 DSG_PSTAMP(0x42);
             }
@@ -493,18 +524,18 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const uint4* rd = priv_consume<SCLIN>(c, it, a, wave, ngroups, stride);
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const float4 xv = __builtin_bit_cast(float4, rd[qq * 64]);
-                        const int r0 = 4 * (2 * hf + qq);
-                        acc3[e][r0 + 0] += xv.x; acc3[e][r0 + 1] += xv.y; acc3[e][r0 + 2] += xv.z; acc3[e][r0 + 3] += xv.w;
-                    }
+                    const int i = 2 * e + hf;
+                    const uint4* rd = priv_consume(c);
+                    const float4 xv0 = __builtin_bit_cast(float4, rd[0]), xv1 = __builtin_bit_cast(float4, rd[64]);
+                    issue_tail(i + 4);
+                    const int r0 = 8 * hf;
+                    acc3[e][r0 + 0] += xv0.x; acc3[e][r0 + 1] += xv0.y; acc3[e][r0 + 2] += xv0.z; acc3[e][r0 + 3] += xv0.w;
+                    acc3[e][r0 + 4] += xv1.x; acc3[e][r0 + 5] += xv1.y; acc3[e][r0 + 6] += xv1.z; acc3[e][r0 + 7] += xv1.w;
                 }
             }
         }
-
         DSG_PSTAMP(0x43);
+
         // ---- statistics + store
         float xmean, xm2;
         acc_stats<N, NT>(acc3, h, xmean, xm2);
@@ -527,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             const uint4* pn = nullptr;
 #pragma unroll
             for (int S = 0; S < 8; ++S) {
-                if (S % ESTEPS == 0) { panel_x(); pn = c.wrd + panel_y() * kPanelU4; }
+                if (S % ESTEPS == 0) { panel_x(); pn = c.wrd + panel_y((PE + S / ESTEPS + 1) % NP) * kPanelU4; }
                 const int sl = S % ESTEPS, t = S >> 1, r0 = 8 * (S & 1);
                 HFrag<NTO> w;
                 panel_wfrag<NTO>(w, pn, ESTEPS, sl);
@@ -595,6 +626,7 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
         }
     }
     if (lead) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's last requests are redundant: nothing may land in LDS after the end
 #ifdef DSG_CYCLE_STAMPS
     if (STAMPED && blockIdx.x == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -45,4 +45,4 @@ ev.sort()
 t0 = ev[0][0]
 half = [e for e in ev if e[0] - t0 > 0][: 2 * 40]
 print("timeline (cycle, wave, tag reached):")
-print(" ".join(f"{t - t0}:w{w}:{tag:02x}" for t, w, tag in ev[:90]))
+print(" ".join(f"{t - t0}:w{w}:{tag:02x}" for t, w, tag in ev[:110]))
