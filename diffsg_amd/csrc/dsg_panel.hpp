@@ -29,13 +29,17 @@ constexpr int kPanelLdsU4 = 2 * kPanelU4 + kPW * kPrivSlots * kPrivU4 + kWideVec
 
 // Measurement build (-DDSG_CYCLE_STAMPS): every wave of workgroup 0 keeps up to 128 (cycle, tag) stamps in LDS and dumps them at
 // the end of the launch (no global traffic inside the pipelined loop); tools/panel_stamps.py reads them.
+#ifndef DSG_STAMP_DBG
+#define DSG_STAMP_DBG 0
+#endif
 #ifdef DSG_CYCLE_STAMPS
 constexpr int kPanelStampU4 = kPW * 128 / 2;
 #define DSG_PSTAMP(tag)                                                                                               \
     do {                                                                                                              \
         if (STAMPED && blockIdx.x == 0 && stamp_k < 128) {                                                           \
             const unsigned long long t_ = __builtin_readcyclecounter();                                               \
-            if (lane == 0) stamp_lds[wave * 128 + stamp_k] = (t_ << 16) | (unsigned long long)(tag);                  \
+            if (lane == 0 && !(DSG_STAMP_DBG & 1)) stamp_lds[wave * 128 + stamp_k] = (t_ << 16) | (unsigned long long)(tag); \
+            if (DSG_STAMP_DBG & 1) asm volatile("" :: "s"(t_));                                                       \
             ++stamp_k;                                                                                                \
         }                                                                                                             \
     } while (0)
@@ -251,7 +255,165 @@ __device__ __forceinline__ void m_phase(f32x16 (&acc)[4], unsigned panel_addr /*
                      : "memory");
 }
 
+// ---- The same MFMA stream written slot by slot: every MFMA is its own `asm volatile` (volatile statements keep their order),
+// the plane reads are ordinary LDS loads placed BETWEEN the statements (a load cannot cross a volatile statement, so it stays in
+// the slot it was written in; hipcc counts its lgkmcnt waits itself and no value is ever copied before it has landed), and
+// ordinary VALU code can be pinned between two MFMAs by passing its inputs / results through the neighbouring statements as
+// "+v" operands (panel_pipe below).
+__device__ __forceinline__ void mfma_slot(f32x16& c, const uint4 a, const h8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(__builtin_bit_cast(h8, a)), "v"(b));
+}
+__device__ __forceinline__ void mfma_slot0(f32x16& c, const uint4 a, const h8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(__builtin_bit_cast(h8, a)), "v"(b));
+}
+constexpr int kPlaneAhead = 8;     // MFMA slots between a plane's read and its use
+
+// slot k of a panel: term t = (k / 4) % 3 (hi*bhi, hi*blo, lo*bhi), out tile nt = k % 4, step s = k / 12
+__device__ __forceinline__ constexpr int slot_plane(int k) { return (((k % 4) * 4 + k / 12) * 2 + ((k / 4) % 3 == 2 ? 1 : 0)) * 64; }   // uint4 offset in the panel
+
+template <bool FIRST>
+__device__ __forceinline__ void m_phase_slots(f32x16 (&acc)[4], const uint4* pn /* + lane */, const BOp4& b) {
+    // plane of slot k, for k in the order of first use: per step hi[0..3] (slots 0-3, reused by 4-7), lo[0..3] (slots 8-11)
+    uint4 pl[48];                                   // only ~kPlaneAhead + 4 of them are live at a time
+#pragma unroll
+    for (int k = 0; k < kPlaneAhead && k < 48; ++k)
+        if ((k / 4) % 3 != 1) pl[k] = pn[slot_plane(k)];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+        const int s = k / 12, t = (k / 4) % 3, nt = k % 4;
+        const int kp = t == 1 ? k - 4 : k;          // the hi*blo term reuses the plane of the hi*bhi slot
+        const h8 bb = t == 1 ? b.lo[s] : b.hi[s];
+        if (FIRST && k < 4) mfma_slot0(acc[nt], pl[kp], bb); else mfma_slot(acc[nt], pl[kp], bb);
+        const int kn = k + kPlaneAhead;
+        if (kn < 48 && (kn / 4) % 3 != 1) pl[kn] = pn[slot_plane(kn)];
+    }
+}
+
 // EPI: 0 = block only, 1 = + raw Linear (Down/Upsample), 2 = + final (LayerNorm + SiLU + Linear, row-major out)
+// ---- panel_pipe: the MFMA stream of one panel WITH the operand preparation of the next panel between the MFMAs.
+// 48 MFMA slots, 16 operand pairs (4 steps x 4 pairs of values): pair m takes slots 3m (LayerNorm + exp2), 3m + 1 (rcp, product)
+// and 3m + 2 (hi/lo split), six / six / four VALU instructions, i.e. the five-or-so instructions a wave can issue under one
+// MFMA (MI355X guide, "instructions hidden per MFMA gap").  The pieces are ordinary C++; what keeps each of them between its two
+// MFMAs is that its inputs and its results pass through the neighbouring `asm volatile` statements as "+v" operands.
+typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
+struct PipePins { float a0, a1, a2, a3; };     // values in flight between two pieces of the chain
+
+__device__ __forceinline__ void mfma_pin(f32x16& c, const uint4 a, const h8 b, float& p0, float& p1, float& p2, float& p3) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[a], %[b], %[c]" : [c] "+v"(c), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : [a] "v"(__builtin_bit_cast(h8, a)), [b] "v"(b));
+}
+__device__ __forceinline__ void mfma_pin0(f32x16& c, const uint4 a, const h8 b, float& p0, float& p1, float& p2, float& p3) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[a], %[b], 0" : [c] "=&v"(c), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : [a] "v"(__builtin_bit_cast(h8, a)), [b] "v"(b));
+}
+
+// PREP: what is prepared under this panel's MFMAs --
+//   PIPE_REG   the next four steps (S0 .. S0 + 3) of a register-fed stage, from the accumulators `in` (LayerNorm + SiLU + split)
+//   PIPE_LN    four steps whose input arrives through the wave's private slots (stage 1): LayerNorm + SiLU + split
+//   PIPE_RAW   the same source, split only (Linear shortcut)
+// For the two private-slot kinds `consume(j)` is called once per step, six MFMA slots before the step's first piece: it waits
+// for the item, requests the one kPrivDist places ahead and returns the slot.
+enum { PIPE_REG = 1, PIPE_LN = 2, PIPE_RAW = 3 };
+typedef __attribute__((address_space(3))) const f32x2 lds_cf2g;
+
+// lo part of the split: v - float(half of `hi`), one v_fma_mix_f32 (f32 * 1.0 - f16): hipcc picks cvt + sub (two instructions) in
+// this context.  Not volatile: an ordinary instruction for the scheduler.
+__device__ __forceinline__ float sub_half_lo(float v, unsigned hi) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float sub_half_hi(float v, unsigned hi) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hi));
+    return r;
+}
+
+template <bool FIRST, int PREP, typename Consume>
+__device__ __forceinline__ void panel_pipe(f32x16 (&acc)[4], const uint4* pn /* + lane */, const BOp4& b, BOp4& bn, const f32x16 (&in)[4], int S0,
+                                           const float* gamma, const float* beta, float cc, float dd, int h, Consume&& consume) {
+    constexpr float kk = -1.44269504088896341f / kActScale;
+    constexpr bool LN = PREP != PIPE_RAW, MEM = PREP != PIPE_REG;
+    lds_cf4* const gl = (lds_cf4*)(gamma + 4 * h);
+    lds_cf4* const bl = (lds_cf4*)(beta + 4 * h);
+    uint4 pl[48];
+    float cpin = cc, u0 = 0.f, u1 = 0.f, p0 = 0.f, p1 = 0.f, v0 = 0.f, v1 = 0.f;
+    f32x4 gq[8], bq[8], xq[8];                       // per HALF step (two pairs): LayerNorm vectors, input values
+    float hq[17], lq[17];                            // results (bit patterns of half pairs); [16] is a dummy pin for the first statement
+    lds_cf4* slot[4];                                // private slot of each of the four steps (+ lane)
+    hq[16] = 0.f; lq[16] = 0.f;
+    auto load_vec = [&](int hs) {                    // half step hs = 2 * step + (0: values 0-3, 1: values 4-7)
+        const int S = S0 + (hs >> 1);
+        gq[hs] = gl[4 * S + 2 * (hs & 1)]; bq[hs] = bl[4 * S + 2 * (hs & 1)];
+    };
+    auto load_x = [&](int hs) { xq[hs] = slot[hs >> 1][(hs & 1) * 64]; };
+#pragma unroll
+    for (int k = 0; k < kPlaneAhead; ++k)
+        if ((k / 4) % 3 != 1) pl[k] = pn[slot_plane(k)];
+    if (MEM) { slot[0] = (lds_cf4*)consume(0); load_x(0); }
+    if (LN) load_vec(0);
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+        const int s = k / 12, t = (k / 4) % 3, nt = k % 4;
+        const int kp = t == 1 ? k - 4 : k;
+        const h8 bb = t == 1 ? b.lo[s] : b.hi[s];
+        const int m = k / 3, ph = k % 3, mp = m == 0 ? 16 : m - 1;
+        // private item of the NEXT step: six slots before its first piece
+        if (MEM && k % 12 == 6 && k / 12 < 3) slot[k / 12 + 1] = (lds_cf4*)consume(k / 12 + 1);
+        // the statement: MFMA k; pins = what flows from the piece behind the previous MFMA into the piece behind this one
+        if (ph == 0) { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, cpin, hq[mp], lq[mp], v0); else mfma_pin(acc[nt], pl[kp], bb, cpin, hq[mp], lq[mp], v0); }
+        else if (ph == 1) { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, u0, u1, p0, p1); else mfma_pin(acc[nt], pl[kp], bb, u0, u1, p0, p1); }
+        else { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, v0, v1, u0, u1); else mfma_pin(acc[nt], pl[kp], bb, v0, v1, u0, u1); }
+        // loads of later slots: planes kPlaneAhead slots ahead; vectors / values of the next half step at the first pair of this one
+        const int kn = k + kPlaneAhead;
+        if (kn < 48 && (kn / 4) % 3 != 1) pl[kn] = pn[slot_plane(kn)];
+        if (ph == 0 && (m & 1) == 0 && m / 2 + 1 < 8) {
+            if (LN) load_vec(m / 2 + 1);
+            if (MEM) load_x(m / 2 + 1);
+        }
+        // the piece behind MFMA k
+        const int S = S0 + (m >> 2), q = m & 3, tt = (S >> 1) & 3, r0 = 8 * (S & 1) + 2 * q, hs = m >> 1, e = 2 * (m & 1);
+        if (ph == 0) {
+            const float x0 = MEM ? xq[hs][e] : in[tt][r0], x1 = MEM ? xq[hs][e + 1] : in[tt][r0 + 1];
+            if (LN) {
+                u0 = fmaf(fmaf(x0, cpin, dd), gq[hs][e], bq[hs][e]);
+                u1 = fmaf(fmaf(x1, cpin, dd), gq[hs][e + 1], bq[hs][e + 1]);
+                p0 = __builtin_amdgcn_exp2f(u0); p1 = __builtin_amdgcn_exp2f(u1);
+            } else {
+                u0 = x0 * (cpin * kRawScale); u1 = x1 * (cpin * kRawScale);      // cpin == 1: keeps the piece behind this MFMA
+            }
+        } else if (ph == 1) {
+            if (LN) {
+                v0 = u0 * __builtin_amdgcn_rcpf(fmaf(p0, kk, kk));
+                v1 = u1 * __builtin_amdgcn_rcpf(fmaf(p1, kk, kk));
+            } else { v0 = u0; v1 = u1; }
+        } else {
+            const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+            const unsigned er = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(sub_half_lo(v0, a), sub_half_hi(v1, a)));
+            hq[m] = __builtin_bit_cast(float, a); lq[m] = __builtin_bit_cast(float, er);
+        }
+    }
+    // the last piece's results are complete here
+    asm volatile("" : "+v"(hq[15]), "+v"(lq[15]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 hv = {hq[4 * j], hq[4 * j + 1], hq[4 * j + 2], hq[4 * j + 3]}, lv = {lq[4 * j], lq[4 * j + 1], lq[4 * j + 2], lq[4 * j + 3]};
+        bn.hi[j] = __builtin_bit_cast(h8, hv); bn.lo[j] = __builtin_bit_cast(h8, lv);
+    }
+}
+
+#ifndef DSG_PANEL_TRAIL_PRIO
+#define DSG_PANEL_TRAIL_PRIO 1
+#endif
+#ifndef DSG_PANEL_PIPE
+#define DSG_PANEL_PIPE 1
+#endif
+#ifndef DSG_PANEL_MSLOTS
+#define DSG_PANEL_MSLOTS 0
+#endif
+template <bool FIRST>
+__device__ __forceinline__ void M_PHASE(f32x16 (&acc)[4], unsigned pa, const BOp4& b, const uint4* lds_lane) {
+    if (DSG_PANEL_MSLOTS) m_phase_slots<FIRST>(acc, lds_lane + (pa - (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds_lane) / 16u, b);
+    else m_phase<FIRST>(acc, pa, b);
+}
 template <bool SCLIN, int EPI, int NTO>
 __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, const int ngroups) {
     constexpr int N = 128, NT = 4, NG = 16;
@@ -278,6 +440,10 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     // MFMAs right behind it; waves 4-7 prepare theirs BEHIND the barrier: while one wave of a SIMD streams MFMAs (at raised
     // priority, dsg_panel_mphase.inc) its partner is in its VALU phase, then they swap.
     const bool lead = wave < 4;
+    // Static priority for the younger half: at equal priority the older wave of a SIMD wins every arbitration, finishes a panel
+    // ~1 400 cycles before its partner and idles at the barrier while the partner runs alone (cycle stamps: 3 000 against 4 400
+    // cycles per LayerNorm panel).  MI355X guide, "two waves per SIMD", item 4.
+    if (!lead) __builtin_amdgcn_s_setprio(DSG_PANEL_TRAIL_PRIO);
     constexpr float kL2 = -1.44269504088896341f;
 
     // ---- per-feature vectors -> LDS, once per launch (LayerNorm vectors times -log2 e)
@@ -340,29 +506,23 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     }
     glds_quad_s(c.lane16, panel_src(0), c.w_lds);
 
-    // Two barriers per panel.  X (before the V phase): my pieces of the panel have landed.  Y (before the M phase): everyone is
-    // done with the OTHER buffer -- refill it with the next panel -- and every wave's pieces of this panel have landed (each
-    // waited before its own X, which precedes this Y).  Waves 4-7 run ONE PHASE BEHIND waves 0-3 (they pass one extra barrier
-    // first, waves 0-3 one at the end): between two barriers one wave of every SIMD is in its M phase and its partner in its V
-    // phase, with the same code for both.  The buffer a lagging wave reads in its M phase is not refilled before the next Y of
-    // the leading waves, which the lagging waves reach only after that M phase.
-    auto panel_x = [&]() {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    // `next`: the panel of the block program that follows this one (the program repeats for the next tile group; the request
-    // after the very last panel of the launch is redundant and drained before the kernel ends)
-    auto panel_y = [&](int next) -> int {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // One barrier per panel: my pieces of the panel have landed (counted wait: `since_w` DMA operations of the private stream
+    // went out behind them); everyone is done with the other buffer; refill that one with the panel after this (`next`: the block
+    // program repeats for the next tile group; the request behind the launch's last panel is redundant and drained at the end).
+    int since_w = 8;                   // the four private requests of the prologue
+    auto panel_begin = [&](int next) -> int {
+        if (since_w >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (since_w >= 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int rd = c.q & 1;
         glds_quad_s(c.lane16, panel_src(next), c.w_lds + (unsigned)((c.q + 1) & 1) * (kPanelU4 * 16u));
+        since_w = 0;
         ++c.q;
         return rd;
     };
     // sources of the concatenated input by k16-step (stage 1 and the shortcut / residual read the same tensors)
     auto xin = [&](const TilePtrs& t, int S) -> const char* { return SCLIN && S >= 8 ? t.x1 + (size_t)(S - 8) * 2048 : t.x0 + (size_t)S * 2048; };
-    if (!lead) __builtin_amdgcn_s_barrier();
 
     for (int g = blockIdx.x; g < ngroups; g += stride) {
         const int tile_raw = g * kPW + wave;
@@ -379,8 +539,22 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             if (T < NE) priv_issue(c, xin(cur, T));
             else if (T == NE) priv_issue_stats(c, nxt.st0, nxt.st1);
             else priv_issue(c, nxt.x0 + (size_t)(T - NE - 1) * 2048);
-            
+            since_w += 2;
         };
+        // stage 1, step S: wait for its item, request the one four places ahead
+        auto consume_s1 = [&](int S) -> const uint4* {
+            const uint4* rd = priv_consume(c);
+            if (S + 4 < KS1) { priv_issue(c, xin(cur, S + 4)); since_w += 2; }
+            else if (my_cond) { priv_issue(c, cur.cp + (size_t)(S + 4 - KS1) * 2048); since_w += 2; }
+            else issue_tail(S + 4 - KS1);
+            return rd;
+        };
+        auto consume_sc = [&](int S) -> const uint4* {        // shortcut, step S
+            const uint4* rd = priv_consume(c);
+            issue_tail(S + 4);
+            return rd;
+        };
+        auto no_consume = [&](int) -> const uint4* { return nullptr; };
 
         // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as resblock_body_h
         float mean1, rstd1;
@@ -395,38 +569,42 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
                 m2 = m2 + s1.y + dd * dd * a.chan_w;
                 mean = mean + dd * a.chan_f;
             }
-            priv_issue(c, cur.x0 + 3 * 2048); 
+            priv_issue(c, cur.x0 + 3 * 2048); since_w += 2;
             mean1 = mean;
             rstd1 = rsqrtf(m2 * a.inv_nin + kLnEps);
             if (SCLIN) range_check(a.range_flag, mean, m2);
         }
 
-        // ---- stage 1: memory-fed, LayerNorm + SiLU
+        // ---- stage 1: memory-fed, LayerNorm + SiLU.  Panel 0's operands are prepared on their own, the others under the MFMAs
+        // of the panel before them.
         f32x16 acc1[NT];
         {
             const float cc = rstd1, dd = -mean1 * rstd1;
+            BOp4 b;
+            DSG_PSTAMP(0x10);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const uint4* rd = consume_s1(s4);
+                const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
+                const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                const BOp o = panel_prep<true>(x, g1v, b1v, s4, cc, dd, h);
+                b.hi[s4] = o.hi; b.lo[s4] = o.lo;
+            }
+            v_phase_done(b);
+            DSG_PSTAMP(0x11);
 #pragma unroll
             for (int p = 0; p < P1; ++p) {
-                BOp4 b;
-                panel_x();
-                DSG_PSTAMP(0x10);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int S = 4 * p + s;
-                    const uint4* rd = priv_consume(c);
-                    const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
-                    if (S + 4 < KS1) { priv_issue(c, xin(cur, S + 4));  }
-                    else if (my_cond) { priv_issue(c, cur.cp + (size_t)(S + 4 - KS1) * 2048);  }
-                    else issue_tail(S + 4 - KS1);
-                    const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                    const BOp o = panel_prep<true>(x, g1v, b1v, S, cc, dd, h);
-                    b.hi[s] = o.hi; b.lo[s] = o.lo;
-                }
-                v_phase_done(b);
-                DSG_PSTAMP(0x11);
-                const unsigned pa = c.w_rd + (unsigned)panel_y(p + 1) * (kPanelU4 * 16u);
+                const int bi = panel_begin(p + 1);
                 DSG_PSTAMP(0x14);
-                if (p == 0) m_phase<true>(acc1, pa, b); else m_phase<false>(acc1, pa, b);
+                if (p + 1 < P1) {
+                    BOp4 bn;
+                    if (p == 0) panel_pipe<true, PIPE_LN>(acc1, c.wrd + bi * kPanelU4, b, bn, acc1, 4 * (p + 1), g1v, b1v, cc, dd, h, [&](int jj) { return consume_s1(4 * (p + 1) + jj); });
+                    else panel_pipe<false, PIPE_LN>(acc1, c.wrd + bi * kPanelU4, b, bn, acc1, 4 * (p + 1), g1v, b1v, cc, dd, h, [&](int jj) { return consume_s1(4 * (p + 1) + jj); });
+                    b = bn;
+                } else {
+                    const unsigned pa = c.w_rd + (unsigned)bi * (kPanelU4 * 16u);
+                    if (p == 0) M_PHASE<true>(acc1, pa, b, c.wrd); else M_PHASE<false>(acc1, pa, b, c.wrd);
+                }
                 DSG_PSTAMP(0x12);
             }
         }
@@ -439,20 +617,19 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             float mean, m2;
             acc_stats<N, NT>(acc1, h, mean, m2);
             const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                BOp4 b;
-                panel_x();
-                DSG_PSTAMP(0x20);
-                v_phase_reg(b, acc1, 4 * p, g2v, b2v, cc, dd, h);
-                v_phase_done(b);
-                DSG_PSTAMP(0x21);
-                const unsigned pa = c.w_rd + (unsigned)panel_y(PA + p + 1) * (kPanelU4 * 16u);
-                DSG_PSTAMP(0x24);
-                if (p == 0) m_phase<true>(acc2, pa, b); else m_phase<false>(acc2, pa, b);
-                if (p == 0) v_phase_fence(acc1[2], acc1[3]);
-                DSG_PSTAMP(0x22);
-            }
+            BOp4 b, bn;
+            DSG_PSTAMP(0x20);
+            v_phase_reg(b, acc1, 0, g2v, b2v, cc, dd, h);
+            v_phase_done(b);
+            DSG_PSTAMP(0x21);
+            int bi = panel_begin(PA + 1);
+            DSG_PSTAMP(0x24);
+            panel_pipe<true, PIPE_REG>(acc2, c.wrd + bi * kPanelU4, b, bn, acc1, 4, g2v, b2v, cc, dd, h, no_consume);
+            DSG_PSTAMP(0x22);
+            bi = panel_begin(PB);
+            DSG_PSTAMP(0x24);
+            M_PHASE<false>(acc2, c.w_rd + (unsigned)bi * (kPanelU4 * 16u), bn, c.wrd);
+            DSG_PSTAMP(0x22);
             acc_unscale_add_lds<NT>(acc2, inv2, c2v, h);
         }
         if (my_cond) {                 // condition embedding of this tile: 8 private items, one accumulator tile per two
@@ -463,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
                     const int i = 2 * e + hf;
                     const uint4* rd = priv_consume(c);
                     const float4 cv0 = __builtin_bit_cast(float4, rd[0]), cv1 = __builtin_bit_cast(float4, rd[64]);
-                    if (i + 4 < 8) { priv_issue(c, cur.cp + (size_t)(i + 4) * 2048);  }
+                    if (i + 4 < 8) { priv_issue(c, cur.cp + (size_t)(i + 4) * 2048); since_w += 2; }
                     else issue_tail(i + 4 - 8);
                     const int r0 = 8 * hf;
                     acc2[e][r0 + 0] += cv0.x; acc2[e][r0 + 1] += cv0.y; acc2[e][r0 + 2] += cv0.z; acc2[e][r0 + 3] += cv0.w;
@@ -473,64 +650,56 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
         }
         DSG_PSTAMP(0x23);
 
-        // ---- stage 3 (+ shortcut in the same scaled accumulator)
+        // ---- stage 3 (+ shortcut in the same scaled accumulator).  The shortcut's operands (raw input, split only) are prepared
+        // under the MFMAs of the panel before them, starting with stage 3's second panel.
         f32x16 (&acc3)[NT] = acc1;
         {
             float mean, m2;
             acc_stats<N, NT>(acc2, h, mean, m2);
             const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                BOp4 b;
-                panel_x();
-                DSG_PSTAMP(0x30);
-                v_phase_reg(b, acc2, 4 * p, g3v, b3v, cc, dd, h);
-                v_phase_done(b);
-                DSG_PSTAMP(0x31);
-                const unsigned pa = c.w_rd + (unsigned)panel_y((PB + p + 1) % NP) * (kPanelU4 * 16u);
-                DSG_PSTAMP(0x34);
-                if (p == 0) m_phase<true>(acc3, pa, b); else m_phase<false>(acc3, pa, b);
-                if (p == 0) v_phase_fence(acc2[2], acc2[3]);
+            BOp4 b, bn;
+            DSG_PSTAMP(0x30);
+            v_phase_reg(b, acc2, 0, g3v, b3v, cc, dd, h);
+            v_phase_done(b);
+            DSG_PSTAMP(0x31);
+            int bi = panel_begin(PB + 1);
+            DSG_PSTAMP(0x34);
+            panel_pipe<true, PIPE_REG>(acc3, c.wrd + bi * kPanelU4, b, bn, acc2, 4, g3v, b3v, cc, dd, h, no_consume);
+            DSG_PSTAMP(0x32);
+            bi = panel_begin((PD) % NP);
+            DSG_PSTAMP(0x34);
+            if (SCLIN) {
+                panel_pipe<false, PIPE_RAW>(acc3, c.wrd + bi * kPanelU4, bn, b, acc3, 0, g3v, b3v, 1.f, 0.f, h, [&](int jj) { return consume_sc(jj); });
                 DSG_PSTAMP(0x32);
-            }
-        }
-        if (SCLIN) {
 #pragma unroll
-            for (int p = 0; p < P1; ++p) {
-                BOp4 b;
-                panel_x();
-                DSG_PSTAMP(0x40);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int S = 4 * p + s;
-                    const uint4* rd = priv_consume(c);
-                    const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
-                    issue_tail(S + 4);
-                    const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                    const BOp o = panel_prep<false>(x, nullptr, nullptr, 0, 0.f, 0.f, h);
-                    b.hi[s] = o.hi; b.lo[s] = o.lo;
+                for (int p = 0; p < P1; ++p) {
+                    bi = panel_begin((PD + p + 1) % NP);
+                    DSG_PSTAMP(0x44);
+                    if (p + 1 < P1) {
+                        panel_pipe<false, PIPE_RAW>(acc3, c.wrd + bi * kPanelU4, b, bn, acc3, 0, g3v, b3v, 1.f, 0.f, h, [&](int jj) { return consume_sc(4 * (p + 1) + jj); });
+                        b = bn;
+                    } else {
+                        M_PHASE<false>(acc3, c.w_rd + (unsigned)bi * (kPanelU4 * 16u), b, c.wrd);
+                    }
+                    DSG_PSTAMP(0x42);
                 }
-                v_phase_done(b);
-                DSG_PSTAMP(0x41);
-                const unsigned pa = c.w_rd + (unsigned)panel_y((PD + p + 1) % NP) * (kPanelU4 * 16u);
-                DSG_PSTAMP(0x44);
-                m_phase<false>(acc3, pa, b);
-                DSG_PSTAMP(0x42);
-            }
-            acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
-        } else {
-            acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
+                acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
+            } else {
+                M_PHASE<false>(acc3, c.w_rd + (unsigned)bi * (kPanelU4 * 16u), bn, c.wrd);
+                DSG_PSTAMP(0x32);
+                acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int i = 2 * e + hf;
-                    const uint4* rd = priv_consume(c);
-                    const float4 xv0 = __builtin_bit_cast(float4, rd[0]), xv1 = __builtin_bit_cast(float4, rd[64]);
-                    issue_tail(i + 4);
-                    const int r0 = 8 * hf;
-                    acc3[e][r0 + 0] += xv0.x; acc3[e][r0 + 1] += xv0.y; acc3[e][r0 + 2] += xv0.z; acc3[e][r0 + 3] += xv0.w;
-                    acc3[e][r0 + 4] += xv1.x; acc3[e][r0 + 5] += xv1.y; acc3[e][r0 + 6] += xv1.z; acc3[e][r0 + 7] += xv1.w;
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int i = 2 * e + hf;
+                        const uint4* rd = priv_consume(c);
+                        const float4 xv0 = __builtin_bit_cast(float4, rd[0]), xv1 = __builtin_bit_cast(float4, rd[64]);
+                        issue_tail(i + 4);
+                        const int r0 = 8 * hf;
+                        acc3[e][r0 + 0] += xv0.x; acc3[e][r0 + 1] += xv0.y; acc3[e][r0 + 2] += xv0.z; acc3[e][r0 + 3] += xv0.w;
+                        acc3[e][r0 + 4] += xv1.x; acc3[e][r0 + 5] += xv1.y; acc3[e][r0 + 6] += xv1.z; acc3[e][r0 + 7] += xv1.w;
+                    }
                 }
             }
         }
@@ -558,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             const uint4* pn = nullptr;
 #pragma unroll
             for (int S = 0; S < 8; ++S) {
-                if (S % ESTEPS == 0) { panel_x(); pn = c.wrd + panel_y((PE + S / ESTEPS + 1) % NP) * kPanelU4; }
+                if (S % ESTEPS == 0) pn = c.wrd + panel_begin((PE + S / ESTEPS + 1) % NP) * kPanelU4;
                 const int sl = S % ESTEPS, t = S >> 1, r0 = 8 * (S & 1);
                 HFrag<NTO> w;
                 panel_wfrag<NTO>(w, pn, ESTEPS, sl);
@@ -625,7 +794,6 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             }
         }
     }
-    if (lead) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's last requests are redundant: nothing may land in LDS after the end
 #ifdef DSG_CYCLE_STAMPS
     if (STAMPED && blockIdx.x == 0) {
