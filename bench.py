@@ -150,10 +150,14 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
         loss = one()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from diffsg_amd import parallel as par
+    ev = par.run_evidence(dev, dt, steps)            # ranks_seen, per-rank rates; the timed figure is the slowest rank's
+    dt = ev["max_seconds"]
+    # the bucket every rank holds after the step's all-reduce must be the same bits everywhere
+    ddpm(y, cond).backward()
+    ddpm.allreduce_grads()
+    eq, csum = par.bucket_checksum_equal(ddpm.grad_bucket)
+    opt.zero_grad()
     # algorithmic FLOP per sample: 3 x 2 x (trunk + cond) MACs with the time path tabulated over T rows
     f_train = 3 * 2 * (566_400 + 100_480)
     sps = world * B * steps / dt
@@ -206,7 +210,9 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
     return {"roofline": roof, "samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": B, "global_batch": world * B,
             "steps": steps, "T": 20, "final_loss": float(loss.detach()), "achieved_tflops": sps / world * f_train / 1e12,
             "frac_f32_mfma": sps / world * f_train / 1e12 / PEAK_F32_TFLOPS, "grad_bucket_bytes": int(ddpm.grad_bucket.numel()) * 4,
-            "collective": "one all_reduce(SUM)/world per step over the flat bucket" if world > 1 else "none (1 GPU)"}
+            "collective": "one all_reduce(AVG) per step over the flat bucket (RCCL)" if world > 1 else "none (1 GPU)",
+            "ranks_seen": ev["ranks_seen"], "per_rank_samples_per_s": [B * r for r in ev["per_rank_steps_per_s"]],
+            "bucket_checksum_equal": bool(eq), "bucket_checksum": csum}
 
 
 def main():
@@ -222,6 +228,7 @@ def main():
                     help="training rows per GPU: BASELINE config 4 is a global batch of 262144 over 8 GPUs")
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-f32-exact", action="store_true", help="skip the exact-float32 re-run of the same K steps")
     ap.add_argument("--warm-seconds", type=float, default=0.3, help="untimed clock warm-up before the timed steps")
     a = ap.parse_args()
 
@@ -275,11 +282,28 @@ def main():
     y0 = ddpm_k.sample(cond, a.omega, seed=2)   # exactly K timed steps
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from diffsg_amd import parallel as par
+    ev = par.run_evidence(dev, dt, K)
+    dt = ev["max_seconds"]
     assert torch.isfinite(y0).all()
+
+    # the same K steps on the exact-float32 kernels (v_mfma_f32_32x32x2_f32), so that a strict-fp32 figure always sits beside the
+    # split-f16 one.  Untimed warm-up first: the precision switch drops the captured step graphs.
+    f32_exact = None
+    if a.precision == "split_f16" and not a.no_f32_exact:
+        ddpm_k.model.set_precision("f32")
+        ddpm_w.sample(cond, a.omega, seed=1)
+        barrier()
+        t1 = time.perf_counter()
+        y1 = ddpm_k.sample(cond, a.omega, seed=2)
+        barrier()
+        ev1 = par.run_evidence(dev, time.perf_counter() - t1, K)
+        ddpm_k.model.set_precision("split_f16")
+        ddpm_w.sample(cond, a.omega, seed=1)          # back on the split path (re-captures its graphs) before anything else is timed
+        torch.cuda.synchronize()
+        f32_exact = {"value": world * K / ev1["max_seconds"], "unit": "steps/s", "ms_per_step": ev1["max_seconds"] / K * 1e3,
+                     "dtype": "f32 (v_mfma_f32_32x32x2_f32, every GEMM exact float32)",
+                     "max_rel_diff_vs_split": float((y1 - y0).abs().max() / y1.abs().max())}
 
     train = None
     if not a.no_train:
@@ -319,8 +343,11 @@ def main():
             traffic, valu_per_mfma = tj.get("hbm_bytes_per_launch"), tj.get("valu_per_mfma")
             tsrc = "imported, not measured in this run: profiles/traffic.json <- " + tj.get("summary", "profiles/") + " (kernel " + tj.get("kernel", "?") + ")"
         large = 2 * ((B + 31) // 32) > 512
-        kname = ("k_wide128_h<linear-shortcut> (4 tiles per workgroup, weight planes through an LDS ring)" if large else "k_resblock_c<128,linear-shortcut>") \
-            if split else "k_resblock<128,linear-shortcut>"
+        panel = 2 * ((B + 31) // 32) >= 2048
+        kname = (("k_panel128_h<linear-shortcut> (persistent, 8 tiles per workgroup, weight panels through LDS, operand preparation "
+                  "interleaved with the MFMA stream)" if panel else
+                  "k_wide128_h<linear-shortcut> (4 tiles per workgroup, weight planes through an LDS ring)") if large
+                 else "k_resblock_c<128,linear-shortcut>") if split else "k_resblock<128,linear-shortcut>"
         out = {
             "metric": "ddpm_reverse_sample_steps_per_sec_msr80c", "value": world * K / dt, "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True,
@@ -335,6 +362,7 @@ def main():
                          "mfma_unit": "v_mfma_f32_32x32x16_f16, 3 per float32 product (hi*hi + hi*lo + lo*hi)" if split else "v_mfma_f32_32x32x2_f32",
                          "algorithmic_tflops": ach, "frac_f32_equiv": ach / PEAK_F32_TFLOPS,
                          "traffic": traffic, "valu_per_mfma": valu_per_mfma, "traffic_source": tsrc,
+                         "traffic_note": (tj.get("note") if os.path.exists(tpath) else None),
                          "algorithmic_bytes_per_launch": by * B, "avg_launch_ms": avg_ms, "flop_per_launch": fl * B,
                          "executed_mfma_flop_per_launch": mfma_x * fl * B, "share_of_step": ms_sum / sum(r[3] for r in prof)},
             "step_roofline": {"f_alg_per_row": F_ALG, "achieved_tflops": F_ALG * B / (step_ms * 1e-3) / 1e12,
@@ -343,7 +371,10 @@ def main():
                               "achieved_gbs_alg": BYT_ALG * B / (step_ms * 1e-3) / 1e9,
                               "frac_hbm": BYT_ALG * B / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             "op_ms_per_step": {r[0]: r[3] / K for r in prof},
+            "ranks_seen": ev["ranks_seen"], "per_rank_steps_per_s": ev["per_rank_steps_per_s"],
         }
+        if f32_exact is not None:
+            out["f32_exact"] = f32_exact
         if train is not None:
             out["train"] = train
         if world == 1 and not a.no_cpu_baseline:

@@ -106,3 +106,33 @@ def broadcast_parameters(module, src=0):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+
+
+def run_evidence(device, seconds_this_rank, steps):
+    """What a multi-rank bench line needs to prove itself on hardware nobody has run it on before: `ranks_seen` (an all-reduced
+    count: every rank of the launch took part in a collective), the per-rank step rates (an all-gather of each rank's own
+    wall time for the same `steps`), and the slowest rank's time.  One process: the trivial record."""
+    rank, ws = world()
+    if ws == 1:
+        return {"ranks_seen": 1, "per_rank_steps_per_s": [steps / seconds_this_rank], "max_seconds": seconds_this_rank}
+    one = torch.ones(1, device=device, dtype=torch.float64)
+    dist.all_reduce(one)
+    t = torch.tensor([seconds_this_rank], device=device, dtype=torch.float64)
+    parts = [torch.zeros_like(t) for _ in range(ws)]
+    dist.all_gather(parts, t)
+    secs = [float(x.item()) for x in parts]
+    return {"ranks_seen": int(round(float(one.item()))), "per_rank_steps_per_s": [steps / x for x in secs], "max_seconds": max(secs)}
+
+
+def bucket_checksum_equal(bucket):
+    """After the gradient all-reduce every rank must hold the SAME bucket, bit for bit (same reduction result delivered to
+    everyone): a float64 sum and a wrap-around sum of the bit patterns, all-gathered and compared.  Returns (equal, checksum)."""
+    rank, ws = world()
+    bits = bucket.detach().view(torch.int32).to(torch.int64).sum()
+    val = bucket.detach().double().sum()
+    mine = torch.stack([bits.double(), val]).to(torch.float64)
+    if ws == 1:
+        return True, [float(mine[0]), float(mine[1])]
+    parts = [torch.zeros_like(mine) for _ in range(ws)]
+    dist.all_gather(parts, mine)
+    return all(torch.equal(p, parts[0]) for p in parts), [float(parts[0][0]), float(parts[0][1])]

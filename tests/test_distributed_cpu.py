@@ -118,6 +118,18 @@ def _worker(rank, ws, port, q):
         after = d2.model.final.weight.detach().clone()
         dist.all_gather(ws_, after)
         assert torch.equal(ws_[0], ws_[1]) and not torch.equal(after, before)
+        # ---- the evidence a multi-rank bench line carries (bench.py): every rank counted, per-rank rates gathered, and the
+        # post-all-reduce bucket identical bit for bit on every rank -- and the check FAILS when one rank's bucket differs
+        ev = par.run_evidence(torch.device("cpu"), 0.5 + 0.25 * rank, 10)
+        assert ev["ranks_seen"] == ws and len(ev["per_rank_steps_per_s"]) == ws
+        assert ev["max_seconds"] == 0.5 + 0.25 * (ws - 1) and ev["per_rank_steps_per_s"][0] == 20.0
+        eq, csum = par.bucket_checksum_equal(d.grad_bucket)
+        assert eq and len(csum) == 2
+        skew = d.grad_bucket.clone()
+        if rank == 1:
+            skew[7] = torch.nextafter(skew[7], torch.tensor(1e9))     # one ulp on one rank
+        eq2, _ = par.bucket_checksum_equal(skew)
+        assert not eq2
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback

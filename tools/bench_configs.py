@@ -31,5 +31,6 @@ for name, B, T, omega in (("msr3", 8192, 1000, 1.0), ("msr3", 512, 20, 500.0), (
         dt = min(dt, time.perf_counter() - t0)
     out.append(dict(config=name, B=B, T=T, omega=omega, ms_per_call=dt * 1e3, steps_per_s=T / dt, row_steps_per_s=B * T / dt,
                     finite=bool(torch.isfinite(y).all())))
-    print(out[-1])
+    print(json.dumps(out[-1]), file=sys.stderr)      # progress, one JSON object per line
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
+print(json.dumps(out))                               # stdout: ONE valid JSON document

@@ -35,3 +35,17 @@ for i, name in enumerate(names):
     tot += ms.value
     print(f"{name:16s} {ms.value*1e3:8.1f} us")
 print(f"{'sum':16s} {tot*1e3:8.1f} us")
+
+# the same operators launched ALTERNATELY, one launch per timing call: what a launch costs when another kernel ran just before it
+# (instruction cache, L2 state) -- the situation inside a reverse step
+if len(want) >= 2:
+    acc = {n: 0.0 for n in want}
+    rounds = 20
+    for r in range(rounds + 2):
+        for n in want:
+            _lib.check(L.dsg_time_op(hd, names.index(n), B, 1, ctypes.byref(ms), _lib.stream_ptr()))
+            if r >= 2:
+                acc[n] += ms.value
+    print("alternating, one launch per call:")
+    for n in want:
+        print(f"{n:16s} {acc[n] / rounds * 1e3:8.1f} us")
