@@ -105,7 +105,12 @@ def load_test_msr(ckpt_path, dataset_path=DEFAULT_DATASET, T=20, omega=500, batc
     diffusion_model.to(device)
     X = torch.tensor(X_test, dtype=torch.float32)
     # each 512-row chunk is its own sample() call, as in the reference (:273-279): the early-step renorm is per call
-    Y_pred = torch.cat([diffusion_model.sample_checked(X[i:i + batch_size].to(device), omega) for i in range(0, len(X), batch_size)])
+    # the reference's loop of independent `batch_size`-row sample() calls (own noise, own early-step renorm per chunk), run as
+    # one set of launches; chunk sizes that are not a multiple of the 32-row tile keep the serial calls
+    if batch_size % 32 == 0:
+        Y_pred = diffusion_model.sample_chunked_checked(X.to(device), omega, batch_size)
+    else:
+        Y_pred = torch.cat([diffusion_model.sample_checked(X[i:i + batch_size].to(device), omega) for i in range(0, len(X), batch_size)])
     Xt = X.to(device) * (custom_config['scaler_max'] - custom_config['scaler_min']) + custom_config['scaler_min']
     Yt = torch.tensor(Y_test, dtype=torch.float32, device=device)
     from .decode import msr_rate

@@ -196,9 +196,15 @@ struct dsg_handle {
     CondTile* ctile_dev = nullptr; int ctile_n = 0; const float* ctile_key = nullptr; size_t ctile_cap = 0;
     std::vector<FusedOpH> fusedh_host;
 
-    // cached step graphs
+    // cached step graphs: per-step pair (with / without the renorm kernels), keyed by (rows, chunks); and ONE graph of a whole
+    // T-step loop for short schedules, keyed by (rows, chunks, T)
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
-    int g_rows = -1;
+    int g_rows = -1, g_chunks = -1;
+    hipGraphExec_t gloop = nullptr;
+    int gl_rows = -1, gl_chunks = -1, gl_T = -1;
+    // chunked calls (dsg_sample_chunked): per-chunk Philox seeds and per-chunk renorm partials
+    unsigned long long* seeds_dev = nullptr; int seeds_cap = 0;
+    double* red_chunks = nullptr; int red_chunks_cap = 0;
 
     // training workspace
     size_t tr_per_tile = 0;      // floats per tile
@@ -366,7 +372,9 @@ void carve(dsg_handle* h) {
 void free_graphs(dsg_handle* h) {
     for (int i = 0; i < 2; ++i)
         if (h->gexec[i]) { (void)hipGraphExecDestroy(h->gexec[i]); h->gexec[i] = nullptr; }
-    h->g_rows = -1;
+    if (h->gloop) { (void)hipGraphExecDestroy(h->gloop); h->gloop = nullptr; }
+    h->g_rows = h->g_chunks = -1;
+    h->gl_rows = h->gl_chunks = h->gl_T = -1;
 }
 
 constexpr int kMaxGmax = 256;   // distinct gradient tensors whose max|G| is tracked (3 per block + 1 per Linear)
@@ -1410,6 +1418,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         }
         h->fuse_lo = best_lo; h->fuse_hi = best_hi;
     }
+    if (const char* e = getenv("DSG_AB_PANEL_MIN")) h->panel_min_tiles = atoi(e);   // TEMPORARY: same-box A/B of the panel kernels
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -1450,6 +1459,8 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
 }
 
 void dsg_destroy(dsg_handle* h) {
+    if (h && h->seeds_dev) (void)hipFree(h->seeds_dev);
+    if (h && h->red_chunks) (void)hipFree(h->red_chunks);
     if (h)
         for (auto& e : h->tev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -1702,7 +1713,7 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
 // (a rank whose graphs are already cached would not issue it: the all-reduces would pair up wrongly or hang) and the caller's
 // `renorm_stats` pointer would be baked into the cached graph and outlive the hook.
 static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, bool renorm, hipStream_t s,
-                        hipEvent_t* ev = nullptr, bool use_hook = true) {
+                        hipEvent_t* ev = nullptr, bool use_hook = true, int chunks = 1, size_t chunk_n = 0) {
     if (ev) {  // DSG_SAMPLE_PROFILE: one event pair per operator launch
         const bool fuse = h->fuse_hi - h->fuse_lo >= 2;
         bool skip_next = false;
@@ -1732,9 +1743,13 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
         hipLaunchKernelGGL(k_renorm_apply_stats, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->renorm_stats);
         hipLaunchKernelGGL(k_record, dim3(ublocks), dim3(256), 0, s, u.y, u.n, u.cp, u.step_ptr);
     } else if (renorm) {   // the record is of the renormalised y (MSR.py:136-141): separate launches on these (at most 4) steps
-        hipLaunchKernelGGL(k_renorm_sum, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red);
-        hipLaunchKernelGGL(k_renorm_sqdiff, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
-        hipLaunchKernelGGL(k_renorm_apply, dim3(kRedBlocks), dim3(256), 0, s, u.y, u.n, h->red, h->red + kRedBlocks);
+        // one call: the handle's two partial rows; chunked: [chunks][kRedBlocks] twice, one grid row per chunk
+        double* p1 = chunks > 1 ? h->red_chunks : h->red;
+        double* p2 = chunks > 1 ? h->red_chunks + (size_t)chunks * kRedBlocks : h->red + kRedBlocks;
+        const size_t cn = chunks > 1 ? chunk_n : (size_t)0;
+        hipLaunchKernelGGL(k_renorm_sum, dim3(kRedBlocks, chunks), dim3(256), 0, s, (const float*)u.y, u.n, p1, cn);
+        hipLaunchKernelGGL(k_renorm_sqdiff, dim3(kRedBlocks, chunks), dim3(256), 0, s, (const float*)u.y, u.n, (const double*)p1, p2, cn);
+        hipLaunchKernelGGL(k_renorm_apply, dim3(kRedBlocks, chunks), dim3(256), 0, s, u.y, u.n, (const double*)p1, (const double*)p2, cn);
         hipLaunchKernelGGL(k_record, dim3(ublocks), dim3(256), 0, s, u.y, u.n, u.cp, u.step_ptr);
     }
     HIPCK(hipGetLastError());
@@ -1758,15 +1773,43 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
     return dsg_sample_rec(h, cond, y_T, noise, seed, omega, coef, T, out, B, flags, nullptr, nullptr, stream);
 }
 
-int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed, float omega,
-                   const float* coef, int T, float* out, int B, int flags, float* rec_y, float* rec_eps, void* stream) {
+namespace {
+constexpr int kWholeLoopMaxT = 64;      // schedules up to this length replay as ONE graph (T x the step's nodes)
+
+// chunk_rows = 0: one call over B rows.  Otherwise the batch is ceil(B / chunk_rows) independent calls (own seed, own renorm
+// statistics), chunk_rows a multiple of 32 so that every chunk starts on a row tile.
+int sample_impl(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed, const unsigned long long* seeds_host,
+                int chunk_rows, float omega, const float* coef, int T, float* out, int B, int flags, float* rec_y, float* rec_eps, hipStream_t s) {
     if (check_bound(h)) return 1;
     if (B < 1 || T < 1) return fail("B and T must be >= 1");
     if (!coef || !cond || !out) return fail("dsg_sample: null pointer argument");
+    const int chunks = chunk_rows > 0 ? cdiv(B, chunk_rows) : 1;
+    if (chunk_rows > 0 && (chunk_rows % 32 != 0)) return fail("dsg_sample_chunked: chunk_rows must be a multiple of 32 (a row tile)");
+    if (chunks > 1 && h->renorm_fn) return fail("dsg_sample_chunked: a renorm hook (sharded global renorm) and chunking exclude each other");
+    if (chunks > 1 && !seeds_host && !(y_T && (noise || T <= 2))) return fail("dsg_sample_chunked: per-chunk seeds are required");
     if (ensure_workspace(h, B, T)) return 1;
-    hipStream_t s = (hipStream_t)stream;
     const int D = h->d.input_dim, CG = groups_of(h->d.cond_dim), tpp = cdiv(B, 32);
     const size_t n = (size_t)B * D;
+    const size_t chunk_n = chunks > 1 ? (size_t)chunk_rows * D : 0;
+    if (chunks > 1) {
+        if (chunks > h->seeds_cap) {
+            HIPCK(hipStreamSynchronize(s));
+            if (h->seeds_dev) (void)hipFree(h->seeds_dev);
+            HIPCK(hipMalloc(&h->seeds_dev, (size_t)chunks * sizeof(unsigned long long)));
+            h->seeds_cap = chunks;
+        }
+        if (chunks > h->red_chunks_cap) {
+            HIPCK(hipStreamSynchronize(s));
+            if (h->red_chunks) (void)hipFree(h->red_chunks);
+            HIPCK(hipMalloc(&h->red_chunks, (size_t)2 * chunks * kRedBlocks * sizeof(double)));
+            h->red_chunks_cap = chunks;
+            free_graphs(h);                        // the captured renorm kernels hold the old buffer
+        }
+        std::vector<unsigned long long> sd(chunks, 0ull);
+        if (seeds_host) sd.assign(seeds_host, seeds_host + chunks);
+        HIPCK(hipMemcpyAsync(h->seeds_dev, sd.data(), (size_t)chunks * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        HIPCK(hipStreamSynchronize(s));            // `sd` is pageable host memory
+    }
 
     // per-call setup: time table for all T steps, condition fragments, start state, step counter
     hipLaunchKernelGGL(k_linspace_t, dim3(cdiv(T, 256)), dim3(256), 0, s, h->tvals, T);
@@ -1776,10 +1819,11 @@ int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const flo
     // condition embeddings of every block, once per call: cond is the same in all T steps (MSR.py:126-127)
     run_cond_embed(h, B, s);
     if (y_T) HIPCK(hipMemcpyAsync(h->ywork, y_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else if (chunks > 1) hipLaunchKernelGGL(k_randn_chunked, dim3(2048), dim3(256), 0, s, h->ywork, n, (const unsigned long long*)h->seeds_dev, chunk_n / 4, 0xFFFFFFFFu);
     else hipLaunchKernelGGL(k_randn, dim3(2048), dim3(256), 0, s, h->ywork, n, seed, 0xFFFFFFFFu);
     // step counter (every step's first operator decrements it before anything reads it: step T-1 first) and the call block go
     // to the device as kernel arguments: no pageable copy, no synchronise - consecutive calls pipeline on the stream
-    const CallParams cp{noise, coef, omega, T, seed, rec_y, rec_eps};
+    const CallParams cp{noise, coef, omega, T, seed, rec_y, rec_eps, chunk_n / 4, chunks > 1 ? h->seeds_dev : nullptr};
     hipLaunchKernelGGL(k_set_call, dim3(1), dim3(64), 0, s, h->step_dev, reinterpret_cast<CallParams*>(h->call_dev), cp, T);
 
     RunCtx c{B, 2, tpp, h->ywork, h->eps, h->step_dev, nullptr, false, true};
@@ -1797,20 +1841,39 @@ int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const flo
         std::vector<hipEvent_t> ev(2 * nops);
         for (auto& e : ev) HIPCK(hipEventCreate(&e));
         int rc = 0;
-        for (int k = 0; k < T && !rc; ++k) rc = enqueue_step(h, c, u, k < n_renorm, s, ev.data());
+        for (int k = 0; k < T && !rc; ++k) rc = enqueue_step(h, c, u, k < n_renorm, s, ev.data(), true, chunks, chunk_n);
         for (auto& e : ev) (void)hipEventDestroy(e);
         if (rc) return 1;
     } else if (flags & DSG_SAMPLE_NO_GRAPH) {
         for (int k = 0; k < T; ++k)
-            if (enqueue_step(h, c, u, k < n_renorm, s)) return 1;
+            if (enqueue_step(h, c, u, k < n_renorm, s, nullptr, true, chunks, chunk_n)) return 1;
+    } else if (T <= kWholeLoopMaxT && !h->renorm_fn) {
+        // short schedule (the shipped T = 20): the WHOLE reverse loop is one graph and one launch -- the step index is a device
+        // counter and everything per call sits in device memory, so the graph depends only on (rows, chunks, T)
+        if (!(h->gloop && h->gl_rows == B && h->gl_chunks == chunks && h->gl_T == T)) {
+            if (h->gloop) { (void)hipGraphExecDestroy(h->gloop); h->gloop = nullptr; }
+            hipGraph_t g = nullptr;
+            HIPCK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            int rc = 0;
+            for (int k = 0; k < T && !rc; ++k) rc = enqueue_step(h, c, u, k < n_renorm, h->cap_stream, nullptr, /*use_hook=*/false, chunks, chunk_n);
+            hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+            if (rc) return 1;
+            if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
+            e = hipGraphInstantiate(&h->gloop, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
+            h->gl_rows = B; h->gl_chunks = chunks; h->gl_T = T;
+        }
+        HIPCK(hipGraphLaunch(h->gloop, s));
     } else {
-        // the per-step graph depends only on the workspace (batch size); everything per call is in device memory
-        if (!(h->gexec[0] && h->g_rows == B)) {
-            free_graphs(h);
+        // the per-step graph depends only on the workspace (batch size, chunk count); everything per call is in device memory
+        if (!(h->gexec[0] && h->g_rows == B && h->g_chunks == chunks)) {
+            for (int i = 0; i < 2; ++i)
+                if (h->gexec[i]) { (void)hipGraphExecDestroy(h->gexec[i]); h->gexec[i] = nullptr; }
             for (int variant = 0; variant < 2; ++variant) {  // 0: with renorm, 1: without
                 hipGraph_t g = nullptr;
                 HIPCK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-                const int rc = enqueue_step(h, c, u, variant == 0, h->cap_stream, nullptr, /*use_hook=*/false);
+                const int rc = enqueue_step(h, c, u, variant == 0, h->cap_stream, nullptr, /*use_hook=*/false, chunks, chunk_n);
                 hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
                 if (rc) return 1;
                 if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -1818,7 +1881,7 @@ int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const flo
                 (void)hipGraphDestroy(g);
                 if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
             }
-            h->g_rows = B;
+            h->g_rows = B; h->g_chunks = chunks;
         }
         for (int k = 0; k < T; ++k) {
             if (k < n_renorm && h->renorm_fn) {          // the hook calls back into the host: these (<= 4) steps run eagerly
@@ -1830,6 +1893,18 @@ int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const flo
     }
     HIPCK(hipMemcpyAsync(out, h->ywork, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
+}
+}  // namespace
+
+int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed, float omega,
+                   const float* coef, int T, float* out, int B, int flags, float* rec_y, float* rec_eps, void* stream) {
+    return sample_impl(h, cond, y_T, noise, seed, nullptr, 0, omega, coef, T, out, B, flags, rec_y, rec_eps, (hipStream_t)stream);
+}
+
+int dsg_sample_chunked(dsg_handle* h, const float* cond, const float* y_T, const float* noise, const unsigned long long* seeds, int chunk_rows,
+                       float omega, const float* coef, int T, float* out, int B, int flags, void* stream) {
+    if (chunk_rows < 1) return fail("dsg_sample_chunked: chunk_rows must be >= 1");
+    return sample_impl(h, cond, y_T, noise, seeds ? seeds[0] : 0ull, seeds, chunk_rows, omega, coef, T, out, B, flags, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

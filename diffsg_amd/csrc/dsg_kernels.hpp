@@ -827,7 +827,15 @@ struct CallParams {
     unsigned long long seed;
     float* rec_y;         // record_denoise_path (MSR.py:139-141): [T][n] y after each step (after the renorm), or null
     float* rec_eps;       // [T][n] guided eps of each step, or null
+    // chunked call (dsg_sample_chunked): the batch is a sequence of independent sample() calls of `chunk_n4` quads each (the last
+    // one may be shorter): chunk c draws from Philox stream seeds[c] with chunk-local element indices, exactly as its own call would
+    size_t chunk_n4;                      // 0: one call
+    const unsigned long long* seeds;      // device [chunks]
 };
+__device__ __forceinline__ void chunk_of(const CallParams& cp, size_t i4, unsigned long long& seed, size_t& local) {
+    seed = cp.seed; local = i4;
+    if (cp.chunk_n4) { const size_t c = i4 / cp.chunk_n4; seed = cp.seeds[c]; local = i4 - c * cp.chunk_n4; }
+}
 
 __global__ void k_set_call(int* step, CallParams* dst, const CallParams cp, int start) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { *step = start; *dst = cp; }
@@ -858,7 +866,7 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a) {
                          reinterpret_cast<uintptr_t>(rec) | reinterpret_cast<uintptr_t>(recy)) & 15) == 0;
     for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
         float zz[4] = {0.f, 0.f, 0.f, 0.f};
-        if (noisy && !zrow) normal4(cp.seed, (uint32_t)step, i4, zz);
+        if (noisy && !zrow) { unsigned long long sd; size_t li; chunk_of(cp, i4, sd, li); normal4(sd, (uint32_t)step, li, zz); }
         if (quads) {
             const float4 e0 = ld4(a.eps + i4 * 4), e1 = ld4(a.eps + a.n + i4 * 4), yv = ld4(a.y + i4 * 4);
             if (zrow) { const float4 zv = ld4(zrow + i4 * 4); zz[0] = zv.x; zz[1] = zv.y; zz[2] = zv.z; zz[3] = zv.w; }
@@ -902,6 +910,18 @@ __global__ void k_randn(float* __restrict__ y, size_t n, unsigned long long seed
     }
 }
 
+// start state of a chunked call: chunk c = k_randn(seed[c]) on its own elements
+__global__ void k_randn_chunked(float* __restrict__ y, size_t n, const unsigned long long* __restrict__ seeds, size_t chunk_n4, unsigned stream) {
+    const size_t n4 = (n + 3) / 4;
+    for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
+        const size_t c = i4 / chunk_n4;
+        float zz[4];
+        normal4(seeds[c], stream, i4 - c * chunk_n4, zz);
+        for (int p = 0; p < 4; ++p)
+            if (i4 * 4 + p < n) y[i4 * 4 + p] = zz[p];
+    }
+}
+
 // device-side trajectory ring (replaces the reference's per-step .cpu().numpy(), MSR.py:139-141); no-op when disabled
 __global__ void k_record(const float* __restrict__ y, size_t n, const CallParams* __restrict__ cp, const int* __restrict__ step_ptr) {
     float* dst = cp->rec_y;
@@ -929,17 +949,25 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
     return t;
 }
 
-__global__ __launch_bounds__(256) void k_renorm_sum(const float* __restrict__ y, size_t n, double* __restrict__ part) {
+// Chunked form (gridDim.y = chunks, dsg_sample_chunked): block (x, c) does for chunk c -- elements [c * chunk_n, min(n, (c + 1) * chunk_n))
+// -- exactly what block x of a one-call launch does for the whole tensor: same strides, same order of additions, so a chunk's
+// statistics are bit-identical to those of its own sample() call.
+__device__ __forceinline__ void renorm_chunk(const float*& y, size_t& n, size_t chunk_n) {
+    if (chunk_n) { const size_t lo = (size_t)blockIdx.y * chunk_n; y += lo; n = n - lo < chunk_n ? n - lo : chunk_n; }
+}
+__global__ __launch_bounds__(256) void k_renorm_sum(const float* y, size_t n, double* __restrict__ part, size_t chunk_n = 0) {
     __shared__ double sm[4];
+    renorm_chunk(y, n, chunk_n); part += (size_t)blockIdx.y * kRedBlocks;
     double s = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += (double)y[i];
     s = block_sum(s, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(256) void k_renorm_sqdiff(const float* __restrict__ y, size_t n, const double* __restrict__ part,
-                                                       double* __restrict__ part2) {
+__global__ __launch_bounds__(256) void k_renorm_sqdiff(const float* y, size_t n, const double* __restrict__ part,
+                                                       double* __restrict__ part2, size_t chunk_n = 0) {
     __shared__ double sm[4];
+    renorm_chunk(y, n, chunk_n); part += (size_t)blockIdx.y * kRedBlocks; part2 += (size_t)blockIdx.y * kRedBlocks;
     double tot = 0.0;
     for (int i = 0; i < kRedBlocks; ++i) tot += part[i];
     const double mean = tot / (double)n;
@@ -978,8 +1006,10 @@ __global__ __launch_bounds__(256) void k_renorm_apply_stats(float* __restrict__ 
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         y[i] = (y[i] - mean) / sd;
 }
-__global__ __launch_bounds__(256) void k_renorm_apply(float* __restrict__ y, size_t n, const double* __restrict__ part,
-                                                      const double* __restrict__ part2) {
+__global__ __launch_bounds__(256) void k_renorm_apply(float* y, size_t n, const double* __restrict__ part,
+                                                      const double* __restrict__ part2, size_t chunk_n = 0) {
+    { const float* yc = y; renorm_chunk(yc, n, chunk_n); y = const_cast<float*>(yc); }
+    part += (size_t)blockIdx.y * kRedBlocks; part2 += (size_t)blockIdx.y * kRedBlocks;
     double tot = 0.0, tot2 = 0.0;
     for (int i = 0; i < kRedBlocks; ++i) { tot += part[i]; tot2 += part2[i]; }
     const float mean = (float)(tot / (double)n);

@@ -127,6 +127,60 @@ class DDPMCore(nn.Module):
         return out
 
     @torch.no_grad()
+    def sample_chunked(self, cond, omega=1.0, chunk_rows=512, *, seeds=None, y_T=None, noise=None, use_graph=True):
+        """The reference's evaluation shape in one set of launches: `cond` is sampled as consecutive `chunk_rows`-row slices, each
+        an independent `sample()` call (own start state and noise, own early-step renorm statistics; classifier_free_MSR.py:257,
+        273-279).  Row for row bit-identical to `torch.cat([self.sample(cond[i:i + chunk_rows], omega, seed=seeds[k]) ...])`,
+        `seeds` = one Philox seed per chunk (default: drawn from torch's global generator, one per chunk, in chunk order)."""
+        import ctypes
+        if not cond.is_cuda:
+            raise RuntimeError("DDPM.sample_chunked: `cond` is not on a HIP device; libdiffsg_hip has no CPU path")
+        hd = self.model.native_handle()
+        B, D, T = cond.shape[0], self.model.cfg["input_dim"], self.T
+        if chunk_rows % 32 != 0:
+            raise ValueError("chunk_rows must be a multiple of 32")
+        nch = (B + chunk_rows - 1) // chunk_rows
+        if nch <= 1:
+            return self.sample(cond, omega, y_T=y_T, noise=noise, seed=None if seeds is None else int(seeds[0]), use_graph=use_graph)
+        cond = cond.detach().to(torch.float32).contiguous()
+        dev = cond.device
+        if seeds is None:
+            seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(nch)]
+        if len(seeds) != nch:
+            raise ValueError(f"{nch} chunks need {nch} seeds")
+        if y_T is not None:
+            y_T = y_T.to(dev, torch.float32).reshape(B, D).contiguous()
+        if noise is not None:
+            noise = noise.to(dev, torch.float32).contiguous()
+            if tuple(noise.shape) != (max(T - 2, 0), B, D):
+                raise ValueError(f"noise must have shape ({max(T - 2, 0)}, {B}, {D})")
+        sd = (ctypes.c_ulonglong * nch)(*[int(x) & (2 ** 64 - 1) for x in seeds])
+        out = torch.empty(B, D, device=dev, dtype=torch.float32)
+        zptr = _lib.ptr(noise) if (noise is not None and noise.numel()) else _lib.ptr(None)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().dsg_sample_chunked(hd, _lib.ptr(cond), _lib.ptr(y_T), zptr, sd, int(chunk_rows), float(omega),
+                                                     _lib.ptr(self._coef_table()), T, _lib.ptr(out), B, 0 if use_graph else 1,
+                                                     _lib.stream_ptr()))
+        return out
+
+    def sample_chunked_checked(self, cond, omega=1.0, chunk_rows=512, **kw):
+        """`sample_chunked` with the fp16 range check of `sample_checked` (same seeds on the exact-f32 repeat)."""
+        import warnings
+        B = cond.shape[0]
+        nch = max((B + chunk_rows - 1) // chunk_rows, 1)
+        if kw.get("seeds") is None:
+            kw["seeds"] = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(nch)]
+        y = self.sample_chunked(cond, omega, chunk_rows, **kw)
+        if B and self.model.range_exceeded():
+            warnings.warn("DDPM.sample_chunked: activations exceeded the fp16 range of the split-f16 path; repeating the call with "
+                          "precision='f32'")
+            self.model.set_precision("f32")
+            try:
+                y = self.sample_chunked(cond, omega, chunk_rows, **kw)
+            finally:
+                self.model.set_precision("split_f16")
+        return y
+
     def sample_checked(self, cond, omega=1.0, **kw):
         """`sample`, then the fp16 range check of the split path (synchronises): if a raw activation left fp16's range
         (very large omega on an untrained net), the call is repeated on the exact-f32 kernels with the same seed -- the

@@ -96,7 +96,8 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
  *         computed by the caller from the registered buffers so that their float64->float32 casts are kept);
  *   y_T   [B][D] start state, or NULL to draw it on the device (Philox, `seed`);
  *   noise [T-2][B][D] the z of steps i = T-1 .. 2 in that order, or NULL to draw on the device;
- *   flags DSG_SAMPLE_NO_GRAPH: launch eagerly instead of replaying the captured per-step hipGraph. */
+ *   flags DSG_SAMPLE_NO_GRAPH: launch eagerly instead of replaying the captured graph (schedules of up to 64 steps are ONE graph
+ *         of the whole reverse loop, longer ones replay a per-step graph T times; the step index is a device counter). */
 #define DSG_SAMPLE_NO_GRAPH 1
 /*         DSG_SAMPLE_PROFILE: eager launch with one HIP-event pair around every operator launch on `stream`
  *         (synchronises once per step); read the totals back with dsg_op_profile. */
@@ -110,6 +111,16 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
 int dsg_sample_rec(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed,
                    float omega, const float* coef, int T, float* out, int B, int flags, float* rec_y, float* rec_eps,
                    void* stream);
+
+/* The reference evaluates a test set as a sequence of INDEPENDENT sample() calls over consecutive `chunk_rows`-row slices
+ * (classifier_free_MSR.py:257,273-279: 512 rows per call; CO :344-366, NU :318-336): every chunk draws its own start state and
+ * noise and standardises the early steps with its OWN statistics.  dsg_sample_chunked runs ceil(B / chunk_rows) such calls in one
+ * set of launches: chunk c uses the Philox stream seeds[c] (host array, one per chunk) with chunk-local element indices and a
+ * segmented renorm reduction, so its rows are bit-identical to dsg_sample(cond + c * chunk_rows * C, ..., seeds[c], ...) on that
+ * slice.  chunk_rows must be a multiple of 32; the last chunk may be shorter.  y_T / noise, when given, cover the whole batch
+ * ([B][D], [T-2][B][D]).  Not available while a renorm hook is installed. */
+int dsg_sample_chunked(dsg_handle* h, const float* cond, const float* y_T, const float* noise, const unsigned long long* seeds,
+                       int chunk_rows, float omega, const float* coef, int T, float* out, int B, int flags, void* stream);
 
 /* One training step's forward + backward: loss = DDPM.forward(y, cond) (classifier_free_MSR.py:100-112) and
  * d(loss)/d(theta) for every denoiser tensor, as `loss.backward()` produces them (classifier_free_MSR.py:223-224).

@@ -430,6 +430,63 @@ def test_global_renorm_reraises_a_failed_reduction():
             d.sample(cond, 1.0, seed=1)
 
 
+@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("name,B,chunk,T", [("msr3", 3000, 512, 20), ("msr80", 1100, 512, 6), ("nu3", 200, 64, 5), ("co3", 96, 32, 70)])
+def test_chunked_sampling_is_the_per_chunk_calls_bit_for_bit(name, B, chunk, T, policy):
+    """dsg_sample_chunked (the reference's evaluation loop, classifier_free_MSR.py:257,273-279, as one set of launches): every chunk
+    -- own Philox stream, own early-step renorm statistics, ragged last chunk -- equals its own sample() call bit for bit, with
+    device noise and with injected noise, for a whole-loop graph (T <= 64) and for per-step graph replays (T = 70)."""
+    plan, p = synth_params(name, 31)
+    cfg = CONFIGS[name]
+    d = make_ddpm(name, p, T, policy)
+    g = torch.Generator().manual_seed(8)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    nch = (B + chunk - 1) // chunk
+    seeds = [1000 + 7 * k for k in range(nch)]
+    whole = d.sample_chunked(cond, 1.0, chunk, seeds=seeds)
+    parts = torch.cat([d.sample(cond[k * chunk:(k + 1) * chunk], 1.0, seed=seeds[k]) for k in range(nch)])
+    assert torch.equal(whole, parts)
+    # a chunked call differs from ONE call on the whole batch (different noise streams, different renorm statistics)
+    assert not torch.equal(whole, d.sample(cond, 1.0, seed=seeds[0]))
+    # injected start state and noise
+    D = cfg["input_dim"]
+    y_T = torch.randn(B, D, generator=g)
+    z = torch.randn(max(T - 2, 0), B, D, generator=g)
+    whole = d.sample_chunked(cond, 2.0, chunk, y_T=y_T, noise=z, seeds=seeds)
+    parts = torch.cat([d.sample(cond[k * chunk:(k + 1) * chunk], 2.0, y_T=y_T[k * chunk:(k + 1) * chunk], noise=z[:, k * chunk:(k + 1) * chunk])
+                       for k in range(nch)])
+    assert torch.equal(whole, parts)
+    # eager launches give the same bits as the graphs
+    assert torch.equal(d.sample_chunked(cond, 1.0, chunk, seeds=seeds, use_graph=False), d.sample_chunked(cond, 1.0, chunk, seeds=seeds))
+
+
+def test_chunked_evaluation_is_faster_than_serial_calls():
+    """A 3 000-row MSR-3c evaluation (six 512-row chunks, T = 20, the shipped load_test_msr shape): the chunked call against the
+    reference's loop of six calls -- at least 3x (six latency-bound 32-wave launches share one set of launches)."""
+    import time
+    plan, p = synth_params("msr3", 31)
+    d = make_ddpm("msr3", p, 20)
+    cond = torch.rand(3000, 3).cuda()
+    seeds = list(range(6))
+
+    def serial():
+        return torch.cat([d.sample(cond[i:i + 512], 500.0, seed=seeds[i // 512]) for i in range(0, 3000, 512)])
+
+    def chunked():
+        return d.sample_chunked(cond, 500.0, 512, seeds=seeds)
+    for f in (serial, chunked):
+        f(); torch.cuda.synchronize()
+    ts = {}
+    for name, f in (("serial", serial), ("chunked", chunked)):
+        best = 1e9
+        for _ in range(5):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        ts[name] = best
+    print(f"serial {ts['serial'] * 1e3:.2f} ms, chunked {ts['chunked'] * 1e3:.2f} ms: {ts['serial'] / ts['chunked']:.1f}x")
+    assert ts["serial"] / ts["chunked"] >= 3.0, ts
+
+
 def test_sample_full_size_properties():
     """A BASELINE-size call (B=8192, D=C=80) checked through size-independent properties:
     duplicated rows give duplicated outputs (rows only couple through the global renorm statistics, which a
