@@ -6,6 +6,7 @@
 #include "dsg_split.hpp"
 #include "dsg_wide.hpp"
 #include "dsg_panel.hpp"
+#include "dsg_res64.hpp"
 #include "dsg_train_split.hpp"
 #include "dsg_eval.hpp"
 #include "dsg_labelgen.hpp"
@@ -672,6 +673,12 @@ void launch_panel128(const dsg_handle* h, const BlockLinArgsH& w, hipStream_t s)
     hipLaunchKernelGGL((k_panel128_h<SC, EPI, NTO>), grid, block, 0, s, w, ngroups);
 }
 
+// 64-wide blocks of large sampling launches: the block's planes resident in LDS (dsg_res64.hpp)
+bool res64_lds_ok(const dsg_handle* h, const ResP& r, const BlockArgs& b) {
+    return r.N == 64 && b.in0.groups == 8 && (b.in1.groups == 0 || b.in1.groups == 8) && (b.in1.groups != 0) == r.sclin && b.cond_pre && !b.ts &&
+           !b.save_h1 && b.tiles_per_pass * 2 >= b.ntiles && b.ntiles >= h->panel_min_tiles && b.ntiles > h->coop_max_tiles;
+}
+
 void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStream_t s) {
     BlockArgsH a;
     fill_block_args_h(h, r, b, a);
@@ -687,6 +694,16 @@ void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStr
             if (r.sclin) hipLaunchKernelGGL((k_resblock_c<64, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_resblock_c<64, false>), grid, block, 0, s, a);
         }
+        return;
+    }
+    if (res64_lds_ok(h, r, a.b)) {
+        const int ngroups = cdiv(a.b.ntiles, kR64Waves);
+        const dim3 grid(ngroups < h->num_cus ? ngroups : h->num_cus), block(kR64Waves * 64);
+        BlockLinArgsH w;
+        memset(&w, 0, sizeof w);
+        w.b = a; w.store_block_out = 1;
+        if (r.sclin) hipLaunchKernelGGL((k_res64_lds<true, 0>), grid, block, 0, s, w, ngroups);
+        else hipLaunchKernelGGL((k_res64_lds<false, 0>), grid, block, 0, s, w, ngroups);
         return;
     }
     if (panel128_ok(h, r, a.b)) {
@@ -741,6 +758,17 @@ bool launch_res_lin_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, co
     a.dbg = 0;
     const dim3 grid(cdiv(b.ntiles, kWavesPerBlock)), block(256);
     const int NTO = cdiv(l.l.N, 32);
+    if (res64_lds_ok(h, r, b) && l.l.K == 64 && !final_op) {
+        const int ngroups = cdiv(b.ntiles, kR64Waves);
+        const dim3 g64(ngroups < h->num_cus ? ngroups : h->num_cus), b64(kR64Waves * 64);
+#define DSG_TRY64(SC_, NTO_)                                                                                 \
+    if (r.sclin == SC_ && NTO == NTO_) {                                                                     \
+        hipLaunchKernelGGL((k_res64_lds<SC_, NTO_>), g64, b64, 0, s, a, ngroups);                            \
+        return true;                                                                                         \
+    }
+        DSG_TRY64(true, 4) DSG_TRY64(true, 2) DSG_TRY64(false, 2) DSG_TRY64(false, 1)
+#undef DSG_TRY64
+    }
     if (panel128_ok(h, r, b) && l.l.K == 128) {
 #define DSG_TRYP(SC_, EPI_, NTO_)                                                                            \
     if (r.sclin == SC_ && (final_op ? 2 : 1) == EPI_ && NTO == NTO_) {                                       \

@@ -154,6 +154,9 @@ __device__ __forceinline__ float silu_scaled_l2s(float up) {
     constexpr float k = -1.44269504088896341f / kActScale;
     return up * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(up), k, k));
 }
+#ifndef DSG_PANEL_VERTICAL
+#define DSG_PANEL_VERTICAL 1
+#endif
 #ifndef DSG_PANEL_VDBG
 #define DSG_PANEL_VDBG 0      // measurement only: 1 = operands are the raw bits of x (no VALU), 2 = no split, 4 = no transcendentals
 #endif
@@ -177,11 +180,24 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
         lds_cf4* const bl = (lds_cf4*)(beta + 4 * h);
         const f32x4 g0 = gl[4 * S], b0 = bl[4 * S], g1 = gl[4 * S + 2], b1 = bl[4 * S + 2];
         const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        // stage by stage over the eight values ("vertical"): hipcc otherwise walks the values pair by pair, and every
+        // transcendental waits for the one issued just before it (exp -> fma -> rcp -> mul: four dependent stages per pair)
+        constexpr float kk = -1.44269504088896341f / kActScale;
+        float u[8], p[8], r[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float u = fmaf(fmaf(x[q], c, d), g[q], b[q]);
-            v[q] = (DSG_PANEL_VDBG & 4) ? u * fmaf(u, 0.25f, 0.5f) : silu_scaled_l2s(u);
-        }
+        for (int q = 0; q < 8; ++q) u[q] = fmaf(fmaf(x[q], c, d), g[q], b[q]);
+        if (DSG_PANEL_VERTICAL) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) p[q] = (DSG_PANEL_VDBG & 4) ? u[q] : __builtin_amdgcn_exp2f(u[q]);
+        if (DSG_PANEL_VERTICAL) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = fmaf(p[q], kk, kk);
+        if (DSG_PANEL_VERTICAL) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = (DSG_PANEL_VDBG & 4) ? r[q] : __builtin_amdgcn_rcpf(r[q]);
+        if (DSG_PANEL_VERTICAL) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = u[q] * r[q];
     } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = x[q] * kRawScale;

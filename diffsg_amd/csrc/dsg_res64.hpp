@@ -1,0 +1,322 @@
+// 64-wide ResidualBlocks for LARGE launches: the WHOLE block's weight planes live in LDS for the whole launch.
+//
+// Why (profiles/r02d_pmc_summary.txt): k_resblock_h<64,*> gives every wave its own copy of every plane from L2 -- 161
+// vector-memory reads per wave, 48 % of wave cycles in s_waitcnt, 0.16 of the matrix-core peak; five such launches are a quarter
+// of a reverse step.  A 64-wide block's planes are 96 KiB (128 -> 64 up block: W1 32, W2 16, W3 16, shortcut 32) or 48 KiB (down
+// block): they fit the CU's 160 KiB of LDS next to nothing else.  So: one 8-wave workgroup per CU stages the planes and the
+// per-feature vectors ONCE (plain loads + ds_write, then the launch's only barrier), then every wave walks its row tiles alone
+// -- no weight stream, no ring, no barrier, no counted waits.  The wave's inputs are ordinary global loads into REGISTERS, one
+// tile ahead: a 64-wide tile is 32 (down) or 64 (up) registers, the accumulator sets are 32 each, so the concat input is read ONCE
+// and serves stage 1 (LayerNorm + SiLU) and the shortcut / residual from registers (the old kernel read it twice), and the next
+// tile's input arrives under the current tile's shortcut stage.  Everything is compiler-visible code: hipcc counts every wait.
+// Arithmetic per element, packed planes, scales and accumulation order are those of resblock_body_h<64, *>.
+#pragma once
+#include "dsg_panel.hpp"
+
+namespace dsg {
+
+constexpr int kR64Waves = 8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 lds_cu4;
+
+// LDS image (uint4): W1 [2][KS1][2][64] | W2 [2][4][2][64] | W3 | Wsc [2][KS1][2][64] (SCLIN) | vectors (floats)
+template <bool SCLIN, int NTO = 0> struct R64Layout {
+    static constexpr int KS1 = SCLIN ? 8 : 4;
+    static constexpr int W1 = 0, W2 = W1 + 2 * KS1 * 128, W3 = W2 + 2 * 4 * 128, WSC = W3 + 2 * 4 * 128, WL = WSC + (SCLIN ? 2 * KS1 * 128 : 0),
+                         VEC = WL + NTO * 4 * 128;     // WL: planes of the consuming Linear (K = 64: 4 steps), NTO out tiles
+    // vectors: gamma1', beta1' (16 * KS1 each) | gamma2', beta2', gamma3', beta3' (64 each) | time bias, c2, c3 (64 each)
+    static constexpr int G1 = 0, B1 = 16 * KS1, G2 = 2 * 16 * KS1, B2 = G2 + 64, G3 = B2 + 64, B3 = G3 + 64, TB = B3 + 64, C2 = TB + 64, C3 = C2 + 64,
+                         BL = C3 + 64, NV = BL + 32 * NTO;
+    static constexpr int TOTAL_U4 = VEC + (NV + 3) / 4;
+};
+
+// 6 MFMAs of one k16-step, two out tiles, planes from the LDS image (term-major as mfma_step_h)
+template <bool FIRST>
+__device__ __forceinline__ void r64_mma(f32x16 (&acc)[2], lds_cu4* w /* step's planes of tile 0, + lane */, int tile_stride, const h8 bhi, const h8 blo) {
+    const u32x4 h0 = w[0], l0 = w[64], h1 = w[tile_stride], l1 = w[tile_stride + 64];
+    if (FIRST) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, h0), bhi, z, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, h1), bhi, z, 0, 0, 0);
+    } else {
+        DSG_MFMA_H(acc[0], __builtin_bit_cast(h8, h0), bhi);
+        DSG_MFMA_H(acc[1], __builtin_bit_cast(h8, h1), bhi);
+    }
+    DSG_MFMA_H(acc[0], __builtin_bit_cast(h8, h0), blo);
+    DSG_MFMA_H(acc[1], __builtin_bit_cast(h8, h1), blo);
+    DSG_MFMA_H(acc[0], __builtin_bit_cast(h8, l0), bhi);
+    DSG_MFMA_H(acc[1], __builtin_bit_cast(h8, l1), bhi);
+}
+
+// B operand of a step from eight values: LayerNorm (vectors from LDS, already times -log2 e) + SiLU + split, or the raw split
+template <bool LNACT>
+__device__ __forceinline__ void r64_prep(const float (&x)[8], const float* gv, const float* bv, int S, float c, float d, int h, h8& hi, h8& lo) {
+    const BOp o = panel_prep<LNACT>(x, gv, bv, S, c, d, h);
+    hi = o.hi; lo = o.lo;
+}
+
+template <int NQ>
+__device__ __forceinline__ void r64_unscale_add(f32x16 (&acc)[2], float inv, const float* vec, int h) {
+    lds_cf4* const v = (lds_cf4*)(vec + 4 * h);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = v[8 * nt + 2 * q];
+            acc[nt][4 * q + 0] = fmaf(acc[nt][4 * q + 0], inv, b[0]); acc[nt][4 * q + 1] = fmaf(acc[nt][4 * q + 1], inv, b[1]);
+            acc[nt][4 * q + 2] = fmaf(acc[nt][4 * q + 2], inv, b[2]); acc[nt][4 * q + 3] = fmaf(acc[nt][4 * q + 3], inv, b[3]);
+        }
+}
+
+struct R64Tile {                // where a row tile's operands live
+    const float *x0, *x1, *cp;  // fragment tensors (+ lane * 4)
+    const float2 *st0, *st1;    // row statistics (+ j)
+    bool cond;
+};
+
+// NTO > 0: + the raw Linear that consumes the block (Upsample 64 -> 32 * NTO), its planes resident too; `store_block_out`: the
+// block's own output is a skip tensor somebody else reads
+template <bool SCLIN, int NTO>
+__global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, const int ngroups) {
+    using L = R64Layout<SCLIN, NTO>;
+    const BlockArgsH& ah = A.b;
+    constexpr int N = 64, NT = 2, NG = 8, KS1 = L::KS1, XG = SCLIN ? 16 : 8;       // XG: 8-feature groups of the (concatenated) input
+    __shared__ uint4 lds[L::TOTAL_U4];
+    float* const vec = reinterpret_cast<float*>(lds + L::VEC);
+    const BlockArgs& a = ah.b;
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr float kL2 = -1.44269504088896341f;
+
+    // ---- the block's planes and vectors -> LDS, once per launch
+    {
+        for (int i = threadIdx.x; i < 2 * KS1 * 128; i += 512) lds[L::W1 + i] = ah.W1h[i];
+        for (int i = threadIdx.x; i < 2 * 4 * 128; i += 512) { lds[L::W2 + i] = ah.W2h[i]; lds[L::W3 + i] = ah.W3h[i]; }
+        if (SCLIN) for (int i = threadIdx.x; i < 2 * KS1 * 128; i += 512) lds[L::WSC + i] = ah.Wsch[i];
+        if (NTO > 0) {
+            for (int i = threadIdx.x; i < NTO * 4 * 128; i += 512) lds[L::WL + i] = A.l.Wh[i];
+            for (int i = threadIdx.x; i < 32 * NTO; i += 512) vec[L::BL + i] = A.l.l.bias[i];
+        }
+        for (int i = threadIdx.x; i < 16 * KS1; i += 512) { vec[L::G1 + i] = a.gamma1[i] * kL2; vec[L::B1 + i] = a.beta1[i] * kL2; }
+        if (threadIdx.x < 64) {
+            const int i = threadIdx.x;
+            vec[L::G2 + i] = a.gamma2[i] * kL2; vec[L::B2 + i] = a.beta2[i] * kL2; vec[L::G3 + i] = a.gamma3[i] * kL2; vec[L::B3 + i] = a.beta3[i] * kL2;
+            vec[L::C2 + i] = a.c2[i]; vec[L::C3 + i] = a.c3[i];
+            vec[L::TB + i] = a.tbias[(size_t)(a.step_ptr ? *a.step_ptr : 0) * a.tb_stride + i];
+        }
+    }
+    const float inv1 = ah.kc[0], inv2 = ah.kc[1], inv3 = ah.kc[2];
+    float invL = 0.f;
+    if (NTO > 0) invL = A.l.kc[0];
+    __syncthreads();
+    lds_cu4* const wl = (lds_cu4*)(lds + L::WL) + lane;
+    lds_cu4* const w1 = (lds_cu4*)(lds + L::W1) + lane;
+    lds_cu4* const w2 = (lds_cu4*)(lds + L::W2) + lane;
+    lds_cu4* const w3 = (lds_cu4*)(lds + L::W3) + lane;
+    lds_cu4* const wsc = (lds_cu4*)(lds + L::WSC) + lane;
+
+    auto tile_of = [&](int g) -> R64Tile {
+        const int traw = g * kR64Waves + wave;
+        const int tile = traw < a.ntiles ? traw : a.ntiles - 1;
+        const int ptile = tile >= a.tiles_per_pass ? tile - a.tiles_per_pass : tile;
+        const int t0 = seg_tile(a.in0, tile), t1 = seg_tile(a.in1, tile);
+        R64Tile t;
+        t.x0 = a.in0.data + (size_t)t0 * 8 * 256 + lane * 4;
+        t.st0 = reinterpret_cast<const float2*>(a.in0.stats) + (size_t)t0 * 32 + j;
+        t.x1 = SCLIN ? a.in1.data + (size_t)t1 * 8 * 256 + lane * 4 : t.x0;
+        t.st1 = SCLIN ? reinterpret_cast<const float2*>(a.in1.stats) + (size_t)t1 * 32 + j : t.st0;
+        t.cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
+        t.cond = tile >= a.uncond_tiles;
+        return t;
+    };
+    auto xsrc = [&](const R64Tile& t, int G) -> const float* { return SCLIN && G >= 8 ? t.x1 + (size_t)(G - 8) * 256 : t.x0 + (size_t)G * 256; };
+
+    // the first tile's input
+    float4 xc[XG];
+    float2 s0c, s1c;
+    {
+        const R64Tile t = tile_of(blockIdx.x < ngroups ? blockIdx.x : 0);
+#pragma unroll
+        for (int G = 0; G < XG; ++G) xc[G] = ld4(xsrc(t, G));
+        s0c = *t.st0; s1c = *t.st1;
+    }
+
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        // the planes in LDS never change inside this loop: without a compiler barrier hipcc hoists ALL the plane reads out of it (loop-
+        // invariant loads) and spills 700 registers
+        asm volatile("" ::: "memory");
+        const int tile_raw = g * kR64Waves + wave;
+        const bool live = tile_raw < a.ntiles;
+        const int tile = live ? tile_raw : a.ntiles - 1;
+        const R64Tile cur = tile_of(g);
+        const R64Tile nxt = tile_of(g + gridDim.x < ngroups ? g + gridDim.x : g);
+        // condition embedding of this tile: requested now, added after stage 2
+        float4 cpv[NG];
+        if (cur.cond) {
+#pragma unroll
+            for (int G = 0; G < NG; ++G) cpv[G] = ld4(cur.cp + (size_t)G * 256);
+        }
+
+        // ---- LN1 statistics (Chan merge over the concat)
+        float mean1, rstd1;
+        {
+            float mean = s0c.x, m2 = s0c.y;
+            if (SCLIN) {
+                const float dd = s1c.x - mean;
+                m2 = m2 + s1c.y + dd * dd * a.chan_w;
+                mean = mean + dd * a.chan_f;
+            }
+            mean1 = mean;
+            rstd1 = rsqrtf(m2 * a.inv_nin + kLnEps);
+            if (SCLIN) range_check(a.range_flag, mean, m2);
+        }
+
+        // ---- stage 1
+        f32x16 acc1[NT];
+        {
+            const float cc = rstd1, dd = -mean1 * rstd1;
+#pragma unroll
+            for (int S = 0; S < KS1; ++S) {
+                const float x[8] = {xc[2 * S].x, xc[2 * S].y, xc[2 * S].z, xc[2 * S].w, xc[2 * S + 1].x, xc[2 * S + 1].y, xc[2 * S + 1].z, xc[2 * S + 1].w};
+                h8 bhi, blo;
+                r64_prep<true>(x, vec + L::G1, vec + L::B1, S, cc, dd, h, bhi, blo);
+                if (S == 0) r64_mma<true>(acc1, w1 + S * 128, KS1 * 128, bhi, blo); else r64_mma<false>(acc1, w1 + S * 128, KS1 * 128, bhi, blo);
+            }
+        }
+        r64_unscale_add<8>(acc1, inv1, vec + L::TB, h);
+
+        // ---- stage 2
+        f32x16 acc2[NT];
+        {
+            float mean, m2;
+            acc_stats<N, NT>(acc1, h, mean, m2);
+            const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
+#pragma unroll
+            for (int S = 0; S < 4; ++S) {
+                const int t = S >> 1, r0 = 8 * (S & 1);
+                const float x[8] = {acc1[t][r0], acc1[t][r0 + 1], acc1[t][r0 + 2], acc1[t][r0 + 3], acc1[t][r0 + 4], acc1[t][r0 + 5], acc1[t][r0 + 6], acc1[t][r0 + 7]};
+                h8 bhi, blo;
+                r64_prep<true>(x, vec + L::G2, vec + L::B2, S, cc, dd, h, bhi, blo);
+                if (S == 0) r64_mma<true>(acc2, w2 + S * 128, 4 * 128, bhi, blo); else r64_mma<false>(acc2, w2 + S * 128, 4 * 128, bhi, blo);
+            }
+            r64_unscale_add<8>(acc2, inv2, vec + L::C2, h);
+        }
+        if (cur.cond) {
+#pragma unroll
+            for (int G = 0; G < NG; ++G) {
+                acc2[G >> 2][4 * (G & 3) + 0] += cpv[G].x; acc2[G >> 2][4 * (G & 3) + 1] += cpv[G].y;
+                acc2[G >> 2][4 * (G & 3) + 2] += cpv[G].z; acc2[G >> 2][4 * (G & 3) + 3] += cpv[G].w;
+            }
+        }
+
+        // ---- stage 3
+        f32x16 (&acc3)[NT] = acc1;
+        {
+            float mean, m2;
+            acc_stats<N, NT>(acc2, h, mean, m2);
+            const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
+#pragma unroll
+            for (int S = 0; S < 4; ++S) {
+                const int t = S >> 1, r0 = 8 * (S & 1);
+                const float x[8] = {acc2[t][r0], acc2[t][r0 + 1], acc2[t][r0 + 2], acc2[t][r0 + 3], acc2[t][r0 + 4], acc2[t][r0 + 5], acc2[t][r0 + 6], acc2[t][r0 + 7]};
+                h8 bhi, blo;
+                r64_prep<true>(x, vec + L::G3, vec + L::B3, S, cc, dd, h, bhi, blo);
+                if (S == 0) r64_mma<true>(acc3, w3 + S * 128, 4 * 128, bhi, blo); else r64_mma<false>(acc3, w3 + S * 128, 4 * 128, bhi, blo);
+            }
+        }
+
+        // ---- shortcut / residual from the SAME registers stage 1 read; the next tile's input is requested step by step behind it
+        float4 xn[XG];
+        float2 s0n, s1n;
+        s0n = *nxt.st0; s1n = *nxt.st1;
+        if (SCLIN) {
+#pragma unroll
+            for (int S = 0; S < KS1; ++S) {
+                const float x[8] = {xc[2 * S].x, xc[2 * S].y, xc[2 * S].z, xc[2 * S].w, xc[2 * S + 1].x, xc[2 * S + 1].y, xc[2 * S + 1].z, xc[2 * S + 1].w};
+                xn[2 * S] = ld4(xsrc(nxt, 2 * S)); xn[2 * S + 1] = ld4(xsrc(nxt, 2 * S + 1));
+                h8 bhi, blo;
+                r64_prep<false>(x, nullptr, nullptr, 0, 0.f, 0.f, h, bhi, blo);
+                r64_mma<false>(acc3, wsc + S * 128, KS1 * 128, bhi, blo);
+            }
+            r64_unscale_add<8>(acc3, inv3, vec + L::C3, h);
+        } else {
+            r64_unscale_add<8>(acc3, inv3, vec + L::C3, h);
+#pragma unroll
+            for (int G = 0; G < NG; ++G) {
+                acc3[G >> 2][4 * (G & 3) + 0] += xc[G].x; acc3[G >> 2][4 * (G & 3) + 1] += xc[G].y;
+                acc3[G >> 2][4 * (G & 3) + 2] += xc[G].z; acc3[G >> 2][4 * (G & 3) + 3] += xc[G].w;
+                xn[G] = ld4(xsrc(nxt, G));
+            }
+        }
+
+        // ---- statistics + store
+        float xmean, xm2;
+        acc_stats<N, NT>(acc3, h, xmean, xm2);
+        if (live && (NTO == 0 || A.store_block_out)) {
+            if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
+#pragma unroll
+            for (int G = 0; G < NG; ++G)
+                st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                    make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2], acc3[G >> 2][4 * (G & 3) + 3]));
+        }
+        if constexpr (NTO > 0) {
+            // ---- the consuming raw Linear: K = 64 (4 k16-steps) from the block's output in registers
+            range_check(a.range_flag, xmean, xm2);
+            const LinArgs& la = A.l.l;
+            f32x16 accL[NTO];
+#pragma unroll
+            for (int S = 0; S < 4; ++S) {
+                const int t = S >> 1, r0 = 8 * (S & 1);
+                const float x[8] = {acc3[t][r0], acc3[t][r0 + 1], acc3[t][r0 + 2], acc3[t][r0 + 3], acc3[t][r0 + 4], acc3[t][r0 + 5], acc3[t][r0 + 6], acc3[t][r0 + 7]};
+                h8 bhi, blo;
+                r64_prep<false>(x, nullptr, nullptr, 0, 0.f, 0.f, h, bhi, blo);
+                HFrag<NTO> w;
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    const u32x4 hh = wl[(nt * 4 + S) * 128], ll = wl[(nt * 4 + S) * 128 + 64];
+                    w.hi[nt] = __builtin_bit_cast(uint4, hh); w.lo[nt] = __builtin_bit_cast(uint4, ll);
+                }
+                if (S == 0) mfma_step_h0<NTO>(accL, w, bhi, blo); else mfma_step_h<NTO>(accL, w, bhi, blo);
+            }
+            {
+                lds_cf4* const v = (lds_cf4*)(vec + L::BL + 4 * h);
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 b = v[8 * nt + 2 * q];
+                        accL[nt][4 * q + 0] = fmaf(accL[nt][4 * q + 0], invL, b[0]); accL[nt][4 * q + 1] = fmaf(accL[nt][4 * q + 1], invL, b[1]);
+                        accL[nt][4 * q + 2] = fmaf(accL[nt][4 * q + 2], invL, b[2]); accL[nt][4 * q + 3] = fmaf(accL[nt][4 * q + 3], invL, b[3]);
+                    }
+            }
+            if (live) {
+                const int NGo = (la.out_width + 7) / 8;
+                float sm = 0.f;
+#pragma unroll
+                for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if (8 * G + 4 * h + qq < la.out_width) sm += accL[G >> 2][4 * (G & 3) + qq];
+                const float m = xhalf_sum(sm) * la.inv_out_w;
+                float sq = 0.f;
+#pragma unroll
+                for (int G = 0; G < NTO * 4; ++G)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if (8 * G + 4 * h + qq < la.out_width) { const float dv = accL[G >> 2][4 * (G & 3) + qq] - m; sq = fmaf(dv, dv, sq); }
+                sq = xhalf_sum(sq);
+                if (h == 0) reinterpret_cast<float2*>(la.out_stats)[(size_t)tile * 32 + j] = make_float2(m, sq);
+#pragma unroll
+                for (int G = 0; G < NTO * 4; ++G)
+                    if (G < NGo)
+                        st4(la.out + ((size_t)tile * NGo + G) * 256 + lane * 4,
+                            make_float4(accL[G >> 2][4 * (G & 3)], accL[G >> 2][4 * (G & 3) + 1], accL[G >> 2][4 * (G & 3) + 2], accL[G >> 2][4 * (G & 3) + 3]));
+            }
+        }
+#pragma unroll
+        for (int G = 0; G < XG; ++G) xc[G] = xn[G];
+        s0c = s0n; s1c = s1n;
+    }
+}
+
+}  // namespace dsg
