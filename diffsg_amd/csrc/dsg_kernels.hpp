@@ -955,11 +955,20 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
 __device__ __forceinline__ void renorm_chunk(const float*& y, size_t& n, size_t chunk_n) {
     if (chunk_n) { const size_t lo = (size_t)blockIdx.y * chunk_n; y += lo; n = n - lo < chunk_n ? n - lo : chunk_n; }
 }
+// every thread visits whole 16-byte quads (the tensor is 21 MB at the bench size: scalar loads ran these passes at 1.7 TB/s), then
+// the < 4 elements of a ragged tail; the order is fixed, so the reductions stay deterministic
+template <typename F>
+__device__ __forceinline__ void renorm_visit(const float* y, size_t n, F&& f) {
+    const size_t n4 = (reinterpret_cast<uintptr_t>(y) & 15) ? 0 : n / 4;
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (size_t i4 = t; i4 < n4; i4 += st) { const float4 v = ld4(y + 4 * i4); f(v.x); f(v.y); f(v.z); f(v.w); }
+    for (size_t i = 4 * n4 + t; i < n; i += st) f(y[i]);
+}
 __global__ __launch_bounds__(256) void k_renorm_sum(const float* y, size_t n, double* __restrict__ part, size_t chunk_n = 0) {
     __shared__ double sm[4];
     renorm_chunk(y, n, chunk_n); part += (size_t)blockIdx.y * kRedBlocks;
     double s = 0.0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += (double)y[i];
+    renorm_visit(y, n, [&](float v) { s += (double)v; });
     s = block_sum(s, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
@@ -972,10 +981,7 @@ __global__ __launch_bounds__(256) void k_renorm_sqdiff(const float* y, size_t n,
     for (int i = 0; i < kRedBlocks; ++i) tot += part[i];
     const double mean = tot / (double)n;
     double s = 0.0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double d = (double)y[i] - mean;
-        s += d * d;
-    }
+    renorm_visit(y, n, [&](float v) { const double d = (double)v - mean; s += d * d; });
     s = block_sum(s, sm);
     if (threadIdx.x == 0) part2[blockIdx.x] = s;
 }
@@ -1006,16 +1012,31 @@ __global__ __launch_bounds__(256) void k_renorm_apply_stats(float* __restrict__ 
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         y[i] = (y[i] - mean) / sd;
 }
+// ... and, fused, the trajectory record of the renormalised y (k_record's job on these steps): `cp` / `step_ptr` null = no record
 __global__ __launch_bounds__(256) void k_renorm_apply(float* y, size_t n, const double* __restrict__ part,
-                                                      const double* __restrict__ part2, size_t chunk_n = 0) {
+                                                      const double* __restrict__ part2, size_t chunk_n = 0,
+                                                      const CallParams* __restrict__ cp = nullptr, const int* __restrict__ step_ptr = nullptr) {
+    float* rec = nullptr;
+    if (cp && cp->rec_y) rec = cp->rec_y + (size_t)(cp->T - 1 - *step_ptr) * n + (chunk_n ? (size_t)blockIdx.y * chunk_n : 0);
     { const float* yc = y; renorm_chunk(yc, n, chunk_n); y = const_cast<float*>(yc); }
     part += (size_t)blockIdx.y * kRedBlocks; part2 += (size_t)blockIdx.y * kRedBlocks;
     double tot = 0.0, tot2 = 0.0;
     for (int i = 0; i < kRedBlocks; ++i) { tot += part[i]; tot2 += part2[i]; }
     const float mean = (float)(tot / (double)n);
     const float sd = sqrtf((float)(tot2 / (double)(n - 1)));
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        y[i] = (y[i] - mean) / sd;
+    const size_t n4 = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(rec)) & 15) ? 0 : n / 4;
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (size_t i4 = t; i4 < n4; i4 += st) {
+        const float4 v = ld4(y + 4 * i4);
+        const float4 o = make_float4((v.x - mean) / sd, (v.y - mean) / sd, (v.z - mean) / sd, (v.w - mean) / sd);
+        st4(y + 4 * i4, o);
+        if (rec) st4(rec + 4 * i4, o);
+    }
+    for (size_t i = 4 * n4 + t; i < n; i += st) {
+        const float o = (y[i] - mean) / sd;
+        y[i] = o;
+        if (rec) rec[i] = o;
+    }
 }
 
 // EMA (ema.py:11-12): avg = decay*avg + (1-decay)*p over one flat range
