@@ -196,13 +196,16 @@ struct dsg_handle {
     std::vector<FusedOp> ce_host;
     CondTile* ctile_dev = nullptr; int ctile_n = 0; const float* ctile_key = nullptr; size_t ctile_cap = 0;
     std::vector<FusedOpH> fusedh_host;
+    // LDS-resident form of the narrow run (k_fused_narrow_lds): per-operator LDS offsets, the copy list of every phase, the phases
+    NarrowLdsOp* nlds_ops_dev = nullptr; NarrowLdsCopy* nlds_copies_dev = nullptr; uint4* nlds_image = nullptr;
+    std::vector<NarrowPhaseArgs> nlds_phases;
+    bool nlds_valid = false;
 
     // cached step graphs: per-step pair (with / without the renorm kernels), keyed by (rows, chunks); and ONE graph of a whole
     // T-step loop for short schedules, keyed by (rows, chunks, T)
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    // captured reverse steps of the current workspace shape: gexec[0] = one early (renorm) step, gexec[1 + k] = 2^k later steps
+    hipGraphExec_t gexec[1 + 6] = {};
     int g_rows = -1, g_chunks = -1;
-    hipGraphExec_t gloop = nullptr;
-    int gl_rows = -1, gl_chunks = -1, gl_T = -1;
     // chunked calls (dsg_sample_chunked): per-chunk Philox seeds and per-chunk renorm partials
     unsigned long long* seeds_dev = nullptr; int seeds_cap = 0;
     double* red_chunks = nullptr; int red_chunks_cap = 0;
@@ -371,11 +374,9 @@ void carve(dsg_handle* h) {
 }
 
 void free_graphs(dsg_handle* h) {
-    for (int i = 0; i < 2; ++i)
-        if (h->gexec[i]) { (void)hipGraphExecDestroy(h->gexec[i]); h->gexec[i] = nullptr; }
-    if (h->gloop) { (void)hipGraphExecDestroy(h->gloop); h->gloop = nullptr; }
+    for (auto& g : h->gexec)
+        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     h->g_rows = h->g_chunks = -1;
-    h->gl_rows = h->gl_chunks = h->gl_T = -1;
 }
 
 constexpr int kMaxGmax = 256;   // distinct gradient tensors whose max|G| is tracked (3 per block + 1 per Linear)
@@ -881,6 +882,98 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
     }
     if (sp) HIPCK(hipMemcpyAsync(c.train ? h->fusedh_train_dev : h->fusedh_dev, h->fusedh_host.data(), n * sizeof(FusedOpH), hipMemcpyHostToDevice, s));
     else HIPCK(hipMemcpyAsync(h->fused_dev, h->fused_host.data(), n * sizeof(FusedOp), hipMemcpyHostToDevice, s));
+    h->nlds_valid = false;
+    if (sp && !c.train && !c.ts) {
+        // LDS image of the run, cut into phases that fit kNarrowLdsU4: per operator its packed planes and per-feature vectors (static:
+        // gathered once into h->nlds_image, a phase's part contiguous) and, behind them, the phase's slice of the time-table row
+        std::vector<NarrowLdsOp> lops(n);
+        std::vector<NarrowLdsCopy> copies;                 // dst_u4: offset in the GLOBAL image buffer
+        h->nlds_phases.clear();
+        unsigned used = 0, image_base = 0;                 // used: static part of the current phase
+        int phase_lo = 0;
+        int tb_first = -1, tb_last_end = 0;                // time-table slice of the current phase (floats in the row)
+        bool fits = true;
+        std::vector<int> phase_of(n, 0);
+        auto close_phase = [&](int hi) {
+            NarrowPhaseArgs ph;
+            ph.image = nullptr; ph.n_u4 = used; ph.tb = h->tb + (tb_first < 0 ? 0 : tb_first); ph.tb_u4 = tb_first < 0 ? 0 : (unsigned)(tb_last_end - tb_first) / 4;
+            ph.op_lo = phase_lo; ph.op_hi = hi;
+            // image pointer filled below (needs the buffer); remember the base through n_u4 bookkeeping
+            h->nlds_phases.push_back(ph);
+            for (int k = phase_lo; k < hi; ++k) {           // the time-bias rows sit behind the static part
+                const Op& o = h->ops[h->fuse_lo + k];
+                if (o.kind == OP_RES) lops[k].tb = 4 * used + (unsigned)(h->res[o.p].tb_off - tb_first);
+            }
+            image_base += used;
+        };
+        std::vector<unsigned> phase_base;
+        phase_base.push_back(0);
+        for (int i = 0; i < n; ++i) {
+            const Op& op = h->ops[h->fuse_lo + i];
+            const float* A = h->arena;
+            unsigned need = 0, need_tb = 0;
+            if (op.kind == OP_RES) {
+                const ResP& r = h->res[op.p];
+                const unsigned KG = groups_of(r.in0) + groups_of(r.in1), KS1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2, KS2 = (groups_of(r.N) + 1) / 2;
+                need = KS1 * 128 * (r.sclin ? 2 : 1) + 2 * KS2 * 128 + 2 * ((KG * 8 + 32 + 3) / 4) + 6 * 8;
+                need_tb = 8;
+            } else {
+                const LinOpP& l = h->lin[op.p];
+                need = ((groups_of(l.l.K) + 1) / 2) * 128 + 8;
+            }
+            if (need + need_tb > (unsigned)kNarrowLdsU4) { fits = false; break; }
+            const unsigned tb_now = tb_first < 0 ? 0 : (unsigned)(tb_last_end - tb_first) / 4;
+            if (used + need + tb_now + need_tb > (unsigned)kNarrowLdsU4) {
+                close_phase(i);
+                lops[i - 1].store_out = 1;                       // the running tensor crosses the boundary through memory
+                phase_base.push_back(image_base);
+                phase_lo = i; used = 0; tb_first = -1; tb_last_end = 0;
+            }
+            NarrowLdsOp& lo = lops[i];
+            const int keep_store = lo.store_out;
+            memset(&lo, 0, sizeof lo);
+            lo.store_out = h->fusedh_host[i].store_out | keep_store;
+            auto take = [&](const void* src, unsigned n_u4) -> unsigned {
+                const unsigned off = used;
+                copies.push_back(NarrowLdsCopy{src, image_base + off, n_u4});
+                used += n_u4;
+                return off;
+            };
+            if (op.kind == OP_RES) {
+                const ResP& r = h->res[op.p];
+                const unsigned KG = groups_of(r.in0) + groups_of(r.in1), KS1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2, KS2 = (groups_of(r.N) + 1) / 2;
+                const unsigned nv1 = (KG * 8 + 32 + 3) / 4;
+                lo.w1 = take(A + r.W1h, KS1 * 128);
+                lo.w2 = take(A + r.W2h, KS2 * 128);
+                lo.w3 = take(A + r.W3h, KS2 * 128);
+                lo.wsc = r.sclin ? take(A + r.Wsch, KS1 * 128) : lo.w1;
+                lo.g1 = 4 * take(A + r.g1p, nv1); lo.b1 = 4 * take(A + r.b1p, nv1);
+                lo.g2 = 4 * take(A + r.g2p, 8); lo.b2 = 4 * take(A + r.b2p, 8);
+                lo.g3 = 4 * take(A + r.g3p, 8); lo.b3 = 4 * take(A + r.b3p, 8);
+                lo.c2 = 4 * take(A + r.c2p, 8); lo.c3 = 4 * take(A + r.c3p, 8);
+                if (tb_first < 0) tb_first = r.tb_off;
+                else if (r.tb_off != tb_last_end) { fits = false; break; }   // a phase's time-bias slices must be one contiguous piece of the row
+                tb_last_end = r.tb_off + pad32(r.N);
+            } else {
+                const LinOpP& l = h->lin[op.p];
+                lo.w1 = take(A + l.Wh, ((groups_of(l.l.K) + 1) / 2) * 128);
+                lo.c2 = 4 * take(A + l.bp, 8);
+            }
+        }
+        if (fits && n > 0) {
+            close_phase(n);
+            const size_t image_u4 = image_base;
+            if (!h->nlds_ops_dev) HIPCK(hipMalloc(&h->nlds_ops_dev, (h->ops.size() + 1) * sizeof(NarrowLdsOp)));
+            if (!h->nlds_copies_dev) HIPCK(hipMalloc(&h->nlds_copies_dev, (h->ops.size() + 1) * 16 * sizeof(NarrowLdsCopy)));
+            if (h->nlds_image) (void)hipFree(h->nlds_image);
+            HIPCK(hipMalloc(&h->nlds_image, (image_u4 + 1) * sizeof(uint4)));
+            HIPCK(hipMemcpy(h->nlds_ops_dev, lops.data(), n * sizeof(NarrowLdsOp), hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(h->nlds_copies_dev, copies.data(), copies.size() * sizeof(NarrowLdsCopy), hipMemcpyHostToDevice));
+            for (size_t k = 0; k < h->nlds_phases.size(); ++k) h->nlds_phases[k].image = h->nlds_image + phase_base[k];
+            hipLaunchKernelGGL(k_narrow_image_build, dim3((unsigned)copies.size()), dim3(256), 0, s, (const NarrowLdsCopy*)h->nlds_copies_dev, h->nlds_image);
+            h->nlds_valid = true;
+        }
+    }
     return 0;
 }
 
@@ -890,6 +983,13 @@ void launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     if (split_ctx(h, c)) {
         // small launches: the latency of one wave is the kernel time -> first-step weight planes requested a stage ahead
         const FusedOpH* tab = c.train ? h->fusedh_train_dev : h->fusedh_dev;
+        if (!c.train && !c.ts && h->nlds_valid && ntiles >= h->panel_min_tiles && ntiles > h->narrow_small_max_tiles) {
+            // large sampling launch: the run's planes and vectors resident in LDS, one launch per phase (dsg_split.hpp)
+            for (const auto& ph : h->nlds_phases)
+                hipLaunchKernelGGL(k_fused_narrow_lds, dim3(cdiv(ntiles, 16)), dim3(1024), 0, s, tab, (const NarrowLdsOp*)h->nlds_ops_dev, ph, ntiles, c.step_ptr,
+                                   h->tb_stride);
+            return;
+        }
         if (ntiles <= h->narrow_small_max_tiles) hipLaunchKernelGGL(k_fused_narrow_h<true>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
         else hipLaunchKernelGGL(k_fused_narrow_h<false>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
     }
@@ -1487,6 +1587,9 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
 }
 
 void dsg_destroy(dsg_handle* h) {
+    if (h && h->nlds_ops_dev) (void)hipFree(h->nlds_ops_dev);
+    if (h && h->nlds_copies_dev) (void)hipFree(h->nlds_copies_dev);
+    if (h && h->nlds_image) (void)hipFree(h->nlds_image);
     if (h && h->seeds_dev) (void)hipFree(h->seeds_dev);
     if (h && h->red_chunks) (void)hipFree(h->red_chunks);
     if (h)
@@ -1802,7 +1905,7 @@ int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* 
 }
 
 namespace {
-constexpr int kWholeLoopMaxT = 64;      // schedules up to this length replay as ONE graph (T x the step's nodes)
+constexpr int kStepRunGraphs = 6;       // captured runs of 1, 2, 4, 8, 16, 32 later steps (dsg_handle::gexec)
 
 // chunk_rows = 0: one call over B rows.  Otherwise the batch is ceil(B / chunk_rows) independent calls (own seed, own renorm
 // statistics), chunk_rows a multiple of 32 so that every chunk starts on a row tile.
@@ -1875,33 +1978,19 @@ int sample_impl(dsg_handle* h, const float* cond, const float* y_T, const float*
     } else if (flags & DSG_SAMPLE_NO_GRAPH) {
         for (int k = 0; k < T; ++k)
             if (enqueue_step(h, c, u, k < n_renorm, s, nullptr, true, chunks, chunk_n)) return 1;
-    } else if (T <= kWholeLoopMaxT && !h->renorm_fn) {
-        // short schedule (the shipped T = 20): the WHOLE reverse loop is one graph and one launch -- the step index is a device
-        // counter and everything per call sits in device memory, so the graph depends only on (rows, chunks, T)
-        if (!(h->gloop && h->gl_rows == B && h->gl_chunks == chunks && h->gl_T == T)) {
-            if (h->gloop) { (void)hipGraphExecDestroy(h->gloop); h->gloop = nullptr; }
-            hipGraph_t g = nullptr;
-            HIPCK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-            int rc = 0;
-            for (int k = 0; k < T && !rc; ++k) rc = enqueue_step(h, c, u, k < n_renorm, h->cap_stream, nullptr, /*use_hook=*/false, chunks, chunk_n);
-            hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
-            if (rc) return 1;
-            if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
-            e = hipGraphInstantiate(&h->gloop, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
-            h->gl_rows = B; h->gl_chunks = chunks; h->gl_T = T;
-        }
-        HIPCK(hipGraphLaunch(h->gloop, s));
     } else {
-        // the per-step graph depends only on the workspace (batch size, chunk count); everything per call is in device memory
+        // The step index is a device counter and everything per call sits in device memory, so a captured step depends only on
+        // the workspace (rows, chunk count) -- not on T, the seed or the schedule.  Captured once per workspace: one early
+        // (renorm) step and runs of 1, 2, 4 ... 32 later steps; a call replays min(T, 4) early steps and the binary
+        // decomposition of the rest (the shipped T = 20: 4 + one 16-step graph = 5 launches for the whole reverse loop).
         if (!(h->gexec[0] && h->g_rows == B && h->g_chunks == chunks)) {
-            for (int i = 0; i < 2; ++i)
-                if (h->gexec[i]) { (void)hipGraphExecDestroy(h->gexec[i]); h->gexec[i] = nullptr; }
-            for (int variant = 0; variant < 2; ++variant) {  // 0: with renorm, 1: without
+            free_graphs(h);
+            for (int variant = 0; variant < 1 + kStepRunGraphs; ++variant) {
+                const int run = variant == 0 ? 1 : 1 << (variant - 1);
                 hipGraph_t g = nullptr;
                 HIPCK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-                const int rc = enqueue_step(h, c, u, variant == 0, h->cap_stream, nullptr, /*use_hook=*/false, chunks, chunk_n);
+                int rc = 0;
+                for (int k = 0; k < run && !rc; ++k) rc = enqueue_step(h, c, u, variant == 0, h->cap_stream, nullptr, /*use_hook=*/false, chunks, chunk_n);
                 hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
                 if (rc) return 1;
                 if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -1911,12 +2000,18 @@ int sample_impl(dsg_handle* h, const float* cond, const float* y_T, const float*
             }
             h->g_rows = B; h->g_chunks = chunks;
         }
-        for (int k = 0; k < T; ++k) {
-            if (k < n_renorm && h->renorm_fn) {          // the hook calls back into the host: these (<= 4) steps run eagerly
+        for (int k = 0; k < n_renorm; ++k) {
+            if (h->renorm_fn) {                           // the hook calls back into the host: these (<= 4) steps run eagerly
                 if (enqueue_step(h, c, u, true, s)) return 1;
             } else {
-                HIPCK(hipGraphLaunch(h->gexec[k < n_renorm ? 0 : 1], s));
+                HIPCK(hipGraphLaunch(h->gexec[0], s));
             }
+        }
+        for (int left = T - n_renorm; left > 0;) {
+            int v = kStepRunGraphs - 1;
+            while ((1 << v) > left) --v;
+            HIPCK(hipGraphLaunch(h->gexec[1 + v], s));
+            left -= 1 << v;
         }
     }
     HIPCK(hipMemcpyAsync(out, h->ywork, n * sizeof(float), hipMemcpyDeviceToDevice, s));

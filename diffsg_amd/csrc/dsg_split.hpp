@@ -1175,6 +1175,124 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
 }
 
 // ---------------------------------------------------------------------------------------------
+// The narrow run for LARGE launches with the run's packed planes and per-feature vectors RESIDENT IN LDS.
+//
+// Why (profiles/r02d_pmc_summary.txt, k_fused_narrow_h<false>): 730 vector-memory reads and 572 scalar loads per wave, 59 % of wave
+// cycles in s_waitcnt -- every stage of every narrow block is one or two k16-steps behind "operator record -> planes / vectors ->
+// MFMA".  The planes of the whole run are 210 KiB for MSR (74 KiB down + middle, 136 KiB up), its vectors 25 KiB: the host cuts
+// the run into PHASES that fit 150 KiB of LDS (dsg_api.hip, plan_narrow_lds), one launch per phase; a 16-wave workgroup (one per
+// CU: 4 waves per SIMD as before, one row tile per wave) copies the phase's image once, then every wave walks its tile through
+// the phase's operators with every plane and vector a ds_read away.  The running tensor crosses a phase boundary through memory
+// (the boundary operator stores, the next phase's first operator reloads: the paths the fused kernel already has).
+// The block and Linear bodies are the ones of k_fused_narrow_h: the operator record's weight / vector pointers are REPLACED by
+// pointers derived from the __shared__ array inside the kernel, so that after inlining hipcc knows their address space and emits
+// ds_read (round 1 handed generic pointers through the record and got flat loads of the LDS aperture -- slower than the L2 hits).
+// ---------------------------------------------------------------------------------------------
+constexpr int kNarrowLdsU4 = 9472;       // 148 KiB image
+struct NarrowLdsOp {                     // LDS offsets (uint4 units for planes, floats for vectors) of one operator of the phase
+    unsigned w1, w2, w3, wsc;            // planes (a Linear: w1 only)
+    unsigned g1, b1, g2, b2, g3, b3, c2, c3, tb;   // vectors (a Linear: c2 = bias); tb: the time-bias row of the CURRENT step
+    int store_out;                       // the table's flag, or 1 at a phase boundary
+};
+// plan time: the static part of a phase's image (planes, vectors) is gathered ONCE into one contiguous device buffer, so that a
+// workgroup stages it with one flat copy loop (a per-entry loop -- ~110 entries, each a dependent round trip -- cost 60 us per
+// launch); per step only the phase's slice of the time-table row is added behind it
+struct NarrowLdsCopy { const void* src; unsigned dst_u4, n_u4; };
+__global__ void k_narrow_image_build(const NarrowLdsCopy* __restrict__ copies, uint4* __restrict__ image) {
+    const NarrowLdsCopy c = copies[blockIdx.x];
+    const uint4* src = reinterpret_cast<const uint4*>(c.src);
+    for (unsigned i = threadIdx.x; i < c.n_u4; i += blockDim.x) image[c.dst_u4 + i] = src[i];
+}
+struct NarrowPhaseArgs {
+    const uint4* image; unsigned n_u4;      // static image of the phase (LDS offset 0)
+    const float* tb; unsigned tb_u4;         // its slice of time-table row 0 (+ step * tb_stride floats), LDS offset n_u4
+    int op_lo, op_hi;
+};
+
+__global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __restrict__ ops, const NarrowLdsOp* __restrict__ lops, const NarrowPhaseArgs ph,
+                                                              int ntiles, const int* step_ptr, int tb_stride) {
+    __shared__ uint4 lds[kNarrowLdsU4];
+    {   // the phase's image: every thread copies 16-byte pieces
+        for (unsigned i = threadIdx.x; i < ph.n_u4; i += 1024) lds[i] = ph.image[i];
+        const uint4* tbs = reinterpret_cast<const uint4*>(ph.tb + (size_t)(step_ptr ? *step_ptr : 0) * tb_stride);
+        for (unsigned i = threadIdx.x; i < ph.tb_u4; i += 1024) lds[ph.n_u4 + i] = tbs[i];
+    }
+    const int op_lo = ph.op_lo, op_hi = ph.op_hi;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 16 + (threadIdx.x >> 6));
+    if (tile >= ntiles) return;
+    const int h = lane >> 5, j = lane & 31;
+    const float* const ldsf = reinterpret_cast<const float*>(lds);
+    f32x16 x[1];
+    float xmean = 0.f, xm2 = 0.f;
+    bool have_x = false;
+    for (int i = op_lo; i < op_hi; ++i) {
+        const FusedOpH& op = ops[i];
+        const NarrowLdsOp lo = lops[i];
+        if (op.kind == 0) {
+            BlockArgsH b = op.b;
+            b.W1h = lds + lo.w1; b.W2h = lds + lo.w2; b.W3h = lds + lo.w3; b.Wsch = lds + lo.wsc;
+            b.b.gamma1 = ldsf + lo.g1; b.b.beta1 = ldsf + lo.b1; b.b.gamma2 = ldsf + lo.g2; b.b.beta2 = ldsf + lo.b2;
+            b.b.gamma3 = ldsf + lo.g3; b.b.beta3 = ldsf + lo.b3; b.b.c2 = ldsf + lo.c2; b.b.c3 = ldsf + lo.c3;
+            b.b.tbias = ldsf + lo.tb;            // the staged row of this step: entry 0
+            if (!have_x) {  // first operator of the phase: bring its (<= 32 wide) input into registers once
+                const Seg& s0 = b.b.in0;
+                const float2 st = reinterpret_cast<const float2*>(s0.stats)[(size_t)seg_tile(s0, tile) * 32 + j];
+                xmean = st.x; xm2 = st.y;
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (G < s0.groups) v = ld4(s0.data + ((size_t)seg_tile(s0, tile) * s0.groups + G) * 256 + lane * 4);
+                    x[0][4 * G] = v.x; x[0][4 * G + 1] = v.y; x[0][4 * G + 2] = v.z; x[0][4 * G + 3] = v.w;
+                }
+                have_x = true;
+            }
+            // skip tensors were stored by this wave earlier in the run (possibly in an earlier launch): make sure this wave's stores have landed
+            if (b.b.in1.groups) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bool st = lo.store_out != 0;
+            if (op.sclin) {
+                switch (op.N) {
+                    case 4: resblock_body_h<4, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 8: resblock_body_h<8, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 16: resblock_body_h<16, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    default: resblock_body_h<32, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                }
+            } else {
+                switch (op.N) {
+                    case 4: resblock_body_h<4, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 8: resblock_body_h<8, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 16: resblock_body_h<16, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    default: resblock_body_h<32, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                }
+            }
+        } else {
+            LinArgsH l = op.l;
+            l.Wh = lds + lo.w1; l.l.bias = ldsf + lo.c2;
+            if (!have_x || l.l.in_groups > 4) {
+                // Linear whose input is wider than one tile (the entry of the run) or the first operator of a phase: memory in, memory
+                // out, then reload
+                linear_body_h<1, IN_FRAG, OUT_FRAG, false>(l, tile, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const LinArgs& a = l.l;
+                const int NG = (a.out_width + 7) / 8;
+                const float2 st = reinterpret_cast<const float2*>(a.out_stats)[(size_t)tile * 32 + j];
+                xmean = st.x; xm2 = st.y;
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (G < NG) v = ld4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4);
+                    x[0][4 * G] = v.x; x[0][4 * G + 1] = v.y; x[0][4 * G + 2] = v.z; x[0][4 * G + 3] = v.w;
+                }
+                have_x = true;
+            } else {
+                linear_reg_h(l, tile, lane, x, xmean, xm2, lo.store_out != 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Bind-time helpers: max|W| per weight tensor, and the fp16 plane packing
 //   dst[((nt*KS + S)*2 + plane)*64 + lane] = 8 halfs: plane(W[32nt + (lane&31)][col(2S + (jj>>2), 4(lane>>5) + (jj&3))] * 2^e)
 // with every K segment padded to an EVEN number of 8-feature groups.

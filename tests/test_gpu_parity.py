@@ -435,7 +435,7 @@ def test_global_renorm_reraises_a_failed_reduction():
 def test_chunked_sampling_is_the_per_chunk_calls_bit_for_bit(name, B, chunk, T, policy):
     """dsg_sample_chunked (the reference's evaluation loop, classifier_free_MSR.py:257,273-279, as one set of launches): every chunk
     -- own Philox stream, own early-step renorm statistics, ragged last chunk -- equals its own sample() call bit for bit, with
-    device noise and with injected noise, for a whole-loop graph (T <= 64) and for per-step graph replays (T = 70)."""
+    device noise and with injected noise, for T = 20 (4 early steps + one 16-step graph) and T = 70 (32 + 32 + 2 later steps)."""
     plan, p = synth_params(name, 31)
     cfg = CONFIGS[name]
     d = make_ddpm(name, p, T, policy)
