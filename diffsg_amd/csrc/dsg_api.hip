@@ -1546,7 +1546,6 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         }
         h->fuse_lo = best_lo; h->fuse_hi = best_hi;
     }
-    if (const char* e = getenv("DSG_AB_PANEL_MIN")) h->panel_min_tiles = atoi(e);   // TEMPORARY: same-box A/B of the panel kernels
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
