@@ -9,10 +9,11 @@
 //   * a PANEL = 4 k16-steps x 4 out tiles x (hi, lo) = 32 KiB, two buffers: one barrier per panel (12 per up block instead of
 //     44), the next panel's LDS-DMA issued right behind the barrier and in flight for a whole panel time;
 //   * the PRIVATE operands of a wave (its tile's row statistics, input tensors, condition embedding) travel through per-wave
-//     LDS slots (4 x 2 KiB, three items ahead) and need no barrier at all: only the issuing wave reads them;
-//   * every wait on the vector-memory counter is counted from sequence numbers kept in SGPRs (ops issued so far vs. ops issued
-//     when the awaited DMA went out): no drain to zero anywhere in the loop.  Stores are not counted (an under-count only
-//     makes a wait stricter).
+//     LDS slots (5 x 2 KiB, four items ahead) and need no barrier at all: only the issuing wave reads them;
+//   * the request targets are static per call site, so the waits on the vector-memory counter are compile-time constants
+//     (private items: vmcnt(6); a panel: the 8 / 2 / 0 ladder of panel_begin) -- no drain to zero inside the loop;
+//   * the operand preparation (LayerNorm, SiLU, hi/lo split) of panel p + 1 sits BETWEEN the MFMAs of panel p (panel_pipe):
+//     one MFMA per `asm volatile` slot, the VALU pieces pinned between the slots through "+v" operands.
 // Arithmetic per element, packed planes, scales and accumulation order are those of k_wide128_h / resblock_body_h.
 #pragma once
 #include "dsg_wide.hpp"
@@ -452,13 +453,11 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int stride = gridDim.x;
-    // Waves w and w + 4 share a SIMD.  Waves 0-3 ("lead") prepare a panel's operands BEFORE the panel's barrier and run their
-    // MFMAs right behind it; waves 4-7 prepare theirs BEHIND the barrier: while one wave of a SIMD streams MFMAs (at raised
-    // priority, dsg_panel_mphase.inc) its partner is in its VALU phase, then they swap.
+    // Waves w and w + 4 share a SIMD.  Both run the same program (every panel's MFMA stream carries the operand preparation of
+    // the next panel between its MFMAs, panel_pipe); the younger half gets a static priority: at equal priority the older wave
+    // of a SIMD wins every arbitration, finishes a panel ~1 400 cycles before its partner and idles at the barrier while the
+    // partner runs alone (cycle stamps: 3 000 against 4 400 cycles per LayerNorm panel).  MI355X guide, "two waves per SIMD".
     const bool lead = wave < 4;
-    // Static priority for the younger half: at equal priority the older wave of a SIMD wins every arbitration, finishes a panel
-    // ~1 400 cycles before its partner and idles at the barrier while the partner runs alone (cycle stamps: 3 000 against 4 400
-    // cycles per LayerNorm panel).  MI355X guide, "two waves per SIMD", item 4.
     if (!lead) __builtin_amdgcn_s_setprio(DSG_PANEL_TRAIL_PRIO);
     constexpr float kL2 = -1.44269504088896341f;
 
