@@ -55,6 +55,96 @@ __device__ __forceinline__ void r64_prep(const float (&x)[8], const float* gv, c
     hi = o.hi; lo = o.lo;
 }
 
+// ---- software-pipelined stage: the operand of step S + 1 is prepared BETWEEN the MFMAs of step S.
+// hipcc emits a stage written step by step (prep, then 4 plane reads, then 6 MFMAs) exactly in that order: the plane reads' LDS
+// round trip and the 6 x 32 MFMA cycles are then exposed once per step in every wave (profiles/r03a: matrix core busy 18 %, VALU
+// 34 %, the union 45 % of the launch).  Here the planes and LayerNorm vectors of step S + 1 are requested first (region A), and
+// one scheduling region (B) holds the 6 MFMAs of step S and the ~64 VALU instructions of step S + 1's preparation, interleaved by
+// sched_group_barrier requests (1 MFMA, then a sixth of the VALU work).
+struct R64Planes { u32x4 h0, l0, h1, l1; };
+__device__ __forceinline__ R64Planes r64_planes(lds_cu4* w, int tile_stride) { return R64Planes{w[0], w[64], w[tile_stride], w[tile_stride + 64]}; }
+struct R64Vec { f32x4 g0, b0, g1, b1; };
+__device__ __forceinline__ R64Vec r64_vec(const float* gv, const float* bv, int S, int h) {
+    lds_cf4* const gl = (lds_cf4*)(gv + 4 * h);
+    lds_cf4* const bl = (lds_cf4*)(bv + 4 * h);
+    return R64Vec{gl[4 * S], bl[4 * S], gl[4 * S + 2], bl[4 * S + 2]};
+}
+template <bool FIRST>
+__device__ __forceinline__ void r64_mma_p(f32x16 (&acc)[2], const R64Planes& p, const h8 bhi, const h8 blo) {
+    if (FIRST) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, p.h0), bhi, z, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, p.h1), bhi, z, 0, 0, 0);
+    } else {
+        DSG_MFMA_H(acc[0], __builtin_bit_cast(h8, p.h0), bhi);
+        DSG_MFMA_H(acc[1], __builtin_bit_cast(h8, p.h1), bhi);
+    }
+    DSG_MFMA_H(acc[0], __builtin_bit_cast(h8, p.h0), blo);
+    DSG_MFMA_H(acc[1], __builtin_bit_cast(h8, p.h1), blo);
+    DSG_MFMA_H(acc[0], __builtin_bit_cast(h8, p.l0), bhi);
+    DSG_MFMA_H(acc[1], __builtin_bit_cast(h8, p.l1), bhi);
+}
+// the preparation with its vectors in registers and no scheduling barriers of its own (same arithmetic as panel_prep)
+template <bool LNACT>
+__device__ __forceinline__ void r64_prep_v(const float (&x)[8], const R64Vec& vv, float c, float d, h8& hi, h8& lo) {
+    float v[8];
+    if (LNACT) {
+        constexpr float kk = -1.44269504088896341f / kActScale;
+        const float g[8] = {vv.g0[0], vv.g0[1], vv.g0[2], vv.g0[3], vv.g1[0], vv.g1[1], vv.g1[2], vv.g1[3]};
+        const float b[8] = {vv.b0[0], vv.b0[1], vv.b0[2], vv.b0[3], vv.b1[0], vv.b1[1], vv.b1[2], vv.b1[3]};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float u = fmaf(fmaf(x[q], c, d), g[q], b[q]);
+            v[q] = u * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(u), kk, kk));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x[q] * kRawScale;
+    }
+    split8(v, hi, lo);
+}
+// KS steps; getx(S, x) fills the eight input values of step S; `first` = the accumulators start from zero
+template <bool LNACT, bool FIRST, int KS, typename GetX, typename Extra>
+__device__ __forceinline__ void r64_stage(f32x16 (&acc)[2], lds_cu4* w, int tile_stride, const float* gv, const float* bv, float cc, float dd, int h,
+                                          GetX&& getx, Extra&& extra) {
+    R64Planes pc = r64_planes(w, tile_stride);
+    h8 bh, bl;
+    {
+        R64Vec v0{};
+        if (LNACT) v0 = r64_vec(gv, bv, 0, h);
+        float x[8];
+        getx(0, x);
+        r64_prep_v<LNACT>(x, v0, cc, dd, bh, bl);
+    }
+#pragma unroll
+    for (int S = 0; S < KS; ++S) {
+        R64Planes pn = pc;
+        R64Vec vn{};
+        h8 nh = bh, nl = bl;
+        if (S + 1 < KS) {                               // region A: requests of step S + 1
+            pn = r64_planes(w + (S + 1) * 128, tile_stride);
+            if (LNACT) vn = r64_vec(gv, bv, S + 1, h);
+        }
+        extra(S);                                       // the caller's own requests (next tile's input)
+        __builtin_amdgcn_sched_barrier(0);
+        if (S + 1 < KS) {                               // region B: MFMAs of step S + preparation of step S + 1
+            float x[8];
+            getx(S + 1, x);
+            r64_prep_v<LNACT>(x, vn, cc, dd, nh, nl);
+        }
+        if (FIRST && S == 0) r64_mma_p<true>(acc, pc, bh, bl); else r64_mma_p<false>(acc, pc, bh, bl);
+        if (S + 1 < KS) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, LNACT ? 11 : 4, 0);     // a sixth of the preparation
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pc = pn; bh = nh; bl = nl;
+    }
+}
+
 template <int NQ>
 __device__ __forceinline__ void r64_unscale_add(f32x16 (&acc)[2], float inv, const float* vec, int h) {
     lds_cf4* const v = (lds_cf4*)(vec + 4 * h);
@@ -88,21 +178,50 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr float kL2 = -1.44269504088896341f;
 
-    // ---- the block's planes and vectors -> LDS, once per launch
+    // ---- the block's planes and vectors -> LDS, once per launch.  EVERY load is issued before the first LDS write: written as
+    // `for (i...) lds[i] = src[i]` hipcc emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration, 13 dependent L2 round trips =
+    // 7-8 us of every launch (time against batch size: profiles/r03b_fixed_cost.txt)
     {
-        for (int i = threadIdx.x; i < 2 * KS1 * 128; i += 512) lds[L::W1 + i] = ah.W1h[i];
-        for (int i = threadIdx.x; i < 2 * 4 * 128; i += 512) { lds[L::W2 + i] = ah.W2h[i]; lds[L::W3 + i] = ah.W3h[i]; }
-        if (SCLIN) for (int i = threadIdx.x; i < 2 * KS1 * 128; i += 512) lds[L::WSC + i] = ah.Wsch[i];
-        if (NTO > 0) {
-            for (int i = threadIdx.x; i < NTO * 4 * 128; i += 512) lds[L::WL + i] = A.l.Wh[i];
-            for (int i = threadIdx.x; i < 32 * NTO; i += 512) vec[L::BL + i] = A.l.l.bias[i];
+        constexpr int N1 = 2 * KS1 * 128 / 512, N2 = 2 * 4 * 128 / 512, NL = (NTO * 4 * 128 + 511) / 512;
+        uint4 r1[N1], r2[N2], r3[N2], rs[SCLIN ? N1 : 1], rl[NTO > 0 ? NL : 1];
+        float g1 = 0.f, b1 = 0.f, bl = 0.f, v6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, tb = 0.f;
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < N1; ++k) r1[k] = ah.W1h[tid + 512 * k];
+#pragma unroll
+        for (int k = 0; k < N2; ++k) { r2[k] = ah.W2h[tid + 512 * k]; r3[k] = ah.W3h[tid + 512 * k]; }
+        if (SCLIN) {
+#pragma unroll
+            for (int k = 0; k < N1; ++k) rs[k] = ah.Wsch[tid + 512 * k];
         }
-        for (int i = threadIdx.x; i < 16 * KS1; i += 512) { vec[L::G1 + i] = a.gamma1[i] * kL2; vec[L::B1 + i] = a.beta1[i] * kL2; }
-        if (threadIdx.x < 64) {
-            const int i = threadIdx.x;
-            vec[L::G2 + i] = a.gamma2[i] * kL2; vec[L::B2 + i] = a.beta2[i] * kL2; vec[L::G3 + i] = a.gamma3[i] * kL2; vec[L::B3 + i] = a.beta3[i] * kL2;
-            vec[L::C2 + i] = a.c2[i]; vec[L::C3 + i] = a.c3[i];
-            vec[L::TB + i] = a.tbias[(size_t)(a.step_ptr ? *a.step_ptr : 0) * a.tb_stride + i];
+        if (NTO > 0) {
+#pragma unroll
+            for (int k = 0; k < NL; ++k) if (tid + 512 * k < NTO * 4 * 128) rl[k] = A.l.Wh[tid + 512 * k];
+            if (tid < 32 * NTO) bl = A.l.l.bias[tid];
+        }
+        if (tid < 16 * KS1) { g1 = a.gamma1[tid]; b1 = a.beta1[tid]; }
+        if (tid < 64) {
+            v6[0] = a.gamma2[tid]; v6[1] = a.beta2[tid]; v6[2] = a.gamma3[tid]; v6[3] = a.beta3[tid]; v6[4] = a.c2[tid]; v6[5] = a.c3[tid];
+            tb = a.tbias[(size_t)(a.step_ptr ? *a.step_ptr : 0) * a.tb_stride + tid];
+        }
+#pragma unroll
+        for (int k = 0; k < N1; ++k) lds[L::W1 + tid + 512 * k] = r1[k];
+#pragma unroll
+        for (int k = 0; k < N2; ++k) { lds[L::W2 + tid + 512 * k] = r2[k]; lds[L::W3 + tid + 512 * k] = r3[k]; }
+        if (SCLIN) {
+#pragma unroll
+            for (int k = 0; k < N1; ++k) lds[L::WSC + tid + 512 * k] = rs[k];
+        }
+        if (NTO > 0) {
+#pragma unroll
+            for (int k = 0; k < NL; ++k) if (tid + 512 * k < NTO * 4 * 128) lds[L::WL + tid + 512 * k] = rl[k];
+            if (tid < 32 * NTO) vec[L::BL + tid] = bl;
+        }
+        if (tid < 16 * KS1) { vec[L::G1 + tid] = g1 * kL2; vec[L::B1 + tid] = b1 * kL2; }
+        if (tid < 64) {
+            vec[L::G2 + tid] = v6[0] * kL2; vec[L::B2 + tid] = v6[1] * kL2; vec[L::G3 + tid] = v6[2] * kL2; vec[L::B3 + tid] = v6[3] * kL2;
+            vec[L::C2 + tid] = v6[4]; vec[L::C3 + tid] = v6[5];
+            vec[L::TB + tid] = tb;
         }
     }
     const float inv1 = ah.kc[0], inv2 = ah.kc[1], inv3 = ah.kc[2];
@@ -175,13 +294,11 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
         f32x16 acc1[NT];
         {
             const float cc = rstd1, dd = -mean1 * rstd1;
-#pragma unroll
-            for (int S = 0; S < KS1; ++S) {
-                const float x[8] = {xc[2 * S].x, xc[2 * S].y, xc[2 * S].z, xc[2 * S].w, xc[2 * S + 1].x, xc[2 * S + 1].y, xc[2 * S + 1].z, xc[2 * S + 1].w};
-                h8 bhi, blo;
-                r64_prep<true>(x, vec + L::G1, vec + L::B1, S, cc, dd, h, bhi, blo);
-                if (S == 0) r64_mma<true>(acc1, w1 + S * 128, KS1 * 128, bhi, blo); else r64_mma<false>(acc1, w1 + S * 128, KS1 * 128, bhi, blo);
-            }
+            r64_stage<true, true, KS1>(acc1, w1, KS1 * 128, vec + L::G1, vec + L::B1, cc, dd, h,
+                                       [&](int S, float (&x)[8]) {
+                                           x[0] = xc[2 * S].x; x[1] = xc[2 * S].y; x[2] = xc[2 * S].z; x[3] = xc[2 * S].w;
+                                           x[4] = xc[2 * S + 1].x; x[5] = xc[2 * S + 1].y; x[6] = xc[2 * S + 1].z; x[7] = xc[2 * S + 1].w;
+                                       }, [](int) {});
         }
         r64_unscale_add<8>(acc1, inv1, vec + L::TB, h);
 
@@ -191,14 +308,12 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
             float mean, m2;
             acc_stats<N, NT>(acc1, h, mean, m2);
             const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
+            r64_stage<true, true, 4>(acc2, w2, 4 * 128, vec + L::G2, vec + L::B2, cc, dd, h,
+                                     [&](int S, float (&x)[8]) {
+                                         const int t = S >> 1, r0 = 8 * (S & 1);
 #pragma unroll
-            for (int S = 0; S < 4; ++S) {
-                const int t = S >> 1, r0 = 8 * (S & 1);
-                const float x[8] = {acc1[t][r0], acc1[t][r0 + 1], acc1[t][r0 + 2], acc1[t][r0 + 3], acc1[t][r0 + 4], acc1[t][r0 + 5], acc1[t][r0 + 6], acc1[t][r0 + 7]};
-                h8 bhi, blo;
-                r64_prep<true>(x, vec + L::G2, vec + L::B2, S, cc, dd, h, bhi, blo);
-                if (S == 0) r64_mma<true>(acc2, w2 + S * 128, 4 * 128, bhi, blo); else r64_mma<false>(acc2, w2 + S * 128, 4 * 128, bhi, blo);
-            }
+                                         for (int q = 0; q < 8; ++q) x[q] = acc1[t][r0 + q];
+                                     }, [](int) {});
             r64_unscale_add<8>(acc2, inv2, vec + L::C2, h);
         }
         if (cur.cond) {
@@ -215,14 +330,12 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
             float mean, m2;
             acc_stats<N, NT>(acc2, h, mean, m2);
             const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
+            r64_stage<true, true, 4>(acc3, w3, 4 * 128, vec + L::G3, vec + L::B3, cc, dd, h,
+                                     [&](int S, float (&x)[8]) {
+                                         const int t = S >> 1, r0 = 8 * (S & 1);
 #pragma unroll
-            for (int S = 0; S < 4; ++S) {
-                const int t = S >> 1, r0 = 8 * (S & 1);
-                const float x[8] = {acc2[t][r0], acc2[t][r0 + 1], acc2[t][r0 + 2], acc2[t][r0 + 3], acc2[t][r0 + 4], acc2[t][r0 + 5], acc2[t][r0 + 6], acc2[t][r0 + 7]};
-                h8 bhi, blo;
-                r64_prep<true>(x, vec + L::G3, vec + L::B3, S, cc, dd, h, bhi, blo);
-                if (S == 0) r64_mma<true>(acc3, w3 + S * 128, 4 * 128, bhi, blo); else r64_mma<false>(acc3, w3 + S * 128, 4 * 128, bhi, blo);
-            }
+                                         for (int q = 0; q < 8; ++q) x[q] = acc2[t][r0 + q];
+                                     }, [](int) {});
         }
 
         // ---- shortcut / residual from the SAME registers stage 1 read; the next tile's input is requested step by step behind it
@@ -230,14 +343,12 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
         float2 s0n, s1n;
         s0n = *nxt.st0; s1n = *nxt.st1;
         if (SCLIN) {
-#pragma unroll
-            for (int S = 0; S < KS1; ++S) {
-                const float x[8] = {xc[2 * S].x, xc[2 * S].y, xc[2 * S].z, xc[2 * S].w, xc[2 * S + 1].x, xc[2 * S + 1].y, xc[2 * S + 1].z, xc[2 * S + 1].w};
-                xn[2 * S] = ld4(xsrc(nxt, 2 * S)); xn[2 * S + 1] = ld4(xsrc(nxt, 2 * S + 1));
-                h8 bhi, blo;
-                r64_prep<false>(x, nullptr, nullptr, 0, 0.f, 0.f, h, bhi, blo);
-                r64_mma<false>(acc3, wsc + S * 128, KS1 * 128, bhi, blo);
-            }
+            r64_stage<false, false, KS1>(acc3, wsc, KS1 * 128, nullptr, nullptr, 0.f, 0.f, h,
+                                         [&](int S, float (&x)[8]) {
+                                             x[0] = xc[2 * S].x; x[1] = xc[2 * S].y; x[2] = xc[2 * S].z; x[3] = xc[2 * S].w;
+                                             x[4] = xc[2 * S + 1].x; x[5] = xc[2 * S + 1].y; x[6] = xc[2 * S + 1].z; x[7] = xc[2 * S + 1].w;
+                                         },
+                                         [&](int S) { xn[2 * S] = ld4(xsrc(nxt, 2 * S)); xn[2 * S + 1] = ld4(xsrc(nxt, 2 * S + 1)); });
             r64_unscale_add<8>(acc3, inv3, vec + L::C3, h);
         } else {
             r64_unscale_add<8>(acc3, inv3, vec + L::C3, h);

@@ -1212,10 +1212,21 @@ struct NarrowPhaseArgs {
 __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __restrict__ ops, const NarrowLdsOp* __restrict__ lops, const NarrowPhaseArgs ph,
                                                               int ntiles, const int* step_ptr, int tb_stride) {
     __shared__ uint4 lds[kNarrowLdsU4];
-    {   // the phase's image: every thread copies 16-byte pieces
-        for (unsigned i = threadIdx.x; i < ph.n_u4; i += 1024) lds[i] = ph.image[i];
+    {   // the phase's image: every thread copies 16-byte pieces -- ALL loads first, then the LDS writes (written as one copy loop
+        // hipcc waits for each load before the next one is issued: ten dependent L2 round trips per launch)
+        constexpr int MAXB = (kNarrowLdsU4 + 1023) / 1024;
+        const unsigned tid = threadIdx.x;
         const uint4* tbs = reinterpret_cast<const uint4*>(ph.tb + (size_t)(step_ptr ? *step_ptr : 0) * tb_stride);
-        for (unsigned i = threadIdx.x; i < ph.tb_u4; i += 1024) lds[ph.n_u4 + i] = tbs[i];
+        uint4 v[MAXB], tv = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (tid + 1024u * b < ph.n_u4) v[b] = ph.image[tid + 1024u * b];
+        if (tid < ph.tb_u4) tv = tbs[tid];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (tid + 1024u * b < ph.n_u4) lds[tid + 1024u * b] = v[b];
+        if (tid < ph.tb_u4) lds[ph.n_u4 + tid] = tv;
+        for (unsigned i = tid + 1024u; i < ph.tb_u4; i += 1024) lds[ph.n_u4 + i] = tbs[i];   // (a phase's time-bias slice is < 1024 pieces)
     }
     const int op_lo = ph.op_lo, op_hi = ph.op_hi;
     __syncthreads();
