@@ -1212,21 +1212,13 @@ struct NarrowPhaseArgs {
 __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __restrict__ ops, const NarrowLdsOp* __restrict__ lops, const NarrowPhaseArgs ph,
                                                               int ntiles, const int* step_ptr, int tb_stride) {
     __shared__ uint4 lds[kNarrowLdsU4];
-    {   // the phase's image: every thread copies 16-byte pieces -- ALL loads first, then the LDS writes (written as one copy loop
-        // hipcc waits for each load before the next one is issued: ten dependent L2 round trips per launch)
-        constexpr int MAXB = (kNarrowLdsU4 + 1023) / 1024;
-        const unsigned tid = threadIdx.x;
+    {   // the phase's image: every thread copies 16-byte pieces, one piece in flight per thread.  More loads in flight per thread
+        // are SLOWER here (same box, us per launch: 1 or 2 pieces 75.3, 4 pieces 80.7, all ten 84.3): 256 workgroups pull the same
+        // 75-150 KiB from L2 at the same moment, and the burst costs more than the round trips it saves.  The staging is 7 us of a
+        // phase's 60 / 89 us (same box, staging skipped: 53 / 82).
         const uint4* tbs = reinterpret_cast<const uint4*>(ph.tb + (size_t)(step_ptr ? *step_ptr : 0) * tb_stride);
-        uint4 v[MAXB], tv = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b)
-            if (tid + 1024u * b < ph.n_u4) v[b] = ph.image[tid + 1024u * b];
-        if (tid < ph.tb_u4) tv = tbs[tid];
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b)
-            if (tid + 1024u * b < ph.n_u4) lds[tid + 1024u * b] = v[b];
-        if (tid < ph.tb_u4) lds[ph.n_u4 + tid] = tv;
-        for (unsigned i = tid + 1024u; i < ph.tb_u4; i += 1024) lds[ph.n_u4 + i] = tbs[i];   // (a phase's time-bias slice is < 1024 pieces)
+        for (unsigned i = threadIdx.x; i < ph.n_u4; i += 1024) lds[i] = ph.image[i];
+        for (unsigned i = threadIdx.x; i < ph.tb_u4; i += 1024) lds[ph.n_u4 + i] = tbs[i];
     }
     const int op_lo = ph.op_lo, op_hi = ph.op_hi;
     __syncthreads();
