@@ -96,8 +96,9 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
  *         computed by the caller from the registered buffers so that their float64->float32 casts are kept);
  *   y_T   [B][D] start state, or NULL to draw it on the device (Philox, `seed`);
  *   noise [T-2][B][D] the z of steps i = T-1 .. 2 in that order, or NULL to draw on the device;
- *   flags DSG_SAMPLE_NO_GRAPH: launch eagerly instead of replaying the captured graph (schedules of up to 64 steps are ONE graph
- *         of the whole reverse loop, longer ones replay a per-step graph T times; the step index is a device counter). */
+ *   flags DSG_SAMPLE_NO_GRAPH: launch eagerly instead of replaying the captured graphs (per workspace shape: one early step and
+ *         runs of 1, 2, 4, 8, 16, 32 later steps; a call replays min(T, 4) early steps and the binary decomposition of the rest --
+ *         T = 20 is five graph launches; the step index is a device counter, so the graphs do not depend on T). */
 #define DSG_SAMPLE_NO_GRAPH 1
 /*         DSG_SAMPLE_PROFILE: eager launch with one HIP-event pair around every operator launch on `stream`
  *         (synchronises once per step); read the totals back with dsg_op_profile. */
