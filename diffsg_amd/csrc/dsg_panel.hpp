@@ -166,7 +166,23 @@ __device__ __forceinline__ float silu_scaled_l2s(float up) {
 // across the whole tile loop and spilled them)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
-template <bool LNACT>
+// lo part of the split: v - float(half of `hi`), one v_fma_mix_f32 (f32 * 1.0 - f16): hipcc picks cvt + sub (two instructions) in
+// this context.  Not volatile: an ordinary instruction for the scheduler.
+__device__ __forceinline__ float sub_half_lo(float v, unsigned hi) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float sub_half_hi(float v, unsigned hi) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hi));
+    return r;
+}
+
+// ASM_SPLIT: the hi/lo split exactly as panel_pipe does it (the lo part from the ROUNDED product through v_fma_mix; in the plain form
+// hipcc contracts `u * r - hi` into one fma, which moves the last bit of lo): a tile whose first panel is prepared here on one
+// occasion and inside panel_pipe on another must get the same bits (rows do not depend on their position in the batch)
+template <bool LNACT, bool ASM_SPLIT = false>
 __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamma, const float* beta, int S, float c, float d, int h) {
     float v[8];
     if (DSG_PANEL_VDBG & 1) {
@@ -208,6 +224,20 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
         const uint4 ua = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
         const uint4 ub = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
         o.hi = __builtin_bit_cast(h8, ua); o.lo = __builtin_bit_cast(h8, ub);
+        return o;
+    }
+    if (ASM_SPLIT) {
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v0 = v[2 * q], v1 = v[2 * q + 1];
+            asm volatile("" : "+v"(v0), "+v"(v1));          // the rounded products, as values
+            const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+            hh[q] = a;
+            ll[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(sub_half_lo(v0, a), sub_half_hi(v1, a)));
+        }
+        const uint4 uh = {hh[0], hh[1], hh[2], hh[3]}, ul = {ll[0], ll[1], ll[2], ll[3]};
+        o.hi = __builtin_bit_cast(h8, uh); o.lo = __builtin_bit_cast(h8, ul);
         return o;
     }
     split8(v, o.hi, o.lo);
@@ -330,19 +360,6 @@ __device__ __forceinline__ void mfma_pin0(f32x16& c, const uint4 a, const h8 b, 
 // for the item, requests the one kPrivDist places ahead and returns the slot.
 enum { PIPE_REG = 1, PIPE_LN = 2, PIPE_RAW = 3 };
 typedef __attribute__((address_space(3))) const f32x2 lds_cf2g;
-
-// lo part of the split: v - float(half of `hi`), one v_fma_mix_f32 (f32 * 1.0 - f16): hipcc picks cvt + sub (two instructions) in
-// this context.  Not volatile: an ordinary instruction for the scheduler.
-__device__ __forceinline__ float sub_half_lo(float v, unsigned hi) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ float sub_half_hi(float v, unsigned hi) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hi));
-    return r;
-}
 
 template <bool FIRST, int PREP, typename Consume>
 __device__ __forceinline__ void panel_pipe(f32x16 (&acc)[4], const uint4* pn /* + lane */, const BOp4& b, BOp4& bn, const f32x16 (&in)[4], int S0,
@@ -539,6 +556,13 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     // sources of the concatenated input by k16-step (stage 1 and the shortcut / residual read the same tensors)
     auto xin = [&](const TilePtrs& t, int S) -> const char* { return SCLIN && S >= 8 ? t.x1 + (size_t)(S - 8) * 2048 : t.x0 + (size_t)S * 2048; };
 
+    // XT (up block without an epilogue Linear): the first panel of a tile's stage 1 is prepared under the MFMAs of the PREVIOUS tile's
+    // last shortcut panel (which has nothing of its own to prepare) instead of on its own -- 5 000 vector-only cycles per tile during
+    // which the eight waves of the CU, in lock-step, all left the matrix cores idle.  Carried across the loop: the operands and the
+    // LayerNorm constants of the coming tile.
+    constexpr bool XT = SCLIN && EPI == 0;
+    BOp4 bcar;
+    float cc_car = 0.f, dd_car = 0.f;
     for (int g = blockIdx.x; g < ngroups; g += stride) {
         const int tile_raw = g * kPW + wave;
         const bool live = tile_raw < a.ntiles;          // idle waves of the last group still move their pieces and meet the barriers
@@ -571,41 +595,45 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
         };
         auto no_consume = [&](int) -> const uint4* { return nullptr; };
 
-        // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as resblock_body_h
-        float mean1, rstd1;
-        {
+        // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as resblock_body_h; `t` = the tile they belong to
+        auto ln1_stats = [&](const TilePtrs& t, float& cc, float& dd) {
             const uint4* rd = priv_consume(c);
             const float2* sp = reinterpret_cast<const float2*>(rd - lane);     // slot base
             const float2 s0 = sp[j];
             float mean = s0.x, m2 = s0.y;
             if (SCLIN) {
                 const float2 s1 = sp[32 + j];
-                const float dd = s1.x - mean;
-                m2 = m2 + s1.y + dd * dd * a.chan_w;
-                mean = mean + dd * a.chan_f;
+                const float dd_ = s1.x - mean;
+                m2 = m2 + s1.y + dd_ * dd_ * a.chan_w;
+                mean = mean + dd_ * a.chan_f;
             }
-            priv_issue(c, cur.x0 + 3 * 2048); since_w += 2;
-            mean1 = mean;
-            rstd1 = rsqrtf(m2 * a.inv_nin + kLnEps);
+            priv_issue(c, t.x0 + 3 * 2048); since_w += 2;
+            const float rstd = rsqrtf(m2 * a.inv_nin + kLnEps);
             if (SCLIN) range_check(a.range_flag, mean, m2);
-        }
+            cc = rstd; dd = -mean * rstd;
+        };
 
-        // ---- stage 1: memory-fed, LayerNorm + SiLU.  Panel 0's operands are prepared on their own, the others under the MFMAs
-        // of the panel before them.
+        // ---- stage 1: memory-fed, LayerNorm + SiLU.  Panel 0's operands are prepared on their own (first tile of the workgroup; every
+        // tile where !XT) or arrive from the previous tile's last panel; the others under the MFMAs of the panel before them.
         f32x16 acc1[NT];
         {
-            const float cc = rstd1, dd = -mean1 * rstd1;
+            float cc, dd;
             BOp4 b;
-            DSG_PSTAMP(0x10);
+            if (!XT || g == (int)blockIdx.x) {
+                ln1_stats(cur, cc, dd);
+                DSG_PSTAMP(0x10);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const uint4* rd = consume_s1(s4);
-                const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
-                const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                const BOp o = panel_prep<true>(x, g1v, b1v, s4, cc, dd, h);
-                b.hi[s4] = o.hi; b.lo[s4] = o.lo;
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const uint4* rd = consume_s1(s4);
+                    const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
+                    const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                    const BOp o = panel_prep<true, XT>(x, g1v, b1v, s4, cc, dd, h);
+                    b.hi[s4] = o.hi; b.lo[s4] = o.lo;
+                }
+                v_phase_done(b);
+            } else {
+                b = bcar; cc = cc_car; dd = dd_car;
             }
-            v_phase_done(b);
             DSG_PSTAMP(0x11);
 #pragma unroll
             for (int p = 0; p < P1; ++p) {
@@ -693,6 +721,14 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
                     if (p + 1 < P1) {
                         panel_pipe<false, PIPE_RAW>(acc3, c.wrd + bi * kPanelU4, b, bn, acc3, 0, g3v, b3v, 1.f, 0.f, h, [&](int jj) { return consume_sc(4 * (p + 1) + jj); });
                         b = bn;
+                    } else if (XT) {
+                        // the coming tile (the same one again behind the workgroup's last group: its requests are in flight either way)
+                        ln1_stats(nxt, cc_car, dd_car);
+                        panel_pipe<false, PIPE_LN>(acc3, c.wrd + bi * kPanelU4, b, bcar, acc3, 0, g1v, b1v, cc_car, dd_car, h, [&](int jj) {
+                            const uint4* rd = priv_consume(c);
+                            priv_issue(c, xin(nxt, jj + 4)); since_w += 2;
+                            return rd;
+                        });
                     } else {
                         M_PHASE<false>(acc3, c.w_rd + (unsigned)bi * (kPanelU4 * 16u), b, c.wrd);
                     }
