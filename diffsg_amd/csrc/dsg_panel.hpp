@@ -249,8 +249,8 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
 //   M: 48 MFMAs over the panel with nothing but the panel's plane reads between them (the planes of step s+1 are requested
 //      under the MFMAs of step s).
 // Why: with the operand preparation of a step sitting between its LDS reads and its MFMAs, every step was a chain of exposed
-// latencies (LDS round trip -> dependent VALU chain -> 12 MFMAs each waiting for its just-requested plane): profiles/r03b,
-// 36 % of wave cycles in s_waitcnt and 30 % in issue stalls.  The M phase has no dependence on anything but LDS reads issued
+// latencies (LDS round trip -> dependent VALU chain -> 12 MFMAs each waiting for its just-requested plane): the first
+// panel kernel's PMC passes: 36 % of wave cycles in s_waitcnt and 30 % in issue stalls.  The M phase has no dependence on anything but LDS reads issued
 // a step ahead; the V phase no MFMA to wait for.  The operands of four steps are 32 registers.
 struct BOp4 { h8 hi[4], lo[4]; };
 // The operands are COMPLETE here: without this the compiler sinks the whole preparation behind the panel's barrier, next to the

@@ -179,8 +179,8 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
     constexpr float kL2 = -1.44269504088896341f;
 
     // ---- the block's planes and vectors -> LDS, once per launch.  EVERY load is issued before the first LDS write: written as
-    // `for (i...) lds[i] = src[i]` hipcc emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration, 13 dependent L2 round trips =
-    // 7-8 us of every launch (time against batch size: profiles/r03b_fixed_cost.txt)
+    // `for (i...) lds[i] = src[i]` hipcc emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration, 13 dependent L2 round trips (1 us of
+    // the 5-6 us every launch costs before its first tile: profiles/r03c_fixed_cost.txt)
     {
         constexpr int N1 = 2 * KS1 * 128 / 512, N2 = 2 * 4 * 128 / 512, NL = (NTO * 4 * 128 + 511) / 512;
         uint4 r1[N1], r2[N2], r3[N2], rs[SCLIN ? N1 : 1], rl[NTO > 0 ? NL : 1];
