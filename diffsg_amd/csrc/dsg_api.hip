@@ -199,6 +199,7 @@ struct dsg_handle {
     // LDS-resident form of the narrow run (k_fused_narrow_lds): per-operator LDS offsets, the copy list of every phase, the phases
     NarrowLdsOp* nlds_ops_dev = nullptr; NarrowLdsCopy* nlds_copies_dev = nullptr; uint4* nlds_image = nullptr;
     std::vector<NarrowPhaseArgs> nlds_phases;
+    bool nlds_tail = false;            // the LDS form of the run also computes the 64-wide Linear at ops[fuse_hi] (kind 2)
     bool nlds_valid = false;
 
     // cached step graphs: per-step pair (with / without the renorm kernels), keyed by (rows, chunks); and ONE graph of a whole
@@ -880,13 +881,32 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
             f.kind = kind; f.N = N; f.sclin = sclin; f.b = b; f.l = l;
         }
     }
-    if (sp) HIPCK(hipMemcpyAsync(c.train ? h->fusedh_train_dev : h->fusedh_dev, h->fusedh_host.data(), n * sizeof(FusedOpH), hipMemcpyHostToDevice, s));
+    // the Linear behind the run (Upsample 32 -> 64 of the shipped nets): the LDS form of the run computes it from the registers of
+    // the run's last tensor (one launch and one round trip of that tensor less); entry n of the table, read by that form only
+    bool tail = false;
+    if (sp && !c.train && !c.ts && h->fuse_hi < (int)h->ops.size()) {
+        const Op& t = h->ops[h->fuse_hi];
+        const Op& last = h->ops[h->fuse_hi - 1];
+        if (t.kind == OP_LIN && t.in0 == last.out && !h->tensors[last.out].is_skip && !h->lin[t.p].lnact && h->lin[t.p].l.N == 64 && h->lin[t.p].l.K <= 32) {
+            LinArgs l;
+            memset(&l, 0, sizeof l);
+            fill_lin_args(h, t, c, l);
+            h->fusedh_host.resize(n + 1);
+            FusedOpH& f = h->fusedh_host[n];
+            memset(&f, 0, sizeof f);
+            f.kind = 2; f.N = 64; f.store_out = 1;
+            fill_lin_args_h(h, h->lin[t.p], l, f.l);
+            tail = true;
+        }
+    }
+    if (sp) HIPCK(hipMemcpyAsync(c.train ? h->fusedh_train_dev : h->fusedh_dev, h->fusedh_host.data(), h->fusedh_host.size() * sizeof(FusedOpH), hipMemcpyHostToDevice, s));
     else HIPCK(hipMemcpyAsync(h->fused_dev, h->fused_host.data(), n * sizeof(FusedOp), hipMemcpyHostToDevice, s));
     h->nlds_valid = false;
+    h->nlds_tail = false;
     if (sp && !c.train && !c.ts) {
         // LDS image of the run, cut into phases that fit kNarrowLdsU4: per operator its packed planes and per-feature vectors (static:
         // gathered once into h->nlds_image, a phase's part contiguous) and, behind them, the phase's slice of the time-table row
-        std::vector<NarrowLdsOp> lops(n);
+        std::vector<NarrowLdsOp> lops(n + 1);
         std::vector<NarrowLdsCopy> copies;                 // dst_u4: offset in the GLOBAL image buffer
         h->nlds_phases.clear();
         unsigned used = 0, image_base = 0;                 // used: static part of the current phase
@@ -960,14 +980,38 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
                 lo.c2 = 4 * take(A + l.bp, 8);
             }
         }
+        int n_all = n;
+        if (fits && n > 0 && tail) {
+            // the tail Linear's planes (2 out tiles x 2 steps) and bias join the last phase when they fit
+            const LinOpP& l = h->lin[h->ops[h->fuse_hi].p];
+            const unsigned KSl = (groups_of(l.l.K) + 1) / 2, need = 2 * KSl * 128 + 16;
+            const unsigned tb_now = tb_first < 0 ? 0 : (unsigned)(tb_last_end - tb_first) / 4;
+            if (used + need + tb_now <= (unsigned)kNarrowLdsU4) {
+                NarrowLdsOp& lo = lops[n];
+                memset(&lo, 0, sizeof lo);
+                lo.store_out = 1;
+                const float* A = h->arena;
+                auto take = [&](const void* src, unsigned n_u4) -> unsigned {
+                    const unsigned off = used;
+                    copies.push_back(NarrowLdsCopy{src, image_base + off, n_u4});
+                    used += n_u4;
+                    return off;
+                };
+                lo.w1 = take(A + l.Wh, 2 * KSl * 128);
+                lo.c2 = 4 * take(A + l.bp, 16);
+                n_all = n + 1;
+                if (phase_lo < n) lops[n - 1].store_out = 0;      // the run's last tensor stays in registers: only the tail reads it
+            }
+        }
         if (fits && n > 0) {
-            close_phase(n);
+            close_phase(n_all);
             const size_t image_u4 = image_base;
             if (!h->nlds_ops_dev) HIPCK(hipMalloc(&h->nlds_ops_dev, (h->ops.size() + 1) * sizeof(NarrowLdsOp)));
             if (!h->nlds_copies_dev) HIPCK(hipMalloc(&h->nlds_copies_dev, (h->ops.size() + 1) * 16 * sizeof(NarrowLdsCopy)));
             if (h->nlds_image) (void)hipFree(h->nlds_image);
             HIPCK(hipMalloc(&h->nlds_image, (image_u4 + 1) * sizeof(uint4)));
-            HIPCK(hipMemcpy(h->nlds_ops_dev, lops.data(), n * sizeof(NarrowLdsOp), hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(h->nlds_ops_dev, lops.data(), n_all * sizeof(NarrowLdsOp), hipMemcpyHostToDevice));
+            h->nlds_tail = n_all > n;
             HIPCK(hipMemcpy(h->nlds_copies_dev, copies.data(), copies.size() * sizeof(NarrowLdsCopy), hipMemcpyHostToDevice));
             for (size_t k = 0; k < h->nlds_phases.size(); ++k) h->nlds_phases[k].image = h->nlds_image + phase_base[k];
             hipLaunchKernelGGL(k_narrow_image_build, dim3((unsigned)copies.size()), dim3(256), 0, s, (const NarrowLdsCopy*)h->nlds_copies_dev, h->nlds_image);
@@ -977,7 +1021,8 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
     return 0;
 }
 
-void launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
+// returns the number of operators BEHIND the run that the launch computed as well (0, or 1: the LDS form's tail Linear)
+int launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     const int ntiles = cdiv(c.nrows, 32) * c.npass;
     const dim3 grid(cdiv(ntiles, kWavesPerBlock)), block(256);
     if (split_ctx(h, c)) {
@@ -988,12 +1033,13 @@ void launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
             for (const auto& ph : h->nlds_phases)
                 hipLaunchKernelGGL(k_fused_narrow_lds, dim3(cdiv(ntiles, 16)), dim3(1024), 0, s, tab, (const NarrowLdsOp*)h->nlds_ops_dev, ph, ntiles, c.step_ptr,
                                    h->tb_stride);
-            return;
+            return h->nlds_tail ? 1 : 0;
         }
         if (ntiles <= h->narrow_small_max_tiles) hipLaunchKernelGGL(k_fused_narrow_h<true>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
         else hipLaunchKernelGGL(k_fused_narrow_h<false>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
     }
     else hipLaunchKernelGGL(k_fused_narrow, grid, block, 0, s, h->fused_dev, h->fuse_hi - h->fuse_lo, ntiles);
+    return 0;
 }
 
 // wide block followed by its consuming Linear (Down/Upsample or final), both outside the fused narrow run
@@ -1017,8 +1063,7 @@ void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     const bool fuse = (!c.train || split_ctx(h, c)) && h->fuse_hi - h->fuse_lo >= 2;
     for (int i = 0; i < (int)h->ops.size(); ++i) {
         if (fuse && i == h->fuse_lo) {
-            launch_fused(h, c, s);
-            i = h->fuse_hi - 1;
+            i = h->fuse_hi - 1 + launch_fused(h, c, s);
             continue;
         }
         if (try_pair(h, i, c, s)) { ++i; continue; }
@@ -1847,11 +1892,12 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
     if (ev) {  // DSG_SAMPLE_PROFILE: one event pair per operator launch
         const bool fuse = h->fuse_hi - h->fuse_lo >= 2;
         bool skip_next = false;
+        int tail = 0;
         for (size_t i = 0; i < h->ops.size(); ++i) {
             HIPCK(hipEventRecord(ev[2 * i], s));
             // the fused narrow run is one launch: its time is booked on its first operator, the others read ~0
-            if (fuse && (int)i == h->fuse_lo) launch_fused(h, c, s);
-            else if (fuse && (int)i > h->fuse_lo && (int)i < h->fuse_hi) {}
+            if (fuse && (int)i == h->fuse_lo) tail = launch_fused(h, c, s);
+            else if (fuse && (int)i > h->fuse_lo && (int)i < h->fuse_hi + tail) {}
             else if (skip_next) { skip_next = false; }   // consumed by the pair launch booked on the previous operator
             else if (try_pair(h, (int)i, c, s)) skip_next = true;
             else launch_op(h, h->ops[i], c, s);

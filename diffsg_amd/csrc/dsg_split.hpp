@@ -1099,6 +1099,40 @@ __device__ __forceinline__ void linear_reg_h(const LinArgsH& ah, const int tile,
     }
 }
 
+// Linear with register input (in width <= 32) and a 32 * NTO wide output that leaves the run: the Upsample behind the last narrow
+// block (k_fused_narrow_lds, operator kind 2) -- always stored, with its row statistics
+template <int NTO>
+__device__ __forceinline__ void linear_reg_out_h(const LinArgsH& ah, const int tile, const int lane, const f32x16 (&x)[1], float xmean, float xm2) {
+    const LinArgs& a = ah.l;
+    const int h = lane >> 5, j = lane & 31;
+    const int KS = (a.in_groups + 1) >> 1;
+    f32x16 acc[NTO];
+    range_check(a.range_flag, xmean, xm2);
+    chain_raw_from_reg_h<NTO, 1, true>(acc, x, a.in_groups, ah.Wh, (size_t)KS * 128, lane);
+    acc_unscale_add<NTO>(acc, ah.kc[0], a.bias, h);
+    const int NG = (a.out_width + 7) / 8;
+    float s = 0.f;
+#pragma unroll
+    for (int G = 0; G < 4 * NTO; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (8 * G + 4 * h + p < a.out_width) s += acc[G >> 2][4 * (G & 3) + p];
+    const float m = xhalf_sum(s) * a.inv_out_w;
+    float q = 0.f;
+#pragma unroll
+    for (int G = 0; G < 4 * NTO; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (8 * G + 4 * h + p < a.out_width) { const float d = acc[G >> 2][4 * (G & 3) + p] - m; q = fmaf(d, d, q); }
+    q = xhalf_sum(q);
+    if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
+#pragma unroll
+    for (int G = 0; G < 4 * NTO; ++G)
+        if (G < NG)
+            st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
+}
+
 template <bool PRE>
 __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles) {
     const int lane = threadIdx.x & 63;
@@ -1269,6 +1303,11 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
                     default: resblock_body_h<32, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                 }
             }
+        } else if (op.kind == 2) {
+            // the 64-wide Linear that consumes the run's last tensor (Upsample): input from registers, output to memory
+            LinArgsH l = op.l;
+            l.Wh = lds + lo.w1; l.l.bias = ldsf + lo.c2;
+            linear_reg_out_h<2>(l, tile, lane, x, xmean, xm2);
         } else {
             LinArgsH l = op.l;
             l.Wh = lds + lo.w1; l.l.bias = ldsf + lo.c2;
