@@ -1059,6 +1059,31 @@ bool try_pair(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
     return launch_res_lin_h(h, r, ba, h->lin[b.p], la, b.kind == OP_FINAL, h->tensors[a.out].is_skip, s);
 }
 
+// two consecutive down-64 blocks of a large sampling launch in one launch (k_res64_dual)
+bool try_dual64(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
+    if (!split_ctx(h, c) || c.train || i + 1 >= (int)h->ops.size()) return false;
+    const Op& oa = h->ops[i];
+    const Op& ob = h->ops[i + 1];
+    if (oa.kind != OP_RES || ob.kind != OP_RES || ob.in0 != oa.out) return false;
+    const bool fuse = h->fuse_hi - h->fuse_lo >= 2;
+    if (fuse && i + 1 >= h->fuse_lo && i < h->fuse_hi) return false;
+    const ResP& ra = h->res[oa.p];
+    const ResP& rb = h->res[ob.p];
+    if (ra.N != 64 || rb.N != 64 || ra.sclin || rb.sclin) return false;
+    BlockArgs ba, bb;
+    fill_block_args(h, oa, c, ba);
+    fill_block_args(h, ob, c, bb);
+    if (!res64_lds_ok(h, ra, ba) || !res64_lds_ok(h, rb, bb)) return false;
+    if (bb.in0.wrap || ba.ntiles != bb.ntiles || ba.tiles_per_pass != bb.tiles_per_pass || ba.uncond_tiles != bb.uncond_tiles) return false;
+    BlockArgsH a0, a1;
+    fill_block_args_h(h, ra, ba, a0);
+    fill_block_args_h(h, rb, bb, a1);
+    const int ngroups = cdiv(ba.ntiles, kR64Waves);
+    const dim3 grid(ngroups < h->num_cus ? ngroups : h->num_cus), block(kR64Waves * 64);
+    hipLaunchKernelGGL(k_res64_dual, grid, block, 0, s, a0, a1, ngroups);
+    return true;
+}
+
 void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
     const bool fuse = (!c.train || split_ctx(h, c)) && h->fuse_hi - h->fuse_lo >= 2;
     for (int i = 0; i < (int)h->ops.size(); ++i) {
@@ -1066,7 +1091,7 @@ void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
             i = h->fuse_hi - 1 + launch_fused(h, c, s);
             continue;
         }
-        if (try_pair(h, i, c, s)) { ++i; continue; }
+        if (try_dual64(h, i, c, s) || try_pair(h, i, c, s)) { ++i; continue; }
         launch_op(h, h->ops[i], c, s);
     }
 }
@@ -1899,7 +1924,7 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
             if (fuse && (int)i == h->fuse_lo) tail = launch_fused(h, c, s);
             else if (fuse && (int)i > h->fuse_lo && (int)i < h->fuse_hi + tail) {}
             else if (skip_next) { skip_next = false; }   // consumed by the pair launch booked on the previous operator
-            else if (try_pair(h, (int)i, c, s)) skip_next = true;
+            else if (try_dual64(h, (int)i, c, s) || try_pair(h, (int)i, c, s)) skip_next = true;
             else launch_op(h, h->ops[i], c, s);
             HIPCK(hipEventRecord(ev[2 * i + 1], s));
         }

@@ -430,4 +430,165 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
     }
 }
 
+// ---- two consecutive down-64 blocks (no Linear shortcut, no consuming Linear) in ONE launch: both blocks' planes are resident
+// (2 x 48 KiB), the first block's output is stored (it is a skip tensor) AND handed to the second block in registers -- a launch's
+// fixed cost (5-6 us, profiles/r03c_fixed_cost.txt) and one read of that tensor less per step.  Arithmetic as k_res64_lds<false, 0>.
+__global__ __launch_bounds__(512, 2) void k_res64_dual(const BlockArgsH A0, const BlockArgsH A1, const int ngroups) {
+    using L = R64Layout<false, 0>;
+    constexpr int N = 64, NT = 2, NG = 8, KS1 = 4;
+    __shared__ uint4 lds[2 * L::TOTAL_U4];
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr float kL2 = -1.44269504088896341f;
+    const int tid = threadIdx.x;
+    {   // every load of both blocks first, then the LDS writes
+        uint4 r1[2][2], r2[2][2], r3[2][2];
+        float g1[2] = {0.f, 0.f}, b1[2] = {0.f, 0.f}, v6[2][6], tb[2] = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const BlockArgsH& ah = k == 0 ? A0 : A1;
+            const BlockArgs& a = ah.b;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { r1[k][q] = ah.W1h[tid + 512 * q]; r2[k][q] = ah.W2h[tid + 512 * q]; r3[k][q] = ah.W3h[tid + 512 * q]; }
+            if (tid < 16 * KS1) { g1[k] = a.gamma1[tid]; b1[k] = a.beta1[tid]; }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v6[k][q] = 0.f;
+            if (tid < 64) {
+                v6[k][0] = a.gamma2[tid]; v6[k][1] = a.beta2[tid]; v6[k][2] = a.gamma3[tid]; v6[k][3] = a.beta3[tid]; v6[k][4] = a.c2[tid]; v6[k][5] = a.c3[tid];
+                tb[k] = a.tbias[(size_t)(a.step_ptr ? *a.step_ptr : 0) * a.tb_stride + tid];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint4* const lb = lds + k * L::TOTAL_U4;
+            float* const vec = reinterpret_cast<float*>(lb + L::VEC);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { lb[L::W1 + tid + 512 * q] = r1[k][q]; lb[L::W2 + tid + 512 * q] = r2[k][q]; lb[L::W3 + tid + 512 * q] = r3[k][q]; }
+            if (tid < 16 * KS1) { vec[L::G1 + tid] = g1[k] * kL2; vec[L::B1 + tid] = b1[k] * kL2; }
+            if (tid < 64) {
+                vec[L::G2 + tid] = v6[k][0] * kL2; vec[L::B2 + tid] = v6[k][1] * kL2; vec[L::G3 + tid] = v6[k][2] * kL2; vec[L::B3 + tid] = v6[k][3] * kL2;
+                vec[L::C2 + tid] = v6[k][4]; vec[L::C3 + tid] = v6[k][5];
+                vec[L::TB + tid] = tb[k];
+            }
+        }
+    }
+    __syncthreads();
+    const BlockArgs& a0 = A0.b;
+    auto x0_of = [&](int g) -> const float* {
+        const int traw = g * kR64Waves + wave;
+        const int tile = traw < a0.ntiles ? traw : a0.ntiles - 1;
+        return a0.in0.data + (size_t)seg_tile(a0.in0, tile) * 8 * 256 + lane * 4;
+    };
+    auto st0_of = [&](int g) -> const float2* {
+        const int traw = g * kR64Waves + wave;
+        const int tile = traw < a0.ntiles ? traw : a0.ntiles - 1;
+        return reinterpret_cast<const float2*>(a0.in0.stats) + (size_t)seg_tile(a0.in0, tile) * 32 + j;
+    };
+    float4 xc[NG];
+    float2 sc;
+    {
+        const float* xp = x0_of(blockIdx.x < ngroups ? blockIdx.x : 0);
+#pragma unroll
+        for (int G = 0; G < NG; ++G) xc[G] = ld4(xp + (size_t)G * 256);
+        sc = *st0_of(blockIdx.x < ngroups ? blockIdx.x : 0);
+    }
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        asm volatile("" ::: "memory");                   // as k_res64_lds: keeps the plane reads inside the loop
+        const int tile_raw = g * kR64Waves + wave;
+        const bool live = tile_raw < a0.ntiles;
+        const int tile = live ? tile_raw : a0.ntiles - 1;
+        const int ptile = tile >= a0.tiles_per_pass ? tile - a0.tiles_per_pass : tile;
+        const bool cond = tile >= a0.uncond_tiles;
+        const int gn = g + gridDim.x < ngroups ? g + gridDim.x : g;
+        float4 xn[NG];
+        float2 sn = sc;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const BlockArgsH& ah = k == 0 ? A0 : A1;
+            const BlockArgs& a = ah.b;
+            lds_cu4* const w1 = (lds_cu4*)(lds + k * L::TOTAL_U4 + L::W1) + lane;
+            lds_cu4* const w2 = (lds_cu4*)(lds + k * L::TOTAL_U4 + L::W2) + lane;
+            lds_cu4* const w3 = (lds_cu4*)(lds + k * L::TOTAL_U4 + L::W3) + lane;
+            const float* const vec = reinterpret_cast<const float*>(lds + k * L::TOTAL_U4 + L::VEC);
+            const float inv1 = ah.kc[0], inv2 = ah.kc[1], inv3 = ah.kc[2];
+            float4 cpv[NG];
+            if (cond) {
+                const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
+#pragma unroll
+                for (int G = 0; G < NG; ++G) cpv[G] = ld4(cp + (size_t)G * 256);
+            }
+            const float rstd1 = rsqrtf(sc.y * a.inv_nin + kLnEps), mean1 = sc.x;
+            f32x16 acc1[NT];
+            r64_stage<true, true, KS1>(acc1, w1, KS1 * 128, vec + L::G1, vec + L::B1, rstd1, -mean1 * rstd1, h,
+                                       [&](int S, float (&x)[8]) {
+                                           x[0] = xc[2 * S].x; x[1] = xc[2 * S].y; x[2] = xc[2 * S].z; x[3] = xc[2 * S].w;
+                                           x[4] = xc[2 * S + 1].x; x[5] = xc[2 * S + 1].y; x[6] = xc[2 * S + 1].z; x[7] = xc[2 * S + 1].w;
+                                       }, [](int) {});
+            r64_unscale_add<8>(acc1, inv1, vec + L::TB, h);
+            f32x16 acc2[NT];
+            {
+                float mean, m2;
+                acc_stats<N, NT>(acc1, h, mean, m2);
+                const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+                r64_stage<true, true, 4>(acc2, w2, 4 * 128, vec + L::G2, vec + L::B2, rstd, -mean * rstd, h,
+                                         [&](int S, float (&x)[8]) {
+                                             const int t = S >> 1, r0 = 8 * (S & 1);
+#pragma unroll
+                                             for (int q = 0; q < 8; ++q) x[q] = acc1[t][r0 + q];
+                                         }, [](int) {});
+                r64_unscale_add<8>(acc2, inv2, vec + L::C2, h);
+            }
+            if (cond) {
+#pragma unroll
+                for (int G = 0; G < NG; ++G) {
+                    acc2[G >> 2][4 * (G & 3) + 0] += cpv[G].x; acc2[G >> 2][4 * (G & 3) + 1] += cpv[G].y;
+                    acc2[G >> 2][4 * (G & 3) + 2] += cpv[G].z; acc2[G >> 2][4 * (G & 3) + 3] += cpv[G].w;
+                }
+            }
+            f32x16 (&acc3)[NT] = acc1;
+            {
+                float mean, m2;
+                acc_stats<N, NT>(acc2, h, mean, m2);
+                const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps);
+                r64_stage<true, true, 4>(acc3, w3, 4 * 128, vec + L::G3, vec + L::B3, rstd, -mean * rstd, h,
+                                         [&](int S, float (&x)[8]) {
+                                             const int t = S >> 1, r0 = 8 * (S & 1);
+#pragma unroll
+                                             for (int q = 0; q < 8; ++q) x[q] = acc2[t][r0 + q];
+                                         }, [](int) {});
+            }
+            r64_unscale_add<8>(acc3, inv3, vec + L::C3, h);
+            if (k == 1) {                              // the next tile's input of the FIRST block, behind the residual add
+                const float* xp = x0_of(gn);
+#pragma unroll
+                for (int G = 0; G < NG; ++G) xn[G] = ld4(xp + (size_t)G * 256);
+                sn = *st0_of(gn);
+            }
+#pragma unroll
+            for (int G = 0; G < NG; ++G) {
+                acc3[G >> 2][4 * (G & 3) + 0] += xc[G].x; acc3[G >> 2][4 * (G & 3) + 1] += xc[G].y;
+                acc3[G >> 2][4 * (G & 3) + 2] += xc[G].z; acc3[G >> 2][4 * (G & 3) + 3] += xc[G].w;
+            }
+            float xmean, xm2;
+            acc_stats<N, NT>(acc3, h, xmean, xm2);
+            if (live) {
+                if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
+#pragma unroll
+                for (int G = 0; G < NG; ++G)
+                    st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                        make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2], acc3[G >> 2][4 * (G & 3) + 3]));
+            }
+            if (k == 0) {                              // the second block's input: this block's output, in registers
+#pragma unroll
+                for (int G = 0; G < NG; ++G) xc[G] = make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2], acc3[G >> 2][4 * (G & 3) + 3]);
+                sc = make_float2(xmean, xm2);
+            }
+        }
+#pragma unroll
+        for (int G = 0; G < NG; ++G) xc[G] = xn[G];
+        sc = sn;
+    }
+}
+
+
 }  // namespace dsg
