@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
 
     // ---- the block's planes and vectors -> LDS, once per launch.  EVERY load is issued before the first LDS write: written as
     // `for (i...) lds[i] = src[i]` hipcc emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration, 13 dependent L2 round trips (1 us of
-    // the 5-6 us every launch costs before its first tile: profiles/r03c_fixed_cost.txt)
+    // the 5-6 us every launch costs before its first tile: profiles/r03d_fixed_cost.txt)
     {
         constexpr int N1 = 2 * KS1 * 128 / 512, N2 = 2 * 4 * 128 / 512, NL = (NTO * 4 * 128 + 511) / 512;
         uint4 r1[N1], r2[N2], r3[N2], rs[SCLIN ? N1 : 1], rl[NTO > 0 ? NL : 1];
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
 
 // ---- two consecutive down-64 blocks (no Linear shortcut, no consuming Linear) in ONE launch: both blocks' planes are resident
 // (2 x 48 KiB), the first block's output is stored (it is a skip tensor) AND handed to the second block in registers -- a launch's
-// fixed cost (5-6 us, profiles/r03c_fixed_cost.txt) and one read of that tensor less per step.  Arithmetic as k_res64_lds<false, 0>.
+// fixed cost (5-6 us, profiles/r03d_fixed_cost.txt) and one read of that tensor less per step.  Arithmetic as k_res64_lds<false, 0>.
 __global__ __launch_bounds__(512, 2) void k_res64_dual(const BlockArgsH A0, const BlockArgsH A1, const int ngroups) {
     using L = R64Layout<false, 0>;
     constexpr int N = 64, NT = 2, NG = 8, KS1 = 4;

@@ -10,7 +10,7 @@ cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_bench_s
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktt -o kt -- python3 tools/train_prof.py 10 32768 > $OUT/ktt.log 2>&1
 cp $(find $OUT/ktt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_train_32768.csv
 bash tools/pmc_bench.sh $OUT/pmc
-for k in "k_panel128_h<true, 0, 1>" "k_panel128_h<false, 0, 1>" "k_panel128_h<false, 1, 2>" "k_panel128_h<true, 2, 3>" "k_res64_lds<true, 0>" "k_res64_lds<false, 0>" "k_res64_lds<true, 4>" "k_fused_narrow_lds"; do
+for k in "k_panel128_h<true, 0, 1>" "k_panel128_h<false, 0, 1>" "k_panel128_h<false, 1, 2>" "k_panel128_h<true, 2, 3>" "k_res64_lds<true, 0>" "k_res64_lds<false, 0>" "k_res64_lds<true, 4>" "k_res64_dual" "k_fused_narrow_lds"; do
   echo "== $k"; python3 tools/pmc_summary.py $OUT/pmc "$k"
 done > $OUT/pmc_summary.txt
 python3 tools/make_traffic.py $OUT/pmc_summary.txt "k_panel128_h<true, 0, 1>" $OUT/traffic.json "profiles/${ROUND_TAG:-r03}_pmc_summary.txt" > /dev/null
