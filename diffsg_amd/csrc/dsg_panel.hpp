@@ -149,18 +149,6 @@ __device__ __forceinline__ void panel_wfrag(HFrag<NT>& w, const uint4* panel /* 
 }
 
 
-// Operand preparation WITHOUT packed-f32 instructions (same bits: v_pk_fma_f32 rounds each element like v_fma_f32).  Beside a
-// partner wave's MFMA stream the packed forms are an anti-lever (the guide's filler table; cycle stamps of this kernel).
-__device__ __forceinline__ float silu_scaled_l2s(float up) {
-    constexpr float k = -1.44269504088896341f / kActScale;
-    return up * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(up), k, k));
-}
-#ifndef DSG_PANEL_VERTICAL
-#define DSG_PANEL_VERTICAL 1
-#endif
-#ifndef DSG_PANEL_VDBG
-#define DSG_PANEL_VDBG 0      // measurement only: 1 = operands are the raw bits of x (no VALU), 2 = no split, 4 = no transcendentals
-#endif
 // LayerNorm vectors of a step from LDS: `gl` / `bl` are this lane's address-space-3 pointers (vector + 4 h); with a compile-time S
 // the offset folds into the ds_read instruction (through generic pointers hipcc kept four address registers per step alive
 // across the whole tile loop and spilled them)
@@ -185,13 +173,6 @@ __device__ __forceinline__ float sub_half_hi(float v, unsigned hi) {
 template <bool LNACT, bool ASM_SPLIT = false>
 __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamma, const float* beta, int S, float c, float d, int h) {
     float v[8];
-    if (DSG_PANEL_VDBG & 1) {
-        BOp o;
-        const uint4 ua = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
-        const uint4 ub = {__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
-        o.hi = __builtin_bit_cast(h8, ua); o.lo = __builtin_bit_cast(h8, ub);
-        return o;
-    }
     if (LNACT) {
         lds_cf4* const gl = (lds_cf4*)(gamma + 4 * h);
         lds_cf4* const bl = (lds_cf4*)(beta + 4 * h);
@@ -203,16 +184,16 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
         float u[8], p[8], r[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) u[q] = fmaf(fmaf(x[q], c, d), g[q], b[q]);
-        if (DSG_PANEL_VERTICAL) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) p[q] = (DSG_PANEL_VDBG & 4) ? u[q] : __builtin_amdgcn_exp2f(u[q]);
-        if (DSG_PANEL_VERTICAL) __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < 8; ++q) p[q] = __builtin_amdgcn_exp2f(u[q]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) r[q] = fmaf(p[q], kk, kk);
-        if (DSG_PANEL_VERTICAL) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = (DSG_PANEL_VDBG & 4) ? r[q] : __builtin_amdgcn_rcpf(r[q]);
-        if (DSG_PANEL_VERTICAL) __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < 8; ++q) r[q] = __builtin_amdgcn_rcpf(r[q]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = u[q] * r[q];
     } else {
@@ -220,12 +201,6 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
         for (int q = 0; q < 8; ++q) v[q] = x[q] * kRawScale;
     }
     BOp o;
-    if (DSG_PANEL_VDBG & 2) {
-        const uint4 ua = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-        const uint4 ub = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
-        o.hi = __builtin_bit_cast(h8, ua); o.lo = __builtin_bit_cast(h8, ub);
-        return o;
-    }
     if (ASM_SPLIT) {
         unsigned hh[4], ll[4];
 #pragma unroll
@@ -257,7 +232,6 @@ struct BOp4 { h8 hi[4], lo[4]; };
 // MFMA stream that consumes it (cycle stamps: the "M phase" of both SIMD partners then contained the V phase's arithmetic)
 // ... and the second half of a register-fed stage's input is "redefined" behind the first panel's MFMA stream, so that its
 // preparation cannot be hoisted above that stream (32 more live registers exactly where the plane registers are needed)
-__device__ __forceinline__ void v_phase_fence(f32x16& x0, f32x16& x1) { asm volatile("" : "+v"(x0), "+v"(x1)); }
 __device__ __forceinline__ void v_phase_done(BOp4& b) {
     asm volatile("" : "+v"(b.hi[0]), "+v"(b.hi[1]), "+v"(b.hi[2]), "+v"(b.hi[3]), "+v"(b.lo[0]), "+v"(b.lo[1]), "+v"(b.lo[2]), "+v"(b.lo[3]));
 }
@@ -302,39 +276,14 @@ __device__ __forceinline__ void m_phase(f32x16 (&acc)[4], unsigned panel_addr /*
                      : "memory");
 }
 
-// ---- The same MFMA stream written slot by slot: every MFMA is its own `asm volatile` (volatile statements keep their order),
-// the plane reads are ordinary LDS loads placed BETWEEN the statements (a load cannot cross a volatile statement, so it stays in
-// the slot it was written in; hipcc counts its lgkmcnt waits itself and no value is ever copied before it has landed), and
-// ordinary VALU code can be pinned between two MFMAs by passing its inputs / results through the neighbouring statements as
-// "+v" operands (panel_pipe below).
-__device__ __forceinline__ void mfma_slot(f32x16& c, const uint4 a, const h8 b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(__builtin_bit_cast(h8, a)), "v"(b));
-}
-__device__ __forceinline__ void mfma_slot0(f32x16& c, const uint4 a, const h8 b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(__builtin_bit_cast(h8, a)), "v"(b));
-}
+// ---- One MFMA per `asm volatile` slot (panel_pipe below): volatile statements keep their order, the plane reads are ordinary LDS
+// loads placed BETWEEN the statements (a load cannot cross a volatile statement, so it stays in the slot it was written in; hipcc counts
+// its lgkmcnt waits itself), and ordinary VALU code is pinned between two MFMAs by passing its inputs / results through the
+// neighbouring statements as "+v" operands.
 constexpr int kPlaneAhead = 8;     // MFMA slots between a plane's read and its use
 
 // slot k of a panel: term t = (k / 4) % 3 (hi*bhi, hi*blo, lo*bhi), out tile nt = k % 4, step s = k / 12
 __device__ __forceinline__ constexpr int slot_plane(int k) { return (((k % 4) * 4 + k / 12) * 2 + ((k / 4) % 3 == 2 ? 1 : 0)) * 64; }   // uint4 offset in the panel
-
-template <bool FIRST>
-__device__ __forceinline__ void m_phase_slots(f32x16 (&acc)[4], const uint4* pn /* + lane */, const BOp4& b) {
-    // plane of slot k, for k in the order of first use: per step hi[0..3] (slots 0-3, reused by 4-7), lo[0..3] (slots 8-11)
-    uint4 pl[48];                                   // only ~kPlaneAhead + 4 of them are live at a time
-#pragma unroll
-    for (int k = 0; k < kPlaneAhead && k < 48; ++k)
-        if ((k / 4) % 3 != 1) pl[k] = pn[slot_plane(k)];
-#pragma unroll
-    for (int k = 0; k < 48; ++k) {
-        const int s = k / 12, t = (k / 4) % 3, nt = k % 4;
-        const int kp = t == 1 ? k - 4 : k;          // the hi*blo term reuses the plane of the hi*bhi slot
-        const h8 bb = t == 1 ? b.lo[s] : b.hi[s];
-        if (FIRST && k < 4) mfma_slot0(acc[nt], pl[kp], bb); else mfma_slot(acc[nt], pl[kp], bb);
-        const int kn = k + kPlaneAhead;
-        if (kn < 48 && (kn / 4) % 3 != 1) pl[kn] = pn[slot_plane(kn)];
-    }
-}
 
 // EPI: 0 = block only, 1 = + raw Linear (Down/Upsample), 2 = + final (LayerNorm + SiLU + Linear, row-major out)
 // ---- panel_pipe: the MFMA stream of one panel WITH the operand preparation of the next panel between the MFMAs.
@@ -342,8 +291,6 @@ __device__ __forceinline__ void m_phase_slots(f32x16 (&acc)[4], const uint4* pn 
 // and 3m + 2 (hi/lo split), six / six / four VALU instructions, i.e. the five-or-so instructions a wave can issue under one
 // MFMA (MI355X guide, "instructions hidden per MFMA gap").  The pieces are ordinary C++; what keeps each of them between its two
 // MFMAs is that its inputs and its results pass through the neighbouring `asm volatile` statements as "+v" operands.
-typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
-struct PipePins { float a0, a1, a2, a3; };     // values in flight between two pieces of the chain
 
 __device__ __forceinline__ void mfma_pin(f32x16& c, const uint4 a, const h8 b, float& p0, float& p1, float& p2, float& p3) {
     asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[a], %[b], %[c]" : [c] "+v"(c), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : [a] "v"(__builtin_bit_cast(h8, a)), [b] "v"(b));
@@ -359,7 +306,6 @@ __device__ __forceinline__ void mfma_pin0(f32x16& c, const uint4 a, const h8 b, 
 // For the two private-slot kinds `consume(j)` is called once per step, six MFMA slots before the step's first piece: it waits
 // for the item, requests the one kPrivDist places ahead and returns the slot.
 enum { PIPE_REG = 1, PIPE_LN = 2, PIPE_RAW = 3 };
-typedef __attribute__((address_space(3))) const f32x2 lds_cf2g;
 
 template <bool FIRST, int PREP, typename Consume>
 __device__ __forceinline__ void panel_pipe(f32x16 (&acc)[4], const uint4* pn /* + lane */, const BOp4& b, BOp4& bn, const f32x16 (&in)[4], int S0,
@@ -437,16 +383,9 @@ __device__ __forceinline__ void panel_pipe(f32x16 (&acc)[4], const uint4* pn /* 
 #ifndef DSG_PANEL_TRAIL_PRIO
 #define DSG_PANEL_TRAIL_PRIO 1
 #endif
-#ifndef DSG_PANEL_PIPE
-#define DSG_PANEL_PIPE 1
-#endif
-#ifndef DSG_PANEL_MSLOTS
-#define DSG_PANEL_MSLOTS 0
-#endif
 template <bool FIRST>
 __device__ __forceinline__ void M_PHASE(f32x16 (&acc)[4], unsigned pa, const BOp4& b, const uint4* lds_lane) {
-    if (DSG_PANEL_MSLOTS) m_phase_slots<FIRST>(acc, lds_lane + (pa - (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds_lane) / 16u, b);
-    else m_phase<FIRST>(acc, pa, b);
+    m_phase<FIRST>(acc, pa, b);
 }
 template <bool SCLIN, int EPI, int NTO>
 __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, const int ngroups) {

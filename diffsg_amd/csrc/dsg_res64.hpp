@@ -30,24 +30,6 @@ template <bool SCLIN, int NTO = 0> struct R64Layout {
     static constexpr int TOTAL_U4 = VEC + (NV + 3) / 4;
 };
 
-// 6 MFMAs of one k16-step, two out tiles, planes from the LDS image (term-major as mfma_step_h)
-template <bool FIRST>
-__device__ __forceinline__ void r64_mma(f32x16 (&acc)[2], lds_cu4* w /* step's planes of tile 0, + lane */, int tile_stride, const h8 bhi, const h8 blo) {
-    const u32x4 h0 = w[0], l0 = w[64], h1 = w[tile_stride], l1 = w[tile_stride + 64];
-    if (FIRST) {
-        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, h0), bhi, z, 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, h1), bhi, z, 0, 0, 0);
-    } else {
-        DSG_MFMA_H(acc[0], __builtin_bit_cast(h8, h0), bhi);
-        DSG_MFMA_H(acc[1], __builtin_bit_cast(h8, h1), bhi);
-    }
-    DSG_MFMA_H(acc[0], __builtin_bit_cast(h8, h0), blo);
-    DSG_MFMA_H(acc[1], __builtin_bit_cast(h8, h1), blo);
-    DSG_MFMA_H(acc[0], __builtin_bit_cast(h8, l0), bhi);
-    DSG_MFMA_H(acc[1], __builtin_bit_cast(h8, l1), bhi);
-}
-
 // B operand of a step from eight values: LayerNorm (vectors from LDS, already times -log2 e) + SiLU + split, or the raw split
 template <bool LNACT>
 __device__ __forceinline__ void r64_prep(const float (&x)[8], const float* gv, const float* bv, int S, float c, float d, int h, h8& hi, h8& lo) {
