@@ -210,7 +210,9 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
     return {"roofline": roof, "samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": B, "global_batch": world * B,
             "steps": steps, "T": 20, "final_loss": float(loss.detach()), "achieved_tflops": sps / world * f_train / 1e12,
             "frac_f32_mfma": sps / world * f_train / 1e12 / PEAK_F32_TFLOPS, "grad_bucket_bytes": int(ddpm.grad_bucket.numel()) * 4,
-            "collective": "one all_reduce(AVG) per step over the flat bucket (RCCL)" if world > 1 else "none (1 GPU)",
+            "collective": ("none (1 GPU)" if world == 1 else
+                           "one all_reduce(AVG) per step over the flat bucket (RCCL)" if dist.get_backend() == "nccl" else
+                           f"one all_reduce(SUM) + divide per step over the flat bucket ({dist.get_backend()}: one-GPU plumbing test)"),
             "ranks_seen": ev["ranks_seen"], "per_rank_samples_per_s": [B * r for r in ev["per_rank_steps_per_s"]],
             "bucket_checksum_equal": bool(eq), "bucket_checksum": csum}
 
