@@ -79,6 +79,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             tmp = LIB_PATH + f".{os.getpid()}.tmp"
             extra = os.environ.get("DSG_EXTRA_CXXFLAGS", "")
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-fno-slp-vectorize",
+                   # the panel kernel's 48-slot MFMA loops must unroll completely (the slots index register arrays): the default
+                   # limit on `#pragma unroll` (16 K) is below the largest variant, whose arrays then land in scratch memory
+                   "-mllvm", "-pragma-unroll-threshold=200000",
                    f'-DDSG_BUILD_ID_STR="{source_id(extra)}"', "-o", tmp] + extra.split() + SOURCES
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)

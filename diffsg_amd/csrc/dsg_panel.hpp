@@ -12,8 +12,10 @@
 //     LDS slots (5 x 2 KiB, four items ahead) and need no barrier at all: only the issuing wave reads them;
 //   * the request targets are static per call site, so the waits on the vector-memory counter are compile-time constants
 //     (private items: vmcnt(6); a panel: the 8 / 2 / 0 ladder of panel_begin) -- no drain to zero inside the loop;
-//   * the operand preparation (LayerNorm, SiLU, hi/lo split) of panel p + 1 sits BETWEEN the MFMAs of panel p (panel_pipe):
-//     one MFMA per `asm volatile` slot, the VALU pieces pinned between the slots through "+v" operands.
+//   * the operand preparation (LayerNorm, SiLU, hi/lo split) of k16-step s + 1 sits BETWEEN the MFMAs of step s (panel_pipe_s):
+//     one MFMA per `asm volatile` slot, the VALU pieces pinned between the slots through "+v" operands; only step 0 of a stage
+//     (it needs the stage's row statistics) is prepared outside the MFMA stream, and in the up block without an epilogue not even
+//     that of stage 1: the next tile's first operand is prepared under the last step of the current tile's shortcut.
 // Arithmetic per element, packed planes, scales and accumulation order are those of k_wide128_h / resblock_body_h.
 #pragma once
 #include "dsg_wide.hpp"
@@ -219,63 +221,6 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
     return o;
 }
 
-// ---- V phase / M phase.  A panel's worth of work (4 k16-steps) is split into
-//   V: the four B operands are prepared (LayerNorm, SiLU, hi/lo split: pure VALU + the LayerNorm vectors from LDS), and
-//   M: 48 MFMAs over the panel with nothing but the panel's plane reads between them (the planes of step s+1 are requested
-//      under the MFMAs of step s).
-// Why: with the operand preparation of a step sitting between its LDS reads and its MFMAs, every step was a chain of exposed
-// latencies (LDS round trip -> dependent VALU chain -> 12 MFMAs each waiting for its just-requested plane): the first
-// panel kernel's PMC passes: 36 % of wave cycles in s_waitcnt and 30 % in issue stalls.  The M phase has no dependence on anything but LDS reads issued
-// a step ahead; the V phase no MFMA to wait for.  The operands of four steps are 32 registers.
-struct BOp4 { h8 hi[4], lo[4]; };
-// The operands are COMPLETE here: without this the compiler sinks the whole preparation behind the panel's barrier, next to the
-// MFMA stream that consumes it (cycle stamps: the "M phase" of both SIMD partners then contained the V phase's arithmetic)
-// ... and the second half of a register-fed stage's input is "redefined" behind the first panel's MFMA stream, so that its
-// preparation cannot be hoisted above that stream (32 more live registers exactly where the plane registers are needed)
-__device__ __forceinline__ void v_phase_done(BOp4& b) {
-    asm volatile("" : "+v"(b.hi[0]), "+v"(b.hi[1]), "+v"(b.hi[2]), "+v"(b.hi[3]), "+v"(b.lo[0]), "+v"(b.lo[1]), "+v"(b.lo[2]), "+v"(b.lo[3]));
-}
-
-// B operands of steps S0..S0+3 of a register-fed stage from the accumulators of the previous one
-__device__ __forceinline__ void v_phase_reg(BOp4& b, const f32x16 (&in)[4], int S0, const float* gamma, const float* beta, float cc, float dd, int h) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int S = S0 + s, t = S >> 1, r0 = 8 * (S & 1);
-        const float x[8] = {in[t][r0], in[t][r0 + 1], in[t][r0 + 2], in[t][r0 + 3], in[t][r0 + 4], in[t][r0 + 5], in[t][r0 + 6], in[t][r0 + 7]};
-        const BOp o = panel_prep<true>(x, gamma, beta, S, cc, dd, h);
-        b.hi[s] = o.hi; b.lo[s] = o.lo;
-    }
-}
-
-// 48 MFMAs: acc (+)= W[panel] * b, as ONE hand-ordered instruction stream (dsg_panel_mphase.inc, tools/gen/gen_mphase.py): two
-// plane register sets alternate by step, the eight plane reads of step s+1 go out one behind each of the first eight MFMAs of
-// step s, every MFMA waits (counted lgkmcnt: LDS returns in order) only for the plane it needs.  hipcc, given the same program
-// as C++ with sched_group_barrier requests, re-ordered the MFMAs and kept every plane read right in front of its use
-// (read -> wait -> MFMA, five exposed LDS round trips per step).
-#include "dsg_panel_mphase.inc"
-template <bool FIRST>
-__device__ __forceinline__ void m_phase(f32x16 (&acc)[4], unsigned panel_addr /* LDS byte address of the panel + lane * 16 */, const BOp4& b) {
-    uint4 pl[16];
-    if (FIRST)
-        asm volatile(DSG_MPHASE_ASM_FIRST
-                     : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3]),
-                       [pl0] "=&v"(pl[0]), [pl1] "=&v"(pl[1]), [pl2] "=&v"(pl[2]), [pl3] "=&v"(pl[3]), [pl4] "=&v"(pl[4]), [pl5] "=&v"(pl[5]),
-                       [pl6] "=&v"(pl[6]), [pl7] "=&v"(pl[7]), [pl8] "=&v"(pl[8]), [pl9] "=&v"(pl[9]), [pl10] "=&v"(pl[10]), [pl11] "=&v"(pl[11]),
-                       [pl12] "=&v"(pl[12]), [pl13] "=&v"(pl[13]), [pl14] "=&v"(pl[14]), [pl15] "=&v"(pl[15])
-                     : [ad] "v"(panel_addr), [bh0] "v"(b.hi[0]), [bh1] "v"(b.hi[1]), [bh2] "v"(b.hi[2]), [bh3] "v"(b.hi[3]),
-                       [bl0] "v"(b.lo[0]), [bl1] "v"(b.lo[1]), [bl2] "v"(b.lo[2]), [bl3] "v"(b.lo[3])
-                     : "memory");
-    else
-        asm volatile(DSG_MPHASE_ASM
-                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]),
-                       [pl0] "=&v"(pl[0]), [pl1] "=&v"(pl[1]), [pl2] "=&v"(pl[2]), [pl3] "=&v"(pl[3]), [pl4] "=&v"(pl[4]), [pl5] "=&v"(pl[5]),
-                       [pl6] "=&v"(pl[6]), [pl7] "=&v"(pl[7]), [pl8] "=&v"(pl[8]), [pl9] "=&v"(pl[9]), [pl10] "=&v"(pl[10]), [pl11] "=&v"(pl[11]),
-                       [pl12] "=&v"(pl[12]), [pl13] "=&v"(pl[13]), [pl14] "=&v"(pl[14]), [pl15] "=&v"(pl[15])
-                     : [ad] "v"(panel_addr), [bh0] "v"(b.hi[0]), [bh1] "v"(b.hi[1]), [bh2] "v"(b.hi[2]), [bh3] "v"(b.hi[3]),
-                       [bl0] "v"(b.lo[0]), [bl1] "v"(b.lo[1]), [bl2] "v"(b.lo[2]), [bl3] "v"(b.lo[3])
-                     : "memory");
-}
-
 // ---- One MFMA per `asm volatile` slot (panel_pipe below): volatile statements keep their order, the plane reads are ordinary LDS
 // loads placed BETWEEN the statements (a load cannot cross a volatile statement, so it stays in the slot it was written in; hipcc counts
 // its lgkmcnt waits itself), and ordinary VALU code is pinned between two MFMAs by passing its inputs / results through the
@@ -286,79 +231,121 @@ constexpr int kPlaneAhead = 8;     // MFMA slots between a plane's read and its 
 __device__ __forceinline__ constexpr int slot_plane(int k) { return (((k % 4) * 4 + k / 12) * 2 + ((k / 4) % 3 == 2 ? 1 : 0)) * 64; }   // uint4 offset in the panel
 
 // EPI: 0 = block only, 1 = + raw Linear (Down/Upsample), 2 = + final (LayerNorm + SiLU + Linear, row-major out)
-// ---- panel_pipe: the MFMA stream of one panel WITH the operand preparation of the next panel between the MFMAs.
-// 48 MFMA slots, 16 operand pairs (4 steps x 4 pairs of values): pair m takes slots 3m (LayerNorm + exp2), 3m + 1 (rcp, product)
-// and 3m + 2 (hi/lo split), six / six / four VALU instructions, i.e. the five-or-so instructions a wave can issue under one
-// MFMA (MI355X guide, "instructions hidden per MFMA gap").  The pieces are ordinary C++; what keeps each of them between its two
-// MFMAs is that its inputs and its results pass through the neighbouring `asm volatile` statements as "+v" operands.
-
+// ---- The MFMA stream of a panel WITH operand preparation between the MFMAs.  48 MFMA slots, 16 operand pairs (4 steps x 4 pairs
+// of values): pair m takes slots 3m (LayerNorm + exp2), 3m + 1 (rcp, product) and 3m + 2 (hi/lo split), six / six / four VALU
+// instructions, i.e. the five-or-so instructions a wave can issue under one MFMA (MI355X guide, "instructions hidden per MFMA gap").
+// The pieces are ordinary C++; what keeps each of them between its two MFMAs is that its inputs and its results pass through the
+// neighbouring `asm volatile` statements as "+v" operands.
+//   PIPE_REG   source: the accumulators of the previous stage (LayerNorm + SiLU + split)
+//   PIPE_LN    source: the wave's private slots (stage 1): LayerNorm + SiLU + split
+//   PIPE_RAW   the same source, split only (Linear shortcut)
+// For the two private-slot kinds a consume functor is called once per prepared step, six MFMA slots before the step's first piece:
+// it waits for the item, requests the one kPrivDist places ahead and returns the slot.
 __device__ __forceinline__ void mfma_pin(f32x16& c, const uint4 a, const h8 b, float& p0, float& p1, float& p2, float& p3) {
     asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[a], %[b], %[c]" : [c] "+v"(c), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : [a] "v"(__builtin_bit_cast(h8, a)), [b] "v"(b));
 }
 __device__ __forceinline__ void mfma_pin0(f32x16& c, const uint4 a, const h8 b, float& p0, float& p1, float& p2, float& p3) {
     asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[a], %[b], 0" : [c] "=&v"(c), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : [a] "v"(__builtin_bit_cast(h8, a)), [b] "v"(b));
 }
-
-// PREP: what is prepared under this panel's MFMAs --
-//   PIPE_REG   the next four steps (S0 .. S0 + 3) of a register-fed stage, from the accumulators `in` (LayerNorm + SiLU + split)
-//   PIPE_LN    four steps whose input arrives through the wave's private slots (stage 1): LayerNorm + SiLU + split
-//   PIPE_RAW   the same source, split only (Linear shortcut)
-// For the two private-slot kinds `consume(j)` is called once per step, six MFMA slots before the step's first piece: it waits
-// for the item, requests the one kPrivDist places ahead and returns the slot.
 enum { PIPE_REG = 1, PIPE_LN = 2, PIPE_RAW = 3 };
 
-template <bool FIRST, int PREP, typename Consume>
-__device__ __forceinline__ void panel_pipe(f32x16 (&acc)[4], const uint4* pn /* + lane */, const BOp4& b, BOp4& bn, const f32x16 (&in)[4], int S0,
-                                           const float* gamma, const float* beta, float cc, float dd, int h, Consume&& consume) {
+// ---- panel_pipe_s: the same slot structure with the operands prepared ONE STEP ahead instead of one panel ahead.
+// The MFMAs of step s (slots 12 s .. 12 s + 11) use operand s; under them the operand of the NEXT step is prepared: steps 1..3 of
+// this panel under steps 0..2 (mode PREP, source step S0 + 1 + j), and under step 3 the first step of whatever follows (mode PREPN:
+// the next panel of the stage, the first shortcut step behind stage 3, the next tile's first step behind the last shortcut panel,
+// or nothing).  Only step 0 of a STAGE is prepared on its own (it needs the stage's row statistics): a quarter of what the
+// panel-ahead form prepared outside the MFMA stream, and a wave carries one operand (8 registers) across a barrier instead of four.
+struct NextPrep {            // the operand prepared under step 3
+    const f32x16 (*in)[4];   // PIPE_REG: accumulators of the previous stage
+    int S;                   // its step index in ITS stage (LayerNorm vector index, register index)
+    const float *gamma, *beta;
+    float cc, dd;
+    const float *pcc, *pdd;  // non-null: the constants are produced by consume_n() (next tile's row statistics), read them after it
+};
+enum { PIPE_NONE = 0 };
+template <bool FIRST, int PREP, int PREPN, typename Consume, typename ConsumeN>
+__device__ __forceinline__ void panel_pipe_s(f32x16 (&acc)[4], const uint4* pn /* + lane */, const BOp& b0, BOp& bcarry, const f32x16 (&in)[4], int S0,
+                                             const float* gamma, const float* beta, float cc, float dd, int h, Consume&& consume, const NextPrep nx,
+                                             ConsumeN&& consume_n) {
     constexpr float kk = -1.44269504088896341f / kActScale;
-    constexpr bool LN = PREP != PIPE_RAW, MEM = PREP != PIPE_REG;
+    constexpr bool LN_I = PREP != PIPE_RAW, MEM_I = PREP != PIPE_REG;
+    constexpr bool HASN = PREPN != PIPE_NONE, LN_N = PREPN == PIPE_REG || PREPN == PIPE_LN, MEM_N = PREPN == PIPE_LN || PREPN == PIPE_RAW;
     lds_cf4* const gl = (lds_cf4*)(gamma + 4 * h);
     lds_cf4* const bl = (lds_cf4*)(beta + 4 * h);
+    lds_cf4* const gln = (lds_cf4*)(nx.gamma + 4 * h);
+    lds_cf4* const bln = (lds_cf4*)(nx.beta + 4 * h);
     uint4 pl[48];
-    float cpin = cc, u0 = 0.f, u1 = 0.f, p0 = 0.f, p1 = 0.f, v0 = 0.f, v1 = 0.f;
-    f32x4 gq[8], bq[8], xq[8];                       // per HALF step (two pairs): LayerNorm vectors, input values
+    float cpin = cc, cpinn = nx.cc, ddn = nx.dd, u0 = 0.f, u1 = 0.f, p0 = 0.f, p1 = 0.f, v0 = 0.f, v1 = 0.f;
+    f32x4 gq[8], bq[8], xq[8];                       // per HALF step (two pairs) of the PREPARED steps: LayerNorm vectors, input values
     float hq[17], lq[17];                            // results (bit patterns of half pairs); [16] is a dummy pin for the first statement
-    lds_cf4* slot[4];                                // private slot of each of the four steps (+ lane)
+    lds_cf4* slot[4];                                // private slot of each of the four prepared steps (+ lane)
     hq[16] = 0.f; lq[16] = 0.f;
-    auto load_vec = [&](int hs) {                    // half step hs = 2 * step + (0: values 0-3, 1: values 4-7)
-        const int S = S0 + (hs >> 1);
-        gq[hs] = gl[4 * S + 2 * (hs & 1)]; bq[hs] = bl[4 * S + 2 * (hs & 1)];
+    // prepared step j (0..2: this panel's step j + 1; 3: the carry)
+    auto has = [&](int j) { return j < 3 || HASN; };
+    auto is_ln = [&](int j) { return j < 3 ? LN_I : LN_N; };
+    auto is_mem = [&](int j) { return j < 3 ? MEM_I : MEM_N; };
+    auto load_vec = [&](int hs) {                    // half step hs = 2 * j + (0: values 0-3, 1: values 4-7)
+        const int j = hs >> 1;
+        if (j < 3) { const int S = S0 + 1 + j; gq[hs] = gl[4 * S + 2 * (hs & 1)]; bq[hs] = bl[4 * S + 2 * (hs & 1)]; }
+        else { gq[hs] = gln[4 * nx.S + 2 * (hs & 1)]; bq[hs] = bln[4 * nx.S + 2 * (hs & 1)]; }
     };
     auto load_x = [&](int hs) { xq[hs] = slot[hs >> 1][(hs & 1) * 64]; };
 #pragma unroll
     for (int k = 0; k < kPlaneAhead; ++k)
         if ((k / 4) % 3 != 1) pl[k] = pn[slot_plane(k)];
-    if (MEM) { slot[0] = (lds_cf4*)consume(0); load_x(0); }
-    if (LN) load_vec(0);
+    if (MEM_I) { slot[0] = (lds_cf4*)consume(0); load_x(0); }
+    if (LN_I) load_vec(0);
 #pragma unroll
     for (int k = 0; k < 48; ++k) {
         const int s = k / 12, t = (k / 4) % 3, nt = k % 4;
         const int kp = t == 1 ? k - 4 : k;
-        const h8 bb = t == 1 ? b.lo[s] : b.hi[s];
-        const int m = k / 3, ph = k % 3, mp = m == 0 ? 16 : m - 1;
-        // private item of the NEXT step: six slots before its first piece
-        if (MEM && k % 12 == 6 && k / 12 < 3) slot[k / 12 + 1] = (lds_cf4*)consume(k / 12 + 1);
+        // operand of this step: step 0 arrives, the others were prepared under the step before
+        h8 bh, blo_;
+        if (s == 0) { bh = b0.hi; blo_ = b0.lo; }
+        else {
+            const int m0 = 4 * (s - 1);
+            const f32x4 hv = {hq[m0], hq[m0 + 1], hq[m0 + 2], hq[m0 + 3]}, lv = {lq[m0], lq[m0 + 1], lq[m0 + 2], lq[m0 + 3]};
+            bh = __builtin_bit_cast(h8, hv); blo_ = __builtin_bit_cast(h8, lv);
+        }
+        const h8 bb = t == 1 ? blo_ : bh;
+        const int m = k / 3, ph = k % 3, mp = m == 0 ? 16 : m - 1, j = m >> 2;
+        // private item of the next prepared step: six slots before its first piece
+        if (k % 12 == 6 && k / 12 < 3) {
+            const int jn = k / 12 + 1;
+            if (jn < 3) { if (MEM_I) slot[jn] = (lds_cf4*)consume(jn); }
+            else if (MEM_N) {
+                slot[3] = (lds_cf4*)consume_n();
+                if (nx.pcc) { cpinn = *nx.pcc; ddn = *nx.pdd; }
+            }
+        }
         // the statement: MFMA k; pins = what flows from the piece behind the previous MFMA into the piece behind this one
-        if (ph == 0) { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, cpin, hq[mp], lq[mp], v0); else mfma_pin(acc[nt], pl[kp], bb, cpin, hq[mp], lq[mp], v0); }
+        float& cp = j < 3 ? cpin : cpinn;
+        if (ph == 0) { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, cp, hq[mp], lq[mp], v0); else mfma_pin(acc[nt], pl[kp], bb, cp, hq[mp], lq[mp], v0); }
         else if (ph == 1) { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, u0, u1, p0, p1); else mfma_pin(acc[nt], pl[kp], bb, u0, u1, p0, p1); }
         else { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, v0, v1, u0, u1); else mfma_pin(acc[nt], pl[kp], bb, v0, v1, u0, u1); }
         // loads of later slots: planes kPlaneAhead slots ahead; vectors / values of the next half step at the first pair of this one
         const int kn = k + kPlaneAhead;
         if (kn < 48 && (kn / 4) % 3 != 1) pl[kn] = pn[slot_plane(kn)];
         if (ph == 0 && (m & 1) == 0 && m / 2 + 1 < 8) {
-            if (LN) load_vec(m / 2 + 1);
-            if (MEM) load_x(m / 2 + 1);
+            const int hn = m / 2 + 1, jn = hn >> 1;
+            if (has(jn)) {
+                if (is_ln(jn)) load_vec(hn);
+                if (is_mem(jn)) load_x(hn);
+            }
         }
-        // the piece behind MFMA k
-        const int S = S0 + (m >> 2), q = m & 3, tt = (S >> 1) & 3, r0 = 8 * (S & 1) + 2 * q, hs = m >> 1, e = 2 * (m & 1);
+        // the piece behind MFMA k: pair q of prepared step j
+        if (!has(j)) continue;
+        const bool LN = is_ln(j), MEM = is_mem(j);
+        const int S = j < 3 ? S0 + 1 + j : nx.S, q = m & 3, tt = (S >> 1) & 3, r0 = 8 * (S & 1) + 2 * q, hs = m >> 1, e = 2 * (m & 1);
+        const float dcur = j < 3 ? dd : ddn;
         if (ph == 0) {
-            const float x0 = MEM ? xq[hs][e] : in[tt][r0], x1 = MEM ? xq[hs][e + 1] : in[tt][r0 + 1];
+            const float x0 = MEM ? xq[hs][e] : (j < 3 ? in[tt][r0] : (*nx.in)[tt][r0]), x1 = MEM ? xq[hs][e + 1] : (j < 3 ? in[tt][r0 + 1] : (*nx.in)[tt][r0 + 1]);
             if (LN) {
-                u0 = fmaf(fmaf(x0, cpin, dd), gq[hs][e], bq[hs][e]);
-                u1 = fmaf(fmaf(x1, cpin, dd), gq[hs][e + 1], bq[hs][e + 1]);
+                u0 = fmaf(fmaf(x0, cp, dcur), gq[hs][e], bq[hs][e]);
+                u1 = fmaf(fmaf(x1, cp, dcur), gq[hs][e + 1], bq[hs][e + 1]);
                 p0 = __builtin_amdgcn_exp2f(u0); p1 = __builtin_amdgcn_exp2f(u1);
             } else {
-                u0 = x0 * (cpin * kRawScale); u1 = x1 * (cpin * kRawScale);      // cpin == 1: keeps the piece behind this MFMA
+                u0 = x0 * (cp * kRawScale); u1 = x1 * (cp * kRawScale);      // cp == 1: keeps the piece behind this MFMA
             }
         } else if (ph == 1) {
             if (LN) {
@@ -371,22 +358,17 @@ __device__ __forceinline__ void panel_pipe(f32x16 (&acc)[4], const uint4* pn /* 
             hq[m] = __builtin_bit_cast(float, a); lq[m] = __builtin_bit_cast(float, er);
         }
     }
-    // the last piece's results are complete here
-    asm volatile("" : "+v"(hq[15]), "+v"(lq[15]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x4 hv = {hq[4 * j], hq[4 * j + 1], hq[4 * j + 2], hq[4 * j + 3]}, lv = {lq[4 * j], lq[4 * j + 1], lq[4 * j + 2], lq[4 * j + 3]};
-        bn.hi[j] = __builtin_bit_cast(h8, hv); bn.lo[j] = __builtin_bit_cast(h8, lv);
+    if (HASN) {
+        // the last piece's results are complete here
+        asm volatile("" : "+v"(hq[15]), "+v"(lq[15]));
+        const f32x4 hv = {hq[12], hq[13], hq[14], hq[15]}, lv = {lq[12], lq[13], lq[14], lq[15]};
+        bcarry.hi = __builtin_bit_cast(h8, hv); bcarry.lo = __builtin_bit_cast(h8, lv);
     }
 }
 
 #ifndef DSG_PANEL_TRAIL_PRIO
 #define DSG_PANEL_TRAIL_PRIO 1
 #endif
-template <bool FIRST>
-__device__ __forceinline__ void M_PHASE(f32x16 (&acc)[4], unsigned pa, const BOp4& b, const uint4* lds_lane) {
-    m_phase<FIRST>(acc, pa, b);
-}
 template <bool SCLIN, int EPI, int NTO>
 __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, const int ngroups) {
     constexpr int N = 128, NT = 4, NG = 16;
@@ -500,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     // which the eight waves of the CU, in lock-step, all left the matrix cores idle.  Carried across the loop: the operands and the
     // LayerNorm constants of the coming tile.
     constexpr bool XT = SCLIN && EPI == 0;
-    BOp4 bcar;
+    BOp bcar;
     float cc_car = 0.f, dd_car = 0.f;
     for (int g = blockIdx.x; g < ngroups; g += stride) {
         const int tile_raw = g * kPW + wave;
@@ -552,40 +534,46 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             cc = rstd; dd = -mean * rstd;
         };
 
-        // ---- stage 1: memory-fed, LayerNorm + SiLU.  Panel 0's operands are prepared on their own (first tile of the workgroup; every
-        // tile where !XT) or arrive from the previous tile's last panel; the others under the MFMAs of the panel before them.
+        // ---- stage 1: memory-fed, LayerNorm + SiLU.  Step 0's operand is prepared on its own (first tile of the workgroup; every tile
+        // where !XT) or arrives from the previous tile's last panel; every other step under the MFMAs of the step before it.
+        auto step0_mem = [&](const uint4* rd, const float* gv, const float* bv, float cc, float dd) -> BOp {
+            const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
+            const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            return panel_prep<true, true>(x, gv, bv, 0, cc, dd, h);
+        };
+        auto step0_reg = [&](const f32x16 (&in)[NT], const float* gv, const float* bv, float cc, float dd) -> BOp {
+            const float x[8] = {in[0][0], in[0][1], in[0][2], in[0][3], in[0][4], in[0][5], in[0][6], in[0][7]};
+            return panel_prep<true, true>(x, gv, bv, 0, cc, dd, h);
+        };
+        auto none_n = [&]() -> const uint4* { return nullptr; };
         f32x16 acc1[NT];
         {
             float cc, dd;
-            BOp4 b;
+            BOp b0;
             if (!XT || g == (int)blockIdx.x) {
                 ln1_stats(cur, cc, dd);
                 DSG_PSTAMP(0x10);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const uint4* rd = consume_s1(s4);
-                    const float4 xa = __builtin_bit_cast(float4, rd[0]), xb = __builtin_bit_cast(float4, rd[64]);
-                    const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                    const BOp o = panel_prep<true, XT>(x, g1v, b1v, s4, cc, dd, h);
-                    b.hi[s4] = o.hi; b.lo[s4] = o.lo;
-                }
-                v_phase_done(b);
+                b0 = step0_mem(consume_s1(0), g1v, b1v, cc, dd);
+                asm volatile("" : "+v"(b0.hi), "+v"(b0.lo));
             } else {
-                b = bcar; cc = cc_car; dd = dd_car;
+                b0 = bcar; cc = cc_car; dd = dd_car;
             }
             DSG_PSTAMP(0x11);
 #pragma unroll
             for (int p = 0; p < P1; ++p) {
                 const int bi = panel_begin(p + 1);
                 DSG_PSTAMP(0x14);
+                BOp bc;
+                const NextPrep nx{&acc1, 4 * (p + 1), g1v, b1v, cc, dd, nullptr, nullptr};
+                auto cs = [&](int jj) { return consume_s1(4 * p + 1 + jj); };
+                auto cn = [&]() { return consume_s1(4 * p + 4); };
                 if (p + 1 < P1) {
-                    BOp4 bn;
-                    if (p == 0) panel_pipe<true, PIPE_LN>(acc1, c.wrd + bi * kPanelU4, b, bn, acc1, 4 * (p + 1), g1v, b1v, cc, dd, h, [&](int jj) { return consume_s1(4 * (p + 1) + jj); });
-                    else panel_pipe<false, PIPE_LN>(acc1, c.wrd + bi * kPanelU4, b, bn, acc1, 4 * (p + 1), g1v, b1v, cc, dd, h, [&](int jj) { return consume_s1(4 * (p + 1) + jj); });
-                    b = bn;
+                    if (p == 0) panel_pipe_s<true, PIPE_LN, PIPE_LN>(acc1, c.wrd + bi * kPanelU4, b0, bc, acc1, 4 * p, g1v, b1v, cc, dd, h, cs, nx, cn);
+                    else panel_pipe_s<false, PIPE_LN, PIPE_LN>(acc1, c.wrd + bi * kPanelU4, b0, bc, acc1, 4 * p, g1v, b1v, cc, dd, h, cs, nx, cn);
+                    b0 = bc;
                 } else {
-                    const unsigned pa = c.w_rd + (unsigned)bi * (kPanelU4 * 16u);
-                    if (p == 0) M_PHASE<true>(acc1, pa, b, c.wrd); else M_PHASE<false>(acc1, pa, b, c.wrd);
+                    if (p == 0) panel_pipe_s<true, PIPE_LN, PIPE_NONE>(acc1, c.wrd + bi * kPanelU4, b0, bc, acc1, 4 * p, g1v, b1v, cc, dd, h, cs, nx, none_n);
+                    else panel_pipe_s<false, PIPE_LN, PIPE_NONE>(acc1, c.wrd + bi * kPanelU4, b0, bc, acc1, 4 * p, g1v, b1v, cc, dd, h, cs, nx, none_n);
                 }
                 DSG_PSTAMP(0x12);
             }
@@ -599,18 +587,19 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             float mean, m2;
             acc_stats<N, NT>(acc1, h, mean, m2);
             const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
-            BOp4 b, bn;
             DSG_PSTAMP(0x20);
-            v_phase_reg(b, acc1, 0, g2v, b2v, cc, dd, h);
-            v_phase_done(b);
+            BOp b0 = step0_reg(acc1, g2v, b2v, cc, dd), bc, bd;
+            asm volatile("" : "+v"(b0.hi), "+v"(b0.lo));
             DSG_PSTAMP(0x21);
             int bi = panel_begin(PA + 1);
             DSG_PSTAMP(0x24);
-            panel_pipe<true, PIPE_REG>(acc2, c.wrd + bi * kPanelU4, b, bn, acc1, 4, g2v, b2v, cc, dd, h, no_consume);
+            panel_pipe_s<true, PIPE_REG, PIPE_REG>(acc2, c.wrd + bi * kPanelU4, b0, bc, acc1, 0, g2v, b2v, cc, dd, h, no_consume,
+                                                   NextPrep{&acc1, 4, g2v, b2v, cc, dd, nullptr, nullptr}, none_n);
             DSG_PSTAMP(0x22);
             bi = panel_begin(PB);
             DSG_PSTAMP(0x24);
-            M_PHASE<false>(acc2, c.w_rd + (unsigned)bi * (kPanelU4 * 16u), bn, c.wrd);
+            panel_pipe_s<false, PIPE_REG, PIPE_NONE>(acc2, c.wrd + bi * kPanelU4, bc, bd, acc1, 4, g2v, b2v, cc, dd, h, no_consume,
+                                                     NextPrep{&acc1, 0, g2v, b2v, cc, dd, nullptr, nullptr}, none_n);
             DSG_PSTAMP(0x22);
             acc_unscale_add_lds<NT>(acc2, inv2, c2v, h);
         }
@@ -632,50 +621,58 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
         }
         DSG_PSTAMP(0x23);
 
-        // ---- stage 3 (+ shortcut in the same scaled accumulator).  The shortcut's operands (raw input, split only) are prepared
-        // under the MFMAs of the panel before them, starting with stage 3's second panel.
+        // ---- stage 3 (+ shortcut in the same scaled accumulator).  The shortcut's first operand (raw input, split only) is prepared
+        // under the last step of stage 3, the next tile's first operand (XT) under the last step of the shortcut.
         f32x16 (&acc3)[NT] = acc1;
         {
             float mean, m2;
             acc_stats<N, NT>(acc2, h, mean, m2);
             const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
-            BOp4 b, bn;
             DSG_PSTAMP(0x30);
-            v_phase_reg(b, acc2, 0, g3v, b3v, cc, dd, h);
-            v_phase_done(b);
+            BOp b0 = step0_reg(acc2, g3v, b3v, cc, dd), bc, bsc;
+            asm volatile("" : "+v"(b0.hi), "+v"(b0.lo));
             DSG_PSTAMP(0x31);
             int bi = panel_begin(PB + 1);
             DSG_PSTAMP(0x34);
-            panel_pipe<true, PIPE_REG>(acc3, c.wrd + bi * kPanelU4, b, bn, acc2, 4, g3v, b3v, cc, dd, h, no_consume);
+            panel_pipe_s<true, PIPE_REG, PIPE_REG>(acc3, c.wrd + bi * kPanelU4, b0, bc, acc2, 0, g3v, b3v, cc, dd, h, no_consume,
+                                                   NextPrep{&acc2, 4, g3v, b3v, cc, dd, nullptr, nullptr}, none_n);
             DSG_PSTAMP(0x32);
             bi = panel_begin((PD) % NP);
             DSG_PSTAMP(0x34);
             if (SCLIN) {
-                panel_pipe<false, PIPE_RAW>(acc3, c.wrd + bi * kPanelU4, bn, b, acc3, 0, g3v, b3v, 1.f, 0.f, h, [&](int jj) { return consume_sc(jj); });
+                const NextPrep raw{&acc2, 0, g3v, b3v, 1.f, 0.f, nullptr, nullptr};
+                panel_pipe_s<false, PIPE_REG, PIPE_RAW>(acc3, c.wrd + bi * kPanelU4, bc, bsc, acc2, 4, g3v, b3v, cc, dd, h, no_consume, raw,
+                                                        [&]() { return consume_sc(0); });
                 DSG_PSTAMP(0x32);
 #pragma unroll
                 for (int p = 0; p < P1; ++p) {
                     bi = panel_begin((PD + p + 1) % NP);
                     DSG_PSTAMP(0x44);
+                    BOp bn;
+                    auto cs = [&](int jj) { return consume_sc(4 * p + 1 + jj); };
                     if (p + 1 < P1) {
-                        panel_pipe<false, PIPE_RAW>(acc3, c.wrd + bi * kPanelU4, b, bn, acc3, 0, g3v, b3v, 1.f, 0.f, h, [&](int jj) { return consume_sc(4 * (p + 1) + jj); });
-                        b = bn;
+                        panel_pipe_s<false, PIPE_RAW, PIPE_RAW>(acc3, c.wrd + bi * kPanelU4, bsc, bn, acc3, 4 * p, g3v, b3v, 1.f, 0.f, h, cs, raw,
+                                                                [&]() { return consume_sc(4 * p + 4); });
+                        bsc = bn;
                     } else if (XT) {
-                        // the coming tile (the same one again behind the workgroup's last group: its requests are in flight either way)
-                        ln1_stats(nxt, cc_car, dd_car);
-                        panel_pipe<false, PIPE_LN>(acc3, c.wrd + bi * kPanelU4, b, bcar, acc3, 0, g1v, b1v, cc_car, dd_car, h, [&](int jj) {
+                        // the coming tile (the same one again behind the workgroup's last group: its requests are in flight either way): its
+                        // row statistics, then its first stage-1 operand under this panel's last step
+                        const NextPrep nt1{&acc3, 0, g1v, b1v, 0.f, 0.f, &cc_car, &dd_car};
+                        panel_pipe_s<false, PIPE_RAW, PIPE_LN>(acc3, c.wrd + bi * kPanelU4, bsc, bcar, acc3, 4 * p, g3v, b3v, 1.f, 0.f, h, cs, nt1, [&]() {
+                            ln1_stats(nxt, cc_car, dd_car);
                             const uint4* rd = priv_consume(c);
-                            priv_issue(c, xin(nxt, jj + 4)); since_w += 2;
+                            priv_issue(c, xin(nxt, 4)); since_w += 2;
                             return rd;
                         });
                     } else {
-                        M_PHASE<false>(acc3, c.w_rd + (unsigned)bi * (kPanelU4 * 16u), b, c.wrd);
+                        panel_pipe_s<false, PIPE_RAW, PIPE_NONE>(acc3, c.wrd + bi * kPanelU4, bsc, bn, acc3, 4 * p, g3v, b3v, 1.f, 0.f, h, cs, raw, none_n);
                     }
                     DSG_PSTAMP(0x42);
                 }
                 acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
             } else {
-                M_PHASE<false>(acc3, c.w_rd + (unsigned)bi * (kPanelU4 * 16u), bn, c.wrd);
+                panel_pipe_s<false, PIPE_REG, PIPE_NONE>(acc3, c.wrd + bi * kPanelU4, bc, bsc, acc2, 4, g3v, b3v, cc, dd, h, no_consume,
+                                                         NextPrep{&acc2, 0, g3v, b3v, cc, dd, nullptr, nullptr}, none_n);
                 DSG_PSTAMP(0x32);
                 acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
 #pragma unroll
