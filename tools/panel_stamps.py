@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Phase stamps of the persistent panel kernel (library built with -DDSG_CYCLE_STAMPS; run with DSG_EXTRA_CXXFLAGS=-DDSG_CYCLE_STAMPS):
     python tools/panel_stamps.py [op] [B]
-Tags: 01 group start; S0 = V phase done, S1 = panel begun (weights waited, barrier, next panel issued), S2 = M phase done for stage
-S (1 stage 1, 2 stage 2, 3 stage 3, 4 shortcut); 13 / 23 / 43 = stage epilogue (un-scale, condition term); 50 = stored."""
+Tags (stage S: 1 stage 1, 2 stage 2, 3 stage 3, 4 shortcut): 01 group start; S0 = the stage's row statistics done; S1 = step 0's operand
+prepared (outside the MFMA stream); S4 = panel begun (weights waited, barrier, next panel issued); S2 = panel's MFMA stream done (with the
+next step's operand prepared inside it); 13 / 23 / 43 = stage epilogue (un-scale, condition term); 50 = stored.  The stamps write LDS:
+the stamped binary's RESULTS are not valid, only its timing."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
