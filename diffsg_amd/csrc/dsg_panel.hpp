@@ -26,7 +26,7 @@ constexpr int kPW = 8;                 // waves per workgroup (two per SIMD), ON
 constexpr int kPanelU4 = 2048;         // uint4 per weight panel (32 KiB)
 constexpr int kPrivU4 = 128;           // uint4 per private item (2 KiB = two 8-feature groups of one row tile)
 constexpr int kPrivSlots = 5;          // per wave
-constexpr int kPrivDist = 4;           // items in flight ahead of the consumer (a whole V phase: its four items are requested during
+constexpr int kPrivDist = 4;           // items in flight ahead of the consumer (four k16-steps: their items are requested during
                                        // the previous one); the slot refilled is the one read a step earlier
 constexpr int kPanelLdsU4 = 2 * kPanelU4 + kPW * kPrivSlots * kPrivU4 + kWideVec / 4;
 
@@ -114,7 +114,7 @@ __device__ __forceinline__ TilePtrs tile_ptrs(const BlockArgs& a, int g, int wav
 struct PanelCtx {
     unsigned lane16, lane4;
     unsigned w_lds;            // LDS byte address of this wave's 4 KiB piece of weight buffer 0 (buffer 1: + 32 KiB)
-    unsigned w_rd;             // LDS byte address of weight buffer 0 + lane * 16 (M phase)
+    unsigned w_rd;             // LDS byte address of weight buffer 0 + lane * 16
     unsigned p_lds;            // LDS byte address of this wave's private slot 0
     const uint4* wrd;          // weight buffer 0 as ordinary LDS, + lane
     const uint4* prd;          // this wave's private slot 0, + lane
@@ -169,9 +169,9 @@ __device__ __forceinline__ float sub_half_hi(float v, unsigned hi) {
     return r;
 }
 
-// ASM_SPLIT: the hi/lo split exactly as panel_pipe does it (the lo part from the ROUNDED product through v_fma_mix; in the plain form
+// ASM_SPLIT: the hi/lo split exactly as panel_pipe_s does it (the lo part from the ROUNDED product through v_fma_mix; in the plain form
 // hipcc contracts `u * r - hi` into one fma, which moves the last bit of lo): a tile whose first panel is prepared here on one
-// occasion and inside panel_pipe on another must get the same bits (rows do not depend on their position in the batch)
+// occasion and inside panel_pipe_s on another must get the same bits (rows do not depend on their position in the batch)
 template <bool LNACT, bool ASM_SPLIT = false>
 __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamma, const float* beta, int S, float c, float d, int h) {
     float v[8];
@@ -221,7 +221,7 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
     return o;
 }
 
-// ---- One MFMA per `asm volatile` slot (panel_pipe below): volatile statements keep their order, the plane reads are ordinary LDS
+// ---- One MFMA per `asm volatile` slot (panel_pipe_s below): volatile statements keep their order, the plane reads are ordinary LDS
 // loads placed BETWEEN the statements (a load cannot cross a volatile statement, so it stays in the slot it was written in; hipcc counts
 // its lgkmcnt waits itself), and ordinary VALU code is pinned between two MFMAs by passing its inputs / results through the
 // neighbouring statements as "+v" operands.
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int stride = gridDim.x;
     // Waves w and w + 4 share a SIMD.  Both run the same program (every panel's MFMA stream carries the operand preparation of
-    // the next panel between its MFMAs, panel_pipe); the younger half gets a static priority: at equal priority the older wave
+    // the next step between its MFMAs, panel_pipe_s); the younger half gets a static priority: at equal priority the older wave
     // of a SIMD wins every arbitration, finishes a panel ~1 400 cycles before its partner and idles at the barrier while the
     // partner runs alone (cycle stamps: 3 000 against 4 400 cycles per LayerNorm panel).  MI355X guide, "two waves per SIMD".
     const bool lead = wave < 4;
