@@ -276,12 +276,13 @@ def test_msr_and_co_evaluators_on_sampled_outputs_match_the_oracle_scoring():
     assert rel(cost.sum(), ref.sum()) <= 1e-5
 
 
-@pytest.mark.parametrize("name,B", [("msr80", 16384 + 33), ("co3", 16384 + 7)])
+@pytest.mark.parametrize("name,B", [("msr80", 16384 + 33), ("co3", 16384 + 7), ("msr80", 98304 + 33)])
 def test_sample_large_launch_split_vs_exact_f32(name, B):
     """Above the cooperative-kernel threshold (> 512 row tiles per launch) the wide blocks run one wave per tile, the pair
     kernels are used and feature_proj is computed for one CFG pass only (the other pass's consumers wrap their tile index).
     The exact-f32 path shares none of that (full launches for both passes, f32 MFMA kernels): same injected noise, ragged
-    batch, the two must agree to the float32-accuracy bar."""
+    batch, the two must agree to the float32-accuracy bar.  98 337 rows: a persistent workgroup walks 3 (6 in the duplicated call) tile
+    groups, so the operand carried from one tile's last panel into the next tile's first is exercised across several seams."""
     plan, p = synth_params(name, 5)
     cfg = CONFIGS[name]
     T = 5
