@@ -225,7 +225,8 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
 // loads placed BETWEEN the statements (a load cannot cross a volatile statement, so it stays in the slot it was written in; hipcc counts
 // its lgkmcnt waits itself), and ordinary VALU code is pinned between two MFMAs by passing its inputs / results through the
 // neighbouring statements as "+v" operands.
-constexpr int kPlaneAhead = 8;     // MFMA slots between a plane's read and its use
+constexpr int kPlaneAhead = 6;     // MFMA slots between a plane's read and its use (same-box sweep, steps/s: 4: 1 223, 5: 1 218, 6: 1 222 | 6: 1 207,
+                                   // 8: 1 203, 10: 1 200 -- the LDS round trip is covered from 4 on, every two more cost four live registers)
 
 // slot k of a panel: term t = (k / 4) % 3 (hi*bhi, hi*blo, lo*bhi), out tile nt = k % 4, step s = k / 12
 __device__ __forceinline__ constexpr int slot_plane(int k) { return (((k % 4) * 4 + k / 12) * 2 + ((k / 4) % 3 == 2 ? 1 : 0)) * 64; }   // uint4 offset in the panel
