@@ -267,6 +267,12 @@ class UNet1D(nn.Module):
         split on the f16 matrix cores, f32 accumulate) or "f32" (exact v_mfma_f32_32x32x2_f32)."""
         code = {"split_f16": 0, "f32": 1}[mode]
         _lib.check(_lib.lib().dsg_set_precision(self.native_handle(), code))
+        self._native.precision = mode
+
+    @property
+    def precision(self):
+        """The handle's current arithmetic mode ("split_f16" unless `set_precision` changed it)."""
+        return getattr(self._native, "precision", "split_f16")
 
     def range_exceeded(self):
         """True if, since the last query, a raw operand of the split-f16 path left fp16's range (dsg_range_status;

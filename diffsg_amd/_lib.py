@@ -12,6 +12,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiffsg_hip.so")
+RES_PATH = os.path.join(_HERE, "libdiffsg_hip.resources.txt")     # hipcc's kernel-resource-usage remarks of the build (build())
 SOURCES = [os.path.join(_HERE, "csrc", "dsg_api.hip")]
 
 
@@ -62,16 +63,24 @@ def _stale() -> bool:
     return built_id() != source_id(os.environ.get("DSG_EXTRA_CXXFLAGS", ""))   # a process without the flags refuses a measurement build
 
 
+def _resources_current() -> bool:
+    try:
+        with open(RES_PATH) as f:
+            return f.readline().strip() == "build_id " + source_id(os.environ.get("DSG_EXTRA_CXXFLAGS", ""))
+    except OSError:
+        return False
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU).  Serialised by a file lock: the ranks of a
     multi-process launch must not compile the same file at once."""
-    if not force and not _stale():
+    if not force and not _stale() and _resources_current():
         return LIB_PATH
     import fcntl
     with open(LIB_PATH + ".lock", "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         try:
-            if not force and not _stale():      # another process built it while this one waited
+            if not force and not _stale() and _resources_current():      # another process built it while this one waited
                 return LIB_PATH
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             # -fno-slp-vectorize: with the SLP vectoriser on, the packed-f32 code it forms in k_wgrad_h gave run-to-run
@@ -82,14 +91,56 @@ def build(force: bool = False, verbose: bool = False) -> str:
                    # the panel kernel's 48-slot MFMA loops must unroll completely (the slots index register arrays): the default
                    # limit on `#pragma unroll` (16 K) is below the largest variant, whose arrays then land in scratch memory
                    "-mllvm", "-pragma-unroll-threshold=200000",
+                   # per-kernel register / scratch / LDS figures of THIS build (remarks on stderr), kept beside the library:
+                   # tests/test_host_api.py fails on any scratch in a kernel of the 65 536-row step (kernel_resources())
+                   "-Rpass-analysis=kernel-resource-usage",
                    f'-DDSG_BUILD_ID_STR="{source_id(extra)}"', "-o", tmp] + extra.split() + SOURCES
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.run(cmd, check=True)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            remarks = [ln for ln in r.stderr.splitlines() if "remark:" in ln]
+            other = [ln for ln in r.stderr.splitlines() if "remark:" not in ln]
+            if other:
+                print("\n".join(other), file=sys.stderr)
+            if r.returncode != 0:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            with open(RES_PATH + ".tmp", "w") as f:
+                f.write("build_id " + source_id(extra) + "\n" + "\n".join(remarks) + "\n")
+            os.replace(RES_PATH + ".tmp", RES_PATH)
             os.replace(tmp, LIB_PATH)           # atomic: a reader never maps a half-written library
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB_PATH
+
+
+def kernel_resources():
+    """{demangled kernel name: {"vgprs", "agprs", "scratch", "occupancy", "lds", "sgprs"}} of the library in the tree, from the
+    remarks hipcc printed when `build()` compiled it (-Rpass-analysis=kernel-resource-usage).  Raises if the record does not
+    belong to the current sources (run build() first)."""
+    import re
+    if not os.path.exists(RES_PATH):
+        raise RuntimeError(f"{RES_PATH} is missing: run build()")
+    with open(RES_PATH) as f:
+        txt = f.read()
+    first, _, rest = txt.partition("\n")
+    if first.strip() != "build_id " + source_id(os.environ.get("DSG_EXTRA_CXXFLAGS", "")):
+        raise RuntimeError(f"{RES_PATH} was written by a build of other sources: run build()")
+    blocks = re.split(r"remark: [^\n]*Function Name: ", rest)[1:]
+    names = [b.split("\n")[0].strip() for b in blocks]
+    try:
+        dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout.split("\n")
+    except Exception:
+        dem = names
+    out = {}
+    for b, n in zip(blocks, dem):
+        def g(k):
+            m = re.search(k + r": (\d+)", b)
+            return int(m.group(1)) if m else -1
+        n = re.sub(r"^void ", "", n)
+        n = re.sub(r"\(.*", "", n).strip()
+        out[n] = {"vgprs": g("VGPRs"), "agprs": g("AGPRs"), "scratch": g(r"ScratchSize \[bytes/lane\]"),
+                  "occupancy": g(r"Occupancy \[waves/SIMD\]"), "lds": g(r"LDS Size \[bytes/block\]"), "sgprs": g("SGPRs")}
+    return out
 
 
 _lib = None

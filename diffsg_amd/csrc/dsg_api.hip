@@ -201,12 +201,14 @@ struct dsg_handle {
     std::vector<NarrowPhaseArgs> nlds_phases;
     bool nlds_tail = false;            // the LDS form of the run also computes the 64-wide Linear at ops[fuse_hi] (kind 2)
     bool nlds_valid = false;
+    int nlds_ncopies = 0;              // entries of nlds_copies_dev: dsg_bind_weights re-gathers the image from the re-packed arena
+    size_t nlds_image_cap = 0;         // uint4 capacity of nlds_image (grow-only: captured graphs hold the pointer)
 
     // cached step graphs: per-step pair (with / without the renorm kernels), keyed by (rows, chunks); and ONE graph of a whole
     // T-step loop for short schedules, keyed by (rows, chunks, T)
     // captured reverse steps of the current workspace shape: gexec[0] = one early (renorm) step, gexec[1 + k] = 2^k later steps
     hipGraphExec_t gexec[1 + 6] = {};
-    int g_rows = -1, g_chunks = -1;
+    int g_rows = -1, g_chunks = -1, g_chunk_rows = -1;    // chunk_rows: the renorm kernels capture the segment size as an argument
     // chunked calls (dsg_sample_chunked): per-chunk Philox seeds and per-chunk renorm partials
     unsigned long long* seeds_dev = nullptr; int seeds_cap = 0;
     double* red_chunks = nullptr; int red_chunks_cap = 0;
@@ -377,7 +379,7 @@ void carve(dsg_handle* h) {
 void free_graphs(dsg_handle* h) {
     for (auto& g : h->gexec)
         if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-    h->g_rows = h->g_chunks = -1;
+    h->g_rows = h->g_chunks = h->g_chunk_rows = -1;
 }
 
 constexpr int kMaxGmax = 256;   // distinct gradient tensors whose max|G| is tracked (3 per block + 1 per Linear)
@@ -901,8 +903,9 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
     }
     if (sp) HIPCK(hipMemcpyAsync(c.train ? h->fusedh_train_dev : h->fusedh_dev, h->fusedh_host.data(), h->fusedh_host.size() * sizeof(FusedOpH), hipMemcpyHostToDevice, s));
     else HIPCK(hipMemcpyAsync(h->fused_dev, h->fused_host.data(), n * sizeof(FusedOp), hipMemcpyHostToDevice, s));
-    h->nlds_valid = false;
-    h->nlds_tail = false;
+    // the training forward has its own table and leaves the inference plan (and fused_sig) alone: resetting the LDS plan here
+    // would drop the eager sampling path to the non-LDS kernels for good while cached graphs keep replaying the LDS form
+    if (!c.train) { h->nlds_valid = false; h->nlds_tail = false; }
     if (sp && !c.train && !c.ts) {
         // LDS image of the run, cut into phases that fit kNarrowLdsU4: per operator its packed planes and per-feature vectors (static:
         // gathered once into h->nlds_image, a phase's part contiguous) and, behind them, the phase's slice of the time-table row
@@ -1008,13 +1011,19 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
             const size_t image_u4 = image_base;
             if (!h->nlds_ops_dev) HIPCK(hipMalloc(&h->nlds_ops_dev, (h->ops.size() + 1) * sizeof(NarrowLdsOp)));
             if (!h->nlds_copies_dev) HIPCK(hipMalloc(&h->nlds_copies_dev, (h->ops.size() + 1) * 16 * sizeof(NarrowLdsCopy)));
-            if (h->nlds_image) (void)hipFree(h->nlds_image);
-            HIPCK(hipMalloc(&h->nlds_image, (image_u4 + 1) * sizeof(uint4)));
+            if (image_u4 + 1 > h->nlds_image_cap) {
+                // grow-only: the captured step graphs hold the image pointer (phase arguments are passed by value); when it has
+                // to move, every graph captured with the old one goes (nothing is in flight: the stream was synchronised above)
+                if (h->nlds_image) { (void)hipFree(h->nlds_image); free_graphs(h); }
+                HIPCK(hipMalloc(&h->nlds_image, (image_u4 + 1) * sizeof(uint4)));
+                h->nlds_image_cap = image_u4 + 1;
+            }
             HIPCK(hipMemcpy(h->nlds_ops_dev, lops.data(), n_all * sizeof(NarrowLdsOp), hipMemcpyHostToDevice));
             h->nlds_tail = n_all > n;
             HIPCK(hipMemcpy(h->nlds_copies_dev, copies.data(), copies.size() * sizeof(NarrowLdsCopy), hipMemcpyHostToDevice));
             for (size_t k = 0; k < h->nlds_phases.size(); ++k) h->nlds_phases[k].image = h->nlds_image + phase_base[k];
             hipLaunchKernelGGL(k_narrow_image_build, dim3((unsigned)copies.size()), dim3(256), 0, s, (const NarrowLdsCopy*)h->nlds_copies_dev, h->nlds_image);
+            h->nlds_ncopies = (int)copies.size();
             h->nlds_valid = true;
         }
     }
@@ -1838,6 +1847,11 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
         const int nopc = (int)(h->res.size() + h->lin.size());
         hipLaunchKernelGGL(k_op_consts, dim3(cdiv(nopc, 64)), dim3(64), 0, s, h->maxabs, h->opc_desc_dev, nopc, h->opc_dev);
     }
+    // the LDS image of the narrow run (k_fused_narrow_lds) is a COPY of arena pieces: re-gather it from the planes packed above,
+    // into the same buffer (cached graphs keep its pointer) -- otherwise sample() after an optimizer step, load_state_dict or an
+    // EMA swap would run the narrow run on the previous weights while every other block uses the new ones
+    if (h->nlds_image && h->nlds_ncopies > 0)
+        hipLaunchKernelGGL(k_narrow_image_build, dim3((unsigned)h->nlds_ncopies), dim3(256), 0, s, (const NarrowLdsCopy*)h->nlds_copies_dev, h->nlds_image);
     HIPCK(hipGetLastError());
     h->bound = true;
     return 0;
@@ -1854,10 +1868,8 @@ int dsg_set_precision(dsg_handle* h, int mode) {
 int dsg_set_renorm_hook(dsg_handle* h, double* stats3, void (*reduce)(void*), void* user) {
     if (!h) return fail("null handle");
     if (reduce && !stats3) return fail("dsg_set_renorm_hook: a reduce function needs the 3-double device buffer");
-    // the cached step graphs never contain the hook branch (enqueue_step, use_hook), but drop them anyway so that nothing captured
-    // under another hook state can be replayed
-    (void)hipDeviceSynchronize();
-    free_graphs(h);
+    // the cached step graphs never contain the hook branch (enqueue_step is captured with use_hook = false and neither the
+    // callback nor `stats3` is baked into a node), so they stay valid across installs and removals: no synchronise, no re-capture
     h->renorm_stats = stats3; h->renorm_fn = reduce; h->renorm_user = user;
     return 0;
 }
@@ -2053,33 +2065,39 @@ int sample_impl(dsg_handle* h, const float* cond, const float* y_T, const float*
         // the workspace (rows, chunk count) -- not on T, the seed or the schedule.  Captured once per workspace: one early
         // (renorm) step and runs of 1, 2, 4 ... 32 later steps; a call replays min(T, 4) early steps and the binary
         // decomposition of the rest (the shipped T = 20: 4 + one 16-step graph = 5 launches for the whole reverse loop).
-        if (!(h->gexec[0] && h->g_rows == B && h->g_chunks == chunks)) {
+        if (!(h->g_rows == B && h->g_chunks == chunks && h->g_chunk_rows == chunk_rows)) {
             free_graphs(h);
-            for (int variant = 0; variant < 1 + kStepRunGraphs; ++variant) {
-                const int run = variant == 0 ? 1 : 1 << (variant - 1);
-                hipGraph_t g = nullptr;
-                HIPCK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-                int rc = 0;
-                for (int k = 0; k < run && !rc; ++k) rc = enqueue_step(h, c, u, variant == 0, h->cap_stream, nullptr, /*use_hook=*/false, chunks, chunk_n);
-                hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
-                if (rc) return 1;
-                if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
-                e = hipGraphInstantiate(&h->gexec[variant], g, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(g);
-                if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
-            }
-            h->g_rows = B; h->g_chunks = chunks;
+            h->g_rows = B; h->g_chunks = chunks; h->g_chunk_rows = chunk_rows;
         }
+        // captured lazily: only the run lengths a call replays (a one-off batch size pays for its own decomposition, not for
+        // 64 steps of nodes)
+        auto graph_of = [&](int variant) -> int {
+            if (h->gexec[variant]) return 0;
+            const int run = variant == 0 ? 1 : 1 << (variant - 1);
+            hipGraph_t g = nullptr;
+            HIPCK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            int rc = 0;
+            for (int k = 0; k < run && !rc; ++k) rc = enqueue_step(h, c, u, variant == 0, h->cap_stream, nullptr, /*use_hook=*/false, chunks, chunk_n);
+            hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+            if (rc) return 1;
+            if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
+            e = hipGraphInstantiate(&h->gexec[variant], g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
+            return 0;
+        };
         for (int k = 0; k < n_renorm; ++k) {
             if (h->renorm_fn) {                           // the hook calls back into the host: these (<= 4) steps run eagerly
                 if (enqueue_step(h, c, u, true, s)) return 1;
             } else {
+                if (graph_of(0)) return 1;
                 HIPCK(hipGraphLaunch(h->gexec[0], s));
             }
         }
         for (int left = T - n_renorm; left > 0;) {
             int v = kStepRunGraphs - 1;
             while ((1 << v) > left) --v;
+            if (graph_of(1 + v)) return 1;
             HIPCK(hipGraphLaunch(h->gexec[1 + v], s));
             left -= 1 << v;
         }

@@ -75,7 +75,7 @@ class DDPMCore(nn.Module):
 
     @torch.no_grad()
     def sample(self, cond, omega=1.0, *, y_T=None, noise=None, seed=None, host_rng=False, use_graph=True,
-               profile=False):
+               profile=False, check_range=True):
         """Guided reverse sampling; returns y_0 of shape (B, D).
 
         Beyond the reference's `(cond, omega)`:
@@ -83,10 +83,55 @@ class DDPMCore(nn.Module):
           host_rng    draw them with torch.randn on the host exactly as the reference does (same stream for a seed);
           seed        seed of the device Philox stream (default: drawn from torch's global generator);
           use_graph   replay the captured per-step hipGraph (default) or launch every kernel eagerly;
-          profile     eager launch with HIP events around every operator (read back with `op_profile()`).
+          profile     eager launch with HIP events around every operator (read back with `op_profile()`);
+          check_range the split-f16 path cannot represent raw activations beyond +-6e4 (dsg_split.hpp): by default the call
+                      reads the handle's range flag when its launches are done (one synchronise -- the reference's own loop
+                      synchronises 2T times per call, MSR.py:140-141) and, if it is set, repeats itself on the exact-float32
+                      kernels with the same draws, then restores the caller's precision mode.  `check_range=False` only
+                      enqueues (consecutive calls pipeline); the flag is then sticky: the NEXT sample / sample_chunked /
+                      forward on this object raises if that call's results were saturated.
         """
         if not cond.is_cuda:
             raise RuntimeError("DDPM.sample: `cond` is not on a HIP device; libdiffsg_hip has no CPU path")
+        self._raise_if_unchecked_call_saturated()
+        if check_range and seed is None and not (host_rng and y_T is None):
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # the exact-f32 repeat must see the same Philox stream
+        if check_range and host_rng and y_T is None:
+            # draw once here so that a repeat uses the same start state and noise
+            B0, D0 = cond.shape[0], self.model.cfg["input_dim"]
+            y_T = torch.randn(B0, *self.data_size).reshape(B0, D0)
+            zs = [torch.randn(B0, *self.data_size).reshape(B0, D0) for i in range(self.T - 1, 1, -1)]
+            noise = torch.stack(zs) if zs else torch.zeros(0, B0, D0)
+            host_rng = False
+        out = self._sample_once(cond, omega, y_T, noise, seed, host_rng, use_graph, profile)
+        if cond.shape[0] == 0:
+            return out
+        if not check_range:
+            self._range_unchecked = True
+            return out
+        if self.model.range_exceeded():
+            import warnings
+            warnings.warn("DDPM.sample: activations exceeded the fp16 range of the split-f16 path; repeating the call with "
+                          "precision='f32'")
+            prev = self.model.precision
+            self.model.set_precision("f32")
+            try:
+                out = self._sample_once(cond, omega, y_T, noise, seed, host_rng, use_graph, profile)
+            finally:
+                self.model.set_precision(prev)
+        return out
+
+    def _raise_if_unchecked_call_saturated(self):
+        """Sticky range flag of an earlier `check_range=False` call: raise here, at the next entry point, rather than let its
+        saturated numbers pass silently (the flag is per handle and cleared by the query)."""
+        if getattr(self, "_range_unchecked", False):
+            self._range_unchecked = False
+            if self.model.range_exceeded():
+                raise RuntimeError("libdiffsg_hip: an earlier sample(check_range=False) call on this model left the fp16 range of the "
+                                   "split-f16 path (|x| > 6e4): its results are invalid -- repeat it with check_range=True or "
+                                   "model.set_precision('f32')")
+
+    def _sample_once(self, cond, omega, y_T, noise, seed, host_rng, use_graph, profile):
         hd = self.model.native_handle()
         B, D, T = cond.shape[0], self.model.cfg["input_dim"], self.T
         cond = cond.detach().to(torch.float32).contiguous()
@@ -127,7 +172,7 @@ class DDPMCore(nn.Module):
         return out
 
     @torch.no_grad()
-    def sample_chunked(self, cond, omega=1.0, chunk_rows=512, *, seeds=None, y_T=None, noise=None, use_graph=True):
+    def sample_chunked(self, cond, omega=1.0, chunk_rows=512, *, seeds=None, y_T=None, noise=None, use_graph=True, check_range=True):
         """The reference's evaluation shape in one set of launches: `cond` is sampled as consecutive `chunk_rows`-row slices, each
         an independent `sample()` call (own start state and noise, own early-step renorm statistics; classifier_free_MSR.py:257,
         273-279).  Row for row bit-identical to `torch.cat([self.sample(cond[i:i + chunk_rows], omega, seed=seeds[k]) ...])`,
@@ -135,13 +180,19 @@ class DDPMCore(nn.Module):
         import ctypes
         if not cond.is_cuda:
             raise RuntimeError("DDPM.sample_chunked: `cond` is not on a HIP device; libdiffsg_hip has no CPU path")
-        hd = self.model.native_handle()
         B, D, T = cond.shape[0], self.model.cfg["input_dim"], self.T
         if chunk_rows % 32 != 0:
             raise ValueError("chunk_rows must be a multiple of 32")
         nch = (B + chunk_rows - 1) // chunk_rows
         if nch <= 1:
-            return self.sample(cond, omega, y_T=y_T, noise=noise, seed=None if seeds is None else int(seeds[0]), use_graph=use_graph)
+            return self.sample(cond, omega, y_T=y_T, noise=noise, seed=None if seeds is None else int(seeds[0]), use_graph=use_graph,
+                               check_range=check_range)
+        if self.record_denoise_path:
+            # the trajectory ring belongs to one call (dsg_sample_rec): the chunked launch set has none
+            raise RuntimeError("DDPM.sample_chunked does not record the de-noising trajectory: call sample() per chunk "
+                               "(record_denoise_path is set)")
+        self._raise_if_unchecked_call_saturated()
+        hd = self.model.native_handle()
         cond = cond.detach().to(torch.float32).contiguous()
         dev = cond.device
         if seeds is None:
@@ -155,49 +206,44 @@ class DDPMCore(nn.Module):
             if tuple(noise.shape) != (max(T - 2, 0), B, D):
                 raise ValueError(f"noise must have shape ({max(T - 2, 0)}, {B}, {D})")
         sd = (ctypes.c_ulonglong * nch)(*[int(x) & (2 ** 64 - 1) for x in seeds])
-        out = torch.empty(B, D, device=dev, dtype=torch.float32)
         zptr = _lib.ptr(noise) if (noise is not None and noise.numel()) else _lib.ptr(None)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().dsg_sample_chunked(hd, _lib.ptr(cond), _lib.ptr(y_T), zptr, sd, int(chunk_rows), float(omega),
-                                                     _lib.ptr(self._coef_table()), T, _lib.ptr(out), B, 0 if use_graph else 1,
-                                                     _lib.stream_ptr()))
+        coef = self._coef_table()
+
+        def launch():
+            o = torch.empty(B, D, device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().dsg_sample_chunked(self.model.native_handle(), _lib.ptr(cond), _lib.ptr(y_T), zptr, sd, int(chunk_rows),
+                                                         float(omega), _lib.ptr(coef), T, _lib.ptr(o), B, 0 if use_graph else 1,
+                                                         _lib.stream_ptr()))
+            return o
+
+        out = launch()
+        # the call only enqueues: keep its (converted) inputs alive until the next call on this object
+        self._keepalive = (cond, y_T, noise, coef, sd)
+        if not check_range:
+            self._range_unchecked = True
+            return out
+        if self.model.range_exceeded():
+            import warnings
+            warnings.warn("DDPM.sample_chunked: activations exceeded the fp16 range of the split-f16 path; repeating the call with "
+                          "precision='f32'")
+            prev = self.model.precision
+            self.model.set_precision("f32")
+            try:
+                out = launch()
+            finally:
+                self.model.set_precision(prev)
         return out
 
     def sample_chunked_checked(self, cond, omega=1.0, chunk_rows=512, **kw):
-        """`sample_chunked` with the fp16 range check of `sample_checked` (same seeds on the exact-f32 repeat)."""
-        import warnings
-        B = cond.shape[0]
-        nch = max((B + chunk_rows - 1) // chunk_rows, 1)
-        if kw.get("seeds") is None:
-            kw["seeds"] = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(nch)]
-        y = self.sample_chunked(cond, omega, chunk_rows, **kw)
-        if B and self.model.range_exceeded():
-            warnings.warn("DDPM.sample_chunked: activations exceeded the fp16 range of the split-f16 path; repeating the call with "
-                          "precision='f32'")
-            self.model.set_precision("f32")
-            try:
-                y = self.sample_chunked(cond, omega, chunk_rows, **kw)
-            finally:
-                self.model.set_precision("split_f16")
-        return y
+        """`sample_chunked(..., check_range=True)` -- the default since round 4; kept for the callers of round 3."""
+        kw["check_range"] = True
+        return self.sample_chunked(cond, omega, chunk_rows, **kw)
 
     def sample_checked(self, cond, omega=1.0, **kw):
-        """`sample`, then the fp16 range check of the split path (synchronises): if a raw activation left fp16's range
-        (very large omega on an untrained net), the call is repeated on the exact-f32 kernels with the same seed -- the
-        evaluation entry points use this, they synchronise right after sampling anyway."""
-        import warnings
-        if kw.get("seed") is None:
-            kw["seed"] = int(torch.randint(0, 2 ** 62, (1,)).item())
-        y = self.sample(cond, omega, **kw)
-        if cond.shape[0] and self.model.range_exceeded():
-            warnings.warn("DDPM.sample: activations exceeded the fp16 range of the split-f16 path; repeating the call with "
-                          "precision='f32'")
-            self.model.set_precision("f32")
-            try:
-                y = self.sample(cond, omega, **kw)
-            finally:
-                self.model.set_precision("split_f16")
-        return y
+        """`sample(..., check_range=True)` -- the default since round 4; kept for the callers of round 3."""
+        kw["check_range"] = True
+        return self.sample(cond, omega, **kw)
 
     def _decode_recorded(self, i, y):
         """Post-processing of the i-th recorded state (problem specific; overridden by the problem modules)."""
@@ -226,6 +272,7 @@ class DDPMCore(nn.Module):
         publishes the gradients as `.grad` views of one flat bucket (see `grad_bucket`)."""
         if not y.is_cuda:
             raise RuntimeError("DDPM.forward: inputs are not on a HIP device; libdiffsg_hip has no CPU path")
+        self._raise_if_unchecked_call_saturated()
         hd = self.model.native_handle()
         B, dev = y.shape[0], y.device
         if self.device_draws is not None and ts is None and noise is None and cond_mask is None:

@@ -333,16 +333,164 @@ def test_fp16_range_guard_and_omega500_msr80():
     print(f"omega=500 msr80 T=20: HIP vs float64 {e:.2e}, reference float32 vs float64 {budget:.2e}, max|y| {float(ref64.abs().max()):.3g}")
     assert e <= 3.0 * budget + 1e-4
     big = y_T * 1e6
-    ddpm.sample(cond.cuda(), 1.0, y_T=big, noise=z)
+    ddpm.sample(cond.cuda(), 1.0, y_T=big, noise=z, check_range=False)   # enqueue only: the flag stays up for whoever asks next
     with pytest.raises(RuntimeError):
         ddpm.model.check_range()
     assert not ddpm.model.range_exceeded()                      # the query cleared it
+    ddpm._range_unchecked = False
     with pytest.warns(UserWarning):
         ya = ddpm.sample_checked(cond.cuda(), 1.0, y_T=big, noise=z)
     ddpm.model.set_precision("f32")
     yb = ddpm.sample(cond.cuda(), 1.0, y_T=big, noise=z)
     ddpm.model.set_precision("split_f16")
     assert torch.equal(ya, yb)
+
+
+def test_default_sample_never_returns_saturated_results():
+    """the plain reference-API call `DDPM.sample(cond, omega)` checks the fp16 range flag itself.  A start
+    state of 1e6 makes the split path saturate: the default call must come back with the exact-float32 result (and a warning),
+    leave the handle's precision mode as the CALLER had it (here: f32 stays f32, split stays split), and a second plain call
+    must be clean.  With `check_range=False` the call only enqueues and the flag is sticky: the next entry point raises."""
+    name, T, B = "msr80", 8, 96
+    plan, p = synth_params(name, 31)
+    cfg = CONFIGS[name]
+    ddpm = make_ddpm(name, p, T)
+    g = torch.Generator().manual_seed(3)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    big = y_T * 1e6
+    ddpm.model.set_precision("f32")
+    exact = ddpm.sample(cond, 1.0, y_T=big, noise=z)
+    assert ddpm.model.precision == "f32"
+    ddpm.model.set_precision("split_f16")
+    with pytest.warns(UserWarning):
+        got = ddpm.sample(cond, 1.0, y_T=big, noise=z)                   # plain call, default arguments
+    assert torch.equal(got, exact)
+    assert ddpm.model.precision == "split_f16"                           # the caller's mode, not a hard-coded one
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ok = ddpm.sample(cond, 1.0, y_T=y_T, noise=z)                    # second call: in range, no warning, no stale flag
+    assert torch.isfinite(ok).all() and not ddpm.model.range_exceeded()
+    # device-noise form: the repeat must see the same Philox stream as the saturated first attempt would have
+    torch.manual_seed(77)
+    with pytest.warns(UserWarning):
+        a = ddpm.sample(cond, 1.0, y_T=big)
+    torch.manual_seed(77)
+    ddpm.model.set_precision("f32")
+    b = ddpm.sample(cond, 1.0, y_T=big)
+    ddpm.model.set_precision("split_f16")
+    assert torch.equal(a, b)
+    # enqueue-only calls: sticky flag, raised at the next entry point (sample, sample_chunked and forward alike)
+    ddpm.sample(cond, 1.0, y_T=big, noise=z, check_range=False)
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        ddpm.sample(cond, 1.0, y_T=y_T, noise=z)
+    ok2 = ddpm.sample(cond, 1.0, y_T=y_T, noise=z)                       # the raise consumed the flag
+    assert torch.equal(ok2, ok)
+    ddpm.sample(cond, 1.0, y_T=big, noise=z, check_range=False)
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        ddpm(torch.rand(B, cfg["input_dim"]).cuda(), cond)
+    # chunked form: same default
+    with pytest.warns(UserWarning):
+        ch = ddpm.sample_chunked(cond, 1.0, 32, y_T=big, noise=z, seeds=[1, 2, 3])
+    ddpm.model.set_precision("f32")
+    ch32 = ddpm.sample_chunked(cond, 1.0, 32, y_T=big, noise=z, seeds=[1, 2, 3])
+    ddpm.model.set_precision("split_f16")
+    assert torch.equal(ch, ch32)
+
+
+def test_repacked_weights_reach_the_lds_image_of_the_narrow_run():
+    """the LDS-resident narrow run (k_fused_narrow_lds) reads a gathered COPY of the packed planes.  After an
+    in-place weight change (optimizer step, load_state_dict, EMA swap) dsg_bind_weights re-packs the arena; the copy must follow,
+    in eager launches and in the cached graphs alike: sample -> change weights -> sample must equal a fresh handle with the new
+    weights, bit for bit.  Policy (0, 0) puts a 96-row call on the forms a 65 536-row call uses."""
+    name, T, B = "msr80", 6, 96
+    plan, p1 = synth_params(name, 41)
+    _, p2 = synth_params(name, 42)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(4)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    for graph in (True, False):
+        d = make_ddpm(name, p1, T, "large")
+        first = d.sample(cond, 1.0, y_T=y_T, noise=z, use_graph=graph)
+        with torch.no_grad():
+            for k, v in d.model.state_dict(keep_vars=True).items():
+                v.copy_(p2[k].to(v.device))                                 # in place: same pointers, new values
+        second = d.sample(cond, 1.0, y_T=y_T, noise=z, use_graph=graph)
+        fresh = make_ddpm(name, p2, T, "large").sample(cond, 1.0, y_T=y_T, noise=z, use_graph=graph)
+        assert not torch.equal(first, second)
+        assert torch.equal(second, fresh), graph
+
+
+def test_cached_graphs_survive_other_calls_on_the_handle():
+    """a dsg_unet_forward (or a training step) between two sample() calls of one batch size rewrites the
+    narrow-run tables; the cached step graphs keep pointers into the LDS image, which therefore must not move (or the graphs must
+    go with it).  Same bits before and after, graph and eager, and the eager path keeps using the LDS form afterwards."""
+    name, T, B = "msr80", 6, 96
+    plan, p = synth_params(name, 43)
+    cfg = CONFIGS[name]
+    d = make_ddpm(name, p, T, "large")
+    g = torch.Generator().manual_seed(5)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    a = d.sample(cond, 1.0, y_T=y_T, noise=z)
+    x = torch.rand(40, cfg["input_dim"], generator=g).cuda()
+    d.model(x, torch.full((40, 1), 0.5).cuda(), cond[:40], torch.ones(40, 1).cuda())          # other rows, other context
+    b = d.sample(cond, 1.0, y_T=y_T, noise=z)
+    assert torch.equal(a, b)
+    loss = d(torch.rand(64, cfg["input_dim"], generator=g).cuda(), cond[:64])                 # a training step in between
+    loss.backward()
+    c = d.sample(cond, 1.0, y_T=y_T, noise=z)
+    e = d.sample(cond, 1.0, y_T=y_T, noise=z, use_graph=False)
+    assert torch.equal(a, c) and torch.equal(a, e)
+
+
+def test_chunked_graphs_are_keyed_on_the_chunk_size():
+    """two chunked calls with the same batch and the same NUMBER of chunks but different chunk_rows (1 024 rows
+    as 512 + 512, then as 768 + 256) must not share captured renorm kernels (the segment size is a captured argument)."""
+    name, T, B = "msr3", 6, 1024
+    plan, p = synth_params(name, 31)
+    cfg = CONFIGS[name]
+    d = make_ddpm(name, p, T)
+    g = torch.Generator().manual_seed(6)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    seeds = [11, 12]
+    for chunk in (512, 768, 512):
+        whole = d.sample_chunked(cond, 1.0, chunk, seeds=seeds)
+        parts = torch.cat([d.sample(cond[k * chunk:(k + 1) * chunk], 1.0, seed=seeds[k]) for k in range(2)])
+        assert torch.equal(whole, parts), chunk
+    with pytest.raises(RuntimeError, match="trajectory"):
+        d.record_denoise_path = True
+        d.sample_chunked(cond, 1.0, 512, seeds=seeds)
+    d.record_denoise_path = False
+
+
+def test_sample_many_tile_groups_per_workgroup_vs_oracle():
+    """131 072 rows = 8 192 row tiles with both CFG passes: every persistent workgroup (256 CUs x 8 waves) walks
+    FOUR tile groups -- the carried-operand seam between a workgroup's tiles (next tile's first operand prepared under the previous
+    tile's last shortcut panel) against the CPU oracle, not only against the library's own exact-f32 path."""
+    name, B, T, omega = "msr80", 131072, 3, 1.0
+    plan, p = synth_params(name, 5, "init")
+    cfg = CONFIGS[name]
+    ddpm = make_ddpm(name, p, T)
+    g = torch.Generator().manual_seed(19)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g)
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    y0 = ddpm.sample(cond.cuda(), omega, y_T=y_T, noise=z)
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    zd = {i: z[j] for j, i in enumerate(range(T - 1, 1, -1))}
+    with torch.no_grad():
+        ref = O.ddpm_sample(p, plan, bufs, T, cond, omega, y_T, zd)
+    # float64 budget from the first 16 384 rows' renorm-free part is not separable (the renorm couples all rows): the float32
+    # oracle alone is the yardstick here, at the tolerance the 65 536-row case measures (2.8e-7) with head-room
+    e = rel(y0, ref)
+    print(f"{name} B={B} T={T}: rel err vs oracle {e:.2e}")
+    assert e <= TOL
 
 
 def test_global_renorm_hook_matches_one_call_on_the_whole_batch():

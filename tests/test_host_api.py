@@ -170,3 +170,36 @@ def test_trajectory_writers_fail_loudly_without_gpu(tmp_path):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU path"):
         trajectory.nu_trajectory_gen_store(None, os.path.join(GOLD, "data", "3u_18mW_200samples.csv"), str(tmp_path / "t.csv"))
+
+
+# Kernels a 65 536-row reverse step launches (launch table) and the training step's large kernels.
+# none of them may use scratch memory (a spilled register is a vector-memory round trip inside the inner loop).
+SAMPLING_STEP_KERNELS = [
+    "dsg::k_linear_h<4, 1, 0, false>",          # feature_proj
+    "dsg::k_panel128_h<false, 0, 1>", "dsg::k_panel128_h<false, 1, 2>", "dsg::k_panel128_h<true, 0, 1>", "dsg::k_panel128_h<true, 2, 3>",
+    "dsg::k_res64_dual", "dsg::k_res64_lds<true, 0>", "dsg::k_res64_lds<true, 4>",
+    "dsg::k_fused_narrow_lds",
+    "dsg::k_update", "dsg::k_renorm_sum", "dsg::k_renorm_sqdiff", "dsg::k_renorm_apply",
+]
+OTHER_HOT_KERNELS = [
+    "dsg::k_res64_lds<false, 2>", "dsg::k_res64_lds<false, 1>", "dsg::k_res64_lds<true, 2>", "dsg::k_res64_lds<false, 0>",
+    "dsg::k_fused_narrow_h<true>", "dsg::k_fused_narrow_h<false>",
+    "dsg::k_wgrad_h", "dsg::k_fused_narrow_bwd_h", "dsg::k_resblock_bwd_c<128, true>", "dsg::k_resblock_bwd_c<128, false>",
+    "dsg::k_resblock_bwd_c<64, true>", "dsg::k_resblock_bwd_c<64, false>", "dsg::k_wide128_h<true, 0, 1>", "dsg::k_wide128_h<false, 0, 1>",
+    "dsg::k_resblock_h<64, true>", "dsg::k_resblock_h<64, false>", "dsg::k_cond_embed_h", "dsg::k_colsum",
+]
+
+
+@pytest.mark.parametrize("group", ["sampling_step", "other_hot"])
+def test_hot_kernels_use_no_scratch_memory(group):
+    """Compiled with -Rpass-analysis=kernel-resource-usage (diffsg_amd/_lib.build keeps hipcc's remarks beside the library): every
+    kernel of the bench-size reverse step, and the large kernels of the training step / the other launch forms, report
+    ScratchSize = 0 bytes per lane.  Runs on the CPU: hipcc cross-compiles."""
+    from diffsg_amd import _lib
+    _lib.build()
+    res = _lib.kernel_resources()
+    names = SAMPLING_STEP_KERNELS if group == "sampling_step" else OTHER_HOT_KERNELS
+    missing = [n for n in names if n not in res]
+    assert not missing, f"kernels not in the build record (renamed?): {missing}"
+    spilled = {n: res[n]["scratch"] for n in names if res[n]["scratch"] != 0}
+    assert not spilled, f"scratch bytes per lane: {spilled}"
