@@ -293,6 +293,12 @@ class UNet1D(nn.Module):
         0 = always the large-launch forms (what a 65 536-row call uses)."""
         _lib.check(_lib.lib().dsg_set_launch_policy(self.native_handle(), int(coop_max_tiles), int(narrow_small_max_tiles)))
 
+    def set_option(self, name, value):
+        """Per-handle kernel-form switches (dsg_set_option): "narrow_valu8" -- the 8-wide bottom of the net on the vector
+        unit in float32 inside large sampling launches (default on)."""
+        code = {"narrow_valu8": 1}[name]
+        _lib.check(_lib.lib().dsg_set_option(self.native_handle(), code, int(value)))
+
     def forward(self, x, t, cond, cond_mask):
         """
         :param x: (batch_size, input_dim)

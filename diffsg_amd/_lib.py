@@ -99,11 +99,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), file=sys.stderr)
             r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
             remarks = [ln for ln in r.stderr.splitlines() if "remark:" in ln]
-            other = [ln for ln in r.stderr.splitlines() if "remark:" not in ln]
-            if other:
-                print("\n".join(other), file=sys.stderr)
             if r.returncode != 0:
+                print("\n".join(ln for ln in r.stderr.splitlines() if "remark:" not in ln), file=sys.stderr)
                 raise subprocess.CalledProcessError(r.returncode, cmd)
+            warn = [ln for ln in r.stderr.splitlines() if "warning:" in ln]      # (a remark drags its source line and caret along: dropped)
+            if warn:
+                print("\n".join(warn), file=sys.stderr)
             with open(RES_PATH + ".tmp", "w") as f:
                 f.write("build_id " + source_id(extra) + "\n" + "\n".join(remarks) + "\n")
             os.replace(RES_PATH + ".tmp", RES_PATH)
@@ -164,6 +165,7 @@ _SIGS = {
     "dsg_bind_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
     "dsg_set_precision": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "dsg_set_launch_policy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "dsg_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "dsg_set_renorm_hook": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dsg_range_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "dsg_build_id": (ctypes.c_char_p, []),

@@ -201,6 +201,10 @@ struct dsg_handle {
     std::vector<NarrowPhaseArgs> nlds_phases;
     bool nlds_tail = false;            // the LDS form of the run also computes the 64-wide Linear at ops[fuse_hi] (kind 2)
     bool nlds_valid = false;
+    // the 8-wide bottom of the net as ops [v8_lo, v8_hi) (Downsample 16 -> 8 ... Upsample 8 -> 16), or -1: computed on the vector unit
+    // in float32 by the LDS form of the narrow run (dsg_narrow8.hpp); opt_v8: dsg_set_option(DSG_OPT_NARROW_VALU8)
+    int v8_lo = -1, v8_hi = -1;
+    bool opt_v8 = true;
     int nlds_ncopies = 0;              // entries of nlds_copies_dev: dsg_bind_weights re-gathers the image from the re-packed arena
     size_t nlds_image_cap = 0;         // uint4 capacity of nlds_image (grow-only: captured graphs hold the pointer)
 
@@ -917,10 +921,19 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
         int tb_first = -1, tb_last_end = 0;                // time-table slice of the current phase (floats in the row)
         bool fits = true;
         std::vector<int> phase_of(n, 0);
+        // the float32 section (ops [s_lo, s_hi) of the run): one unit of the plan, placed at its first operator
+        const int s_lo = (h->opt_v8 && h->v8_lo >= 0) ? h->v8_lo - h->fuse_lo : -1, s_hi = s_lo >= 0 ? h->v8_hi - h->fuse_lo : -1;
+        const int s_nb = h->d.n_blocks;
+        const unsigned s_u4 = (unsigned)(s_nb == 3 ? V8SecL<3>::SIZE : V8SecL<2>::SIZE) / 4, s_tb_u4 = (unsigned)(2 * s_nb + 3) * 8;
         auto close_phase = [&](int hi) {
             NarrowPhaseArgs ph;
             ph.image = nullptr; ph.n_u4 = used; ph.tb = h->tb + (tb_first < 0 ? 0 : tb_first); ph.tb_u4 = tb_first < 0 ? 0 : (unsigned)(tb_last_end - tb_first) / 4;
             ph.op_lo = phase_lo; ph.op_hi = hi;
+            ph.v8_at = -1; ph.v8_nops = 0; ph.v8_store = 0; ph.v8_sec = 0; ph.v8_tb = 0;
+            if (s_lo >= phase_lo && s_lo < hi) {       // the float32 section lies in this phase (its image offset was noted when it was taken)
+                ph.v8_at = s_lo; ph.v8_nops = s_hi - s_lo; ph.v8_sec = 4 * lops[s_lo].w1; ph.v8_store = lops[s_lo].store_out;
+                ph.v8_tb = 4 * used + (unsigned)(h->res[h->ops[h->fuse_lo + s_lo + 1].p].tb_off - tb_first);
+            }
             // image pointer filled below (needs the buffer); remember the base through n_u4 bookkeeping
             h->nlds_phases.push_back(ph);
             for (int k = phase_lo; k < hi; ++k) {           // the time-bias rows sit behind the static part
@@ -935,7 +948,13 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
             const Op& op = h->ops[h->fuse_lo + i];
             const float* A = h->arena;
             unsigned need = 0, need_tb = 0;
-            if (op.kind == OP_RES) {
+            if (s_lo >= 0 && i > s_lo && i < s_hi) {         // inside the section: planned with its first operator
+                memset(&lops[i], 0, sizeof lops[i]);
+                continue;
+            }
+            if (i == s_lo) {
+                need = s_u4; need_tb = s_tb_u4;
+            } else if (op.kind == OP_RES) {
                 const ResP& r = h->res[op.p];
                 const unsigned KG = groups_of(r.in0) + groups_of(r.in1), KS1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2, KS2 = (groups_of(r.N) + 1) / 2;
                 need = KS1 * 128 * (r.sclin ? 2 : 1) + 2 * KS2 * 128 + 2 * ((KG * 8 + 32 + 3) / 4) + 6 * 8;
@@ -948,21 +967,46 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
             const unsigned tb_now = tb_first < 0 ? 0 : (unsigned)(tb_last_end - tb_first) / 4;
             if (used + need + tb_now + need_tb > (unsigned)kNarrowLdsU4) {
                 close_phase(i);
-                lops[i - 1].store_out = 1;                       // the running tensor crosses the boundary through memory
+                // the running tensor crosses the boundary through memory
+                if (s_lo >= 0 && i == s_hi) h->nlds_phases.back().v8_store = 1;
+                else lops[i - 1].store_out = 1;
                 phase_base.push_back(image_base);
                 phase_lo = i; used = 0; tb_first = -1; tb_last_end = 0;
             }
             NarrowLdsOp& lo = lops[i];
             const int keep_store = lo.store_out;
             memset(&lo, 0, sizeof lo);
-            lo.store_out = h->fusedh_host[i].store_out | keep_store;
+            lo.store_out = h->fusedh_host[(s_lo >= 0 && i == s_lo) ? s_hi - 1 : i].store_out | keep_store;
             auto take = [&](const void* src, unsigned n_u4) -> unsigned {
                 const unsigned off = used;
                 copies.push_back(NarrowLdsCopy{src, image_base + off, n_u4});
                 used += n_u4;
                 return off;
             };
-            if (op.kind == OP_RES) {
+            if (i == s_lo) {
+                // raw nn.Linear matrices (row-major [out][in]) and raw parameter vectors, in the order of V8SecL / V8BlockL
+                const Param* P = h->params.data();
+                const LinOpP& ld = h->lin[op.p];
+                lo.w1 = take(P[ld.l.w].ptr, 32);
+                take(P[ld.l.b].ptr, 2);
+                for (int k = s_lo + 1; k + 1 < s_hi; ++k) {
+                    const ResP& r = h->res[h->ops[h->fuse_lo + k].p];
+                    const unsigned k1 = r.sclin ? 16 : 8;
+                    take(P[r.l1.w].ptr, 2 * k1); take(P[r.l2.w].ptr, 16); take(P[r.l3.w].ptr, 16);
+                    if (r.sclin) take(P[r.sc.w].ptr, 32);
+                    take(P[r.n1.w].ptr, k1 / 4); take(P[r.n1.b].ptr, k1 / 4);
+                    take(P[r.n2.w].ptr, 2); take(P[r.n2.b].ptr, 2); take(P[r.n3.w].ptr, 2); take(P[r.n3.b].ptr, 2);
+                    take(A + r.c2p, 2); take(A + r.c3p, 2);
+                    if (tb_first < 0) tb_first = r.tb_off;
+                    else if (r.tb_off != tb_last_end) { fits = false; break; }
+                    tb_last_end = r.tb_off + pad32(r.N);
+                }
+                if (!fits) break;
+                const LinOpP& lu = h->lin[h->ops[h->fuse_lo + s_hi - 1].p];
+                take(P[lu.l.w].ptr, 32);
+                take(P[lu.l.b].ptr, 4);
+                if (used - lo.w1 != s_u4) return fail("internal: float32 section image is %u uint4, expected %u", used - lo.w1, s_u4);
+            } else if (op.kind == OP_RES) {
                 const ResP& r = h->res[op.p];
                 const unsigned KG = groups_of(r.in0) + groups_of(r.in1), KS1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2, KS2 = (groups_of(r.N) + 1) / 2;
                 const unsigned nv1 = (KG * 8 + 32 + 3) / 4;
@@ -1039,9 +1083,14 @@ int launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
         const FusedOpH* tab = c.train ? h->fusedh_train_dev : h->fusedh_dev;
         if (!c.train && !c.ts && h->nlds_valid && ntiles >= h->panel_min_tiles && ntiles > h->narrow_small_max_tiles) {
             // large sampling launch: the run's planes and vectors resident in LDS, one launch per phase (dsg_split.hpp)
-            for (const auto& ph : h->nlds_phases)
-                hipLaunchKernelGGL(k_fused_narrow_lds, dim3(cdiv(ntiles, 16)), dim3(1024), 0, s, tab, (const NarrowLdsOp*)h->nlds_ops_dev, ph, ntiles, c.step_ptr,
-                                   h->tb_stride);
+            const int v8nb = (h->opt_v8 && h->v8_lo >= 0) ? h->d.n_blocks : 0;
+            for (const auto& ph : h->nlds_phases) {
+                const dim3 g(cdiv(ntiles, 16)), b(1024);
+                const NarrowLdsOp* lops = h->nlds_ops_dev;
+                if (v8nb == 2) hipLaunchKernelGGL(k_fused_narrow_lds<2>, g, b, 0, s, tab, lops, ph, ntiles, c.step_ptr, h->tb_stride);
+                else if (v8nb == 3) hipLaunchKernelGGL(k_fused_narrow_lds<3>, g, b, 0, s, tab, lops, ph, ntiles, c.step_ptr, h->tb_stride);
+                else hipLaunchKernelGGL(k_fused_narrow_lds<0>, g, b, 0, s, tab, lops, ph, ntiles, c.step_ptr, h->tb_stride);
+            }
             return h->nlds_tail ? 1 : 0;
         }
         if (ntiles <= h->narrow_small_max_tiles) hipLaunchKernelGGL(k_fused_narrow_h<true>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
@@ -1571,6 +1620,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         h->lin.push_back(l);
         const int out = add_tensor(h, d.dims[i], true);
         h->ops.push_back(Op{OP_LIN, (int)h->lin.size() - 1, cur, -1, out, nm});
+        if (i == d.n_res - 1 && w == 16 && d.dims[i] == 8 && (d.n_blocks == 2 || d.n_blocks == 3)) h->v8_lo = (int)h->ops.size() - 1;
         cur = out; skips.push_back(cur); ++idx;
         w = d.dims[i];
         if (i == d.n_res - 1)
@@ -1600,6 +1650,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
         h->lin.push_back(l);
         const int out = add_tensor(h, nw, false);
         h->ops.push_back(Op{OP_LIN, (int)h->lin.size() - 1, cur, -1, out, nm});
+        if (i == d.n_res - 1 && h->v8_lo >= 0 && nw == 16) h->v8_hi = (int)h->ops.size();
         cur = out; ++idx;
         w = nw;
         if (i == 0)
@@ -1624,6 +1675,16 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
             if (!f && lo >= 0) { if (i - lo > best_hi - best_lo) { best_lo = lo; best_hi = i; } lo = -1; }
         }
         h->fuse_lo = best_lo; h->fuse_hi = best_hi;
+        // the float32 section must be the shape dsg_narrow8.hpp is written for and lie inside the fused run
+        if (h->v8_lo < 0 || h->v8_hi != h->v8_lo + 2 * d.n_blocks + 5 || h->v8_lo < h->fuse_lo || h->v8_hi > h->fuse_hi) h->v8_lo = h->v8_hi = -1;
+        for (int i = h->v8_lo + 1; h->v8_lo >= 0 && i + 1 < h->v8_hi; ++i) {
+            const Op& o = h->ops[i];
+            const bool up = i - h->v8_lo > d.n_blocks + 2;
+            if (o.kind != OP_RES || h->res[o.p].N != 8 || h->res[o.p].in0 != 8 || h->res[o.p].in1 != (up ? 8 : 0) || o.in0 != h->ops[i - 1].out ||
+                h->res[o.p].tb_off != h->res[h->ops[h->v8_lo + 1].p].tb_off + 32 * (i - h->v8_lo - 1) || o.p != h->ops[h->v8_lo + 1].p + (i - h->v8_lo - 1) ||
+                (up && o.in1 != h->ops[h->v8_lo + d.n_blocks - (i - h->v8_lo - d.n_blocks - 3)].out))
+                h->v8_lo = h->v8_hi = -1;
+        }
     }
     {
         int dev = 0, cus = 0;
@@ -1711,6 +1772,9 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
         HIPCK(hipStreamSynchronize(s));
         for (int i = 0; i < n; ++i) h->params[i].ptr = ptrs[i];
         h->bound_ptrs.assign(ptrs, ptrs + n);
+        // the LDS image of the narrow run gathers raw parameter tensors (float32 section): new pointers, new copy list
+        h->fused_sig.valid = false;
+        h->nlds_ncopies = 0;
         const Param* P = h->params.data();
         float* A = h->arena;
         std::vector<PackDesc> pd;
@@ -1872,6 +1936,21 @@ int dsg_set_renorm_hook(dsg_handle* h, double* stats3, void (*reduce)(void*), vo
     // callback nor `stats3` is baked into a node), so they stay valid across installs and removals: no synchronise, no re-capture
     h->renorm_stats = stats3; h->renorm_fn = reduce; h->renorm_user = user;
     return 0;
+}
+
+int dsg_set_option(dsg_handle* h, int option, int value) {
+    if (!h) return fail("null handle");
+    switch (option) {
+        case DSG_OPT_NARROW_VALU8:
+            if ((value != 0) != h->opt_v8) {
+                (void)hipDeviceSynchronize();
+                free_graphs(h);                 // the captured narrow-run launches hold the plan made under the other setting
+                h->fused_sig.valid = false;
+                h->opt_v8 = value != 0;
+            }
+            return 0;
+        default: return fail("dsg_set_option: unknown option %d", option);
+    }
 }
 
 int dsg_range_status(dsg_handle* h, int* exceeded) {

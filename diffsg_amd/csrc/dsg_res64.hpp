@@ -178,7 +178,10 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
         }
         if (NTO > 0) {
 #pragma unroll
-            for (int k = 0; k < NL; ++k) if (tid + 512 * k < NTO * 4 * 128) rl[k] = A.l.Wh[tid + 512 * k];
+            for (int k = 0; k < NL; ++k) {              // (whole 512-piece rounds unconditionally: a conditionally written array element sends
+                rl[k] = make_uint4(0u, 0u, 0u, 0u);     // the array to scratch memory)
+                if (512 * (k + 1) <= NTO * 4 * 128 || tid + 512 * k < NTO * 4 * 128) rl[k] = A.l.Wh[tid + 512 * k];
+            }
             if (tid < 32 * NTO) bl = A.l.l.bias[tid];
         }
         if (tid < 16 * KS1) { g1 = a.gamma1[tid]; b1 = a.beta1[tid]; }
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
         }
         if (NTO > 0) {
 #pragma unroll
-            for (int k = 0; k < NL; ++k) if (tid + 512 * k < NTO * 4 * 128) lds[L::WL + tid + 512 * k] = rl[k];
+            for (int k = 0; k < NL; ++k)
+                if (512 * (k + 1) <= NTO * 4 * 128 || tid + 512 * k < NTO * 4 * 128) lds[L::WL + tid + 512 * k] = rl[k];
             if (tid < 32 * NTO) vec[L::BL + tid] = bl;
         }
         if (tid < 16 * KS1) { vec[L::G1 + tid] = g1 * kL2; vec[L::B1 + tid] = b1 * kL2; }

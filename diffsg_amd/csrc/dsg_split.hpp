@@ -17,6 +17,7 @@
 // (out tile, k16-step) two planes (hi, lo) of 64 lanes x 8 halfs.
 #pragma once
 #include "dsg_kernels.hpp"
+#include "dsg_narrow8.hpp"
 
 namespace dsg {
 
@@ -200,10 +201,15 @@ __device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f3
 // missing group of the last step reads as zero (its packed weights are zero too).
 // MAXS > 0 (narrow blocks: a segment has at most MAXS k16-steps): the step loop is unrolled, so the prefetched operands are
 // renamed instead of rotated through v_mov (52 copies per iteration of the runtime loop - a tenth of a narrow block's VALU).
-template <int NT, bool LNACT, int MAXS = 0>
-__device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float* __restrict__ xp, int groups, const uint4* __restrict__ wp,
+// FIXG > 0: the segment's group count is known at compile time (the skip input of a narrow up block is as wide as the block): the
+// per-step conditions below fold away -- with a runtime count every array element is a conditional definition, and hipcc keeps the
+// whole set of prefetched operands alive through the merges (spilled, next to the float32 section's larger live state).
+template <int NT, bool LNACT, int MAXS = 0, int FIXG = 0>
+__device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float* __restrict__ xp, int groups_rt, const uint4* __restrict__ wp,
                                                  size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float mean, float rstd, const HFrag<NT>* w0 = nullptr) {
+    if (FIXG > 0 && groups_rt != FIXG) __builtin_trap();
+    const int groups = FIXG > 0 ? FIXG : groups_rt;
     const int steps = (groups + 1) >> 1;
     if (steps <= 0) return;
     if constexpr (MAXS > 0) {
@@ -422,7 +428,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
             chain_from_mem_h<NT, true, (N <= 32 ? 2 : 0)>(acc1, a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.W1h + lane, nt_stride,
                                        gamma1 + 4 * h, beta1 + 4 * h, mean1, rstd1);
         if (a.in1.groups)
-            chain_from_mem_h<NT, true, (N <= 32 ? 2 : 0)>(acc1, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
+            chain_from_mem_h<NT, true, (N <= 32 ? 2 : 0), (XIN && N <= 32 ? NG : 0)>(acc1, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                        ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, gamma1 + 8 * a.in0.groups + 4 * h,
                                        beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr);
         DSG_STAMP(XIN && tile == 0, 0x13);
@@ -484,7 +490,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
             chain_from_mem_h<NT, false, (N <= 32 ? 2 : 0)>(acc3, a.in0.data + (size_t)seg_tile(a.in0, tile) * a.in0.groups * 256 + lane * 4, a.in0.groups, ah.Wsch + lane, nt_stride,
                                         nullptr, nullptr, 0.f, 1.f);
         if (a.in1.groups)
-            chain_from_mem_h<NT, false, (N <= 32 ? 2 : 0)>(acc3, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
+            chain_from_mem_h<NT, false, (N <= 32 ? 2 : 0), (XIN && N <= 32 ? NG : 0)>(acc3, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                         ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f, PRE ? &psb : nullptr);
         if (PRE) acc_unscale_add_reg<NT, NG>(acc3, inv3, vc3);
         else acc_unscale_add<NT, NG>(acc3, inv3, a.c3, h);
@@ -1138,12 +1144,16 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (tile >= ntiles) return;
-    const int h = lane >> 5, j = lane & 31;
     f32x16 x[1];
     float xmean = 0.f, xm2 = 0.f;
     bool have_x = false;
     int entry = -1;                   // time-table entry of this wave's rows: read once, by the first block of the run
+    const int lane_id = lane;
     for (int i = 0; i < nops; ++i) {
+        // opaque per operator (see k_fused_narrow_lds): keeps the lane-derived indices of every operator body inside its body
+        int lane = lane_id;
+        if (!PRE) asm volatile("" : "+v"(lane));
+        const int h = lane >> 5, j = lane & 31;
         const FusedOpH& op = ops[i];
         if (entry < 0 && op.kind == 0) {
             const BlockArgs& b0 = op.b.b;
@@ -1234,15 +1244,27 @@ struct NarrowLdsOp {                     // LDS offsets (uint4 units for planes,
 struct NarrowLdsCopy { const void* src; unsigned dst_u4, n_u4; };
 __global__ void k_narrow_image_build(const NarrowLdsCopy* __restrict__ copies, uint4* __restrict__ image) {
     const NarrowLdsCopy c = copies[blockIdx.x];
-    const uint4* src = reinterpret_cast<const uint4*>(c.src);
-    for (unsigned i = threadIdx.x; i < c.n_u4; i += blockDim.x) image[c.dst_u4 + i] = src[i];
+    if ((reinterpret_cast<unsigned long long>(c.src) & 15ull) == 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(c.src);
+        for (unsigned i = threadIdx.x; i < c.n_u4; i += blockDim.x) image[c.dst_u4 + i] = src[i];
+    } else {    // a raw parameter tensor (the float32 section copies nn.Linear weights as they are) that is only 4-byte aligned
+        const float* src = reinterpret_cast<const float*>(c.src);
+        float* dst = reinterpret_cast<float*>(image + c.dst_u4);
+        for (unsigned i = threadIdx.x; i < 4 * c.n_u4; i += blockDim.x) dst[i] = src[i];
+    }
 }
 struct NarrowPhaseArgs {
     const uint4* image; unsigned n_u4;      // static image of the phase (LDS offset 0)
     const float* tb; unsigned tb_u4;         // its slice of time-table row 0 (+ step * tb_stride floats), LDS offset n_u4
     int op_lo, op_hi;
+    // the float32 section (dsg_narrow8.hpp: the 8-wide bottom of the net on the vector unit) when it lies in this phase: operators
+    // [v8_at, v8_at + v8_nops), its image at LDS float offset v8_sec, its first block's time-bias slice at v8_tb, v8_store: the tensor
+    // that leaves the section crosses a phase boundary through memory.  v8_at < 0: none.
+    int v8_at, v8_nops, v8_store;
+    unsigned v8_sec, v8_tb;
 };
 
+template <int V8NB>    // n_blocks of the float32 section the plan may contain (0: none; one instance per shape keeps one copy of the section in the kernel)
 __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __restrict__ ops, const NarrowLdsOp* __restrict__ lops, const NarrowPhaseArgs ph,
                                                               int ntiles, const int* step_ptr, int tb_stride) {
     __shared__ uint4 lds[kNarrowLdsU4];
@@ -1251,20 +1273,68 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
         // 75-150 KiB from L2 at the same moment, and the burst costs more than the round trips it saves.  The staging is 7 us of a
         // phase's 60 / 89 us (same box, staging skipped: 53 / 82).
         const uint4* tbs = reinterpret_cast<const uint4*>(ph.tb + (size_t)(step_ptr ? *step_ptr : 0) * tb_stride);
-        for (unsigned i = threadIdx.x; i < ph.n_u4; i += 1024) lds[i] = ph.image[i];
-        for (unsigned i = threadIdx.x; i < ph.tb_u4; i += 1024) lds[ph.n_u4 + i] = tbs[i];
+        for (unsigned i = threadIdx.x; i < ph.n_u4; i += blockDim.x) lds[i] = ph.image[i];
+        for (unsigned i = threadIdx.x; i < ph.tb_u4; i += blockDim.x) lds[ph.n_u4 + i] = tbs[i];
     }
     const int op_lo = ph.op_lo, op_hi = ph.op_hi;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 16 + (threadIdx.x >> 6));
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (tile >= ntiles) return;
-    const int h = lane >> 5, j = lane & 31;
     const float* const ldsf = reinterpret_cast<const float*>(lds);
     f32x16 x[1];
     float xmean = 0.f, xm2 = 0.f;
     bool have_x = false;
-    for (int i = op_lo; i < op_hi; ++i) {
+    const int lane_id = lane;
+    // The float32 section sits BETWEEN two runs of the operator loop, not inside it (`part`): as one more case of the loop body it made
+    // hipcc keep two 16-register tuples of the matrix-core operators in scratch memory.
+    int i = op_lo;
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+    const int stop = (V8NB > 0 && part == 0 && ph.v8_at >= 0) ? ph.v8_at : op_hi;
+    if (V8NB > 0 && part == 1 && ph.v8_at >= 0) {
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        const int h = lane >> 5, j = lane & 31;
+        const FusedOpH& op = ops[i];
+        {
+            // the 8-wide bottom of the net on the vector unit: Downsample 16 -> 8 ... Upsample 8 -> 16, skip tensors in registers
+            const LinArgs& la = op.l.l;
+            if (!have_x) {                           // first operator of the phase: its 16-wide input comes from memory
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (G < 2) v = ld4(la.in.data + ((size_t)seg_tile(la.in, tile) * 2 + G) * 256 + lane * 4);
+                    x[0][4 * G] = v.x; x[0][4 * G + 1] = v.y; x[0][4 * G + 2] = v.z; x[0][4 * G + 3] = v.w;
+                }
+                have_x = true;
+            }
+            const BlockArgs& b0 = ops[i + 1].b.b;
+            const BlockArgs& b1 = ops[i + 2].b.b;
+            const V8Sec sc{b0.cond_pre, (long long)(b1.cond_pre - b0.cond_pre), b0.tiles_per_pass, b0.uncond_tiles};
+            v8_lf* const S = (v8_lf*)(ldsf + ph.v8_sec);
+            v8_lf* const tb0 = (v8_lf*)(ldsf + ph.v8_tb);
+            const float xi[8] = {x[0][0], x[0][1], x[0][2], x[0][3], x[0][4], x[0][5], x[0][6], x[0][7]};
+            float xo[8];
+            v8_section<(V8NB > 0 ? V8NB : 2)>(S, tb0, sc, tile, lane, xi, xo, xmean, xm2);
+            x[0] = f32x16{xo[0], xo[1], xo[2], xo[3], xo[4], xo[5], xo[6], xo[7], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ph.v8_store) {                       // the section ends the phase: hand the 16-wide tensor on through memory
+                const LinArgs& lz = ops[i + ph.v8_nops - 1].l.l;
+                if (h == 0) reinterpret_cast<float2*>(lz.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
+#pragma unroll
+                for (int G = 0; G < 2; ++G)
+                    st4(lz.out + ((size_t)tile * 2 + G) * 256 + lane * 4, make_float4(x[0][4 * G], x[0][4 * G + 1], x[0][4 * G + 2], x[0][4 * G + 3]));
+            }
+            i += ph.v8_nops;
+        }
+    }
+#pragma unroll 1
+    for (; i < stop; ++i) {
+        // the lane index as an opaque value per operator: hipcc otherwise hoists every lane-derived index and comparison of every operator
+        // body (`8 G + 4 h + p`, `... < width`: ~40 registers) out of this loop, keeps them live across all of it and spills them
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        const int h = lane >> 5, j = lane & 31;
         const FusedOpH& op = ops[i];
         const NarrowLdsOp lo = lops[i];
         if (op.kind == 0) {
@@ -1288,17 +1358,20 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             // skip tensors were stored by this wave earlier in the run (possibly in an earlier launch): make sure this wave's stores have landed
             if (b.b.in1.groups) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const bool st = lo.store_out != 0;
+            // with the float32 section in the plan every 8-wide block of the net is inside it (dims[-1] = 8): those kernels carry no
+            // matrix-core form of the 4- and 8-wide blocks
+            const int N = (V8NB > 0 && op.N < 16) ? 16 : op.N;
             if (op.sclin) {
-                switch (op.N) {
-                    case 4: resblock_body_h<4, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 8: resblock_body_h<8, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                switch (N) {
+                    case 4: if (V8NB == 0) resblock_body_h<4, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                     case 16: resblock_body_h<16, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                     default: resblock_body_h<32, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                 }
             } else {
-                switch (op.N) {
-                    case 4: resblock_body_h<4, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 8: resblock_body_h<8, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                switch (N) {
+                    case 4: if (V8NB == 0) resblock_body_h<4, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                     case 16: resblock_body_h<16, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                     default: resblock_body_h<32, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                 }
@@ -1331,6 +1404,7 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
                 linear_reg_h(l, tile, lane, x, xmean, xm2, lo.store_out != 0);
             }
         }
+    }
     }
 }
 

@@ -82,6 +82,14 @@ int dsg_range_status(dsg_handle* h, int* exceeded);
  * parity tests run every golden both ways).  Cached step graphs are dropped when the policy changes. */
 int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_max_tiles);
 
+/* Per-handle switches of alternative kernel FORMS (measurement and parity: every form is checked against the same goldens).
+ *   DSG_OPT_NARROW_VALU8   1 (default): in large sampling launches the 8-wide bottom of the net (Downsample 16 -> 8, the 8-wide
+ *                          Down / Middle / Up blocks of UNetCF.py:278-311, Upsample 8 -> 16) runs on the vector unit in exact
+ *                          float32 with its skip tensors in registers (csrc/dsg_narrow8.hpp); 0: on the matrix cores like the rest
+ *                          of the narrow run.  Cached step graphs are dropped when the value changes. */
+enum { DSG_OPT_NARROW_VALU8 = 1 };
+int dsg_set_option(dsg_handle* h, int option, int value);
+
 /* Pre-size the workspace for up to `max_rows` batch rows and `max_entries` time-table rows. */
 int dsg_reserve(dsg_handle* h, int max_rows, int max_entries);
 
