@@ -152,7 +152,7 @@ struct dsg_handle {
     const float** mx_ptrs_dev = nullptr; long long* mx_numel_dev = nullptr; int* mx_idx_dev = nullptr; int mx_n = 0;
     std::vector<int> mx_param;         // param index of each k_maxabs block
     PackHDesc* packh_dev = nullptr; int packh_n = 0; long long packh_blocks = 0;
-    OpConstDesc* opc_desc_dev = nullptr; float* opc_dev = nullptr;   // [res | lin][4]: un-scale factors, refreshed at every bind (k_op_consts)
+    OpConstDesc* opc_desc_dev = nullptr; float* opc_dev = nullptr;   // [res | lin][4]: un-scale factors, refreshed at every bind (k_pack_h)
 
     // forward workspace
     int cap_rows = 0, cap_entries = 0;
@@ -1901,15 +1901,17 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
         HIPCK(hipMemcpyAsync(h->tdesc_dev, td.data(), td.size() * sizeof(TimeBlockDesc), hipMemcpyHostToDevice, s));
         HIPCK(hipStreamSynchronize(s));  // pd / td are host temporaries
     }
-    hipLaunchKernelGGL(k_pack_grouped, dim3((unsigned)h->pack_blocks), dim3(256), 0, s, h->pack_dev, h->pack_n);
+    // (k_pack_grouped also clears the max|W| words for k_maxabs; its grid of >= params / 256 blocks covers them)
+    if ((long long)h->pack_blocks * 256 < (long long)h->params.size()) return fail("internal: pack grid smaller than the parameter table");
+    hipLaunchKernelGGL(k_pack_grouped, dim3((unsigned)h->pack_blocks), dim3(256), 0, s, h->pack_dev, h->pack_n, h->maxabs, (int)h->params.size());
     if (h->mx_n) {
         // max|W| of every split-packed weight -> maxabs[param index]; the pack and the block kernels derive the same
-        // power-of-two scale from it on the device (no host round trip)
-        HIPCK(hipMemsetAsync(h->maxabs, 0, h->params.size() * sizeof(float), s));
+        // power-of-two scale from it on the device (no host round trip); k_pack_h also writes the operators' un-scale constants
         hipLaunchKernelGGL(k_maxabs, dim3(h->mx_n, kMaxabsSlices), dim3(256), 0, s, h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->maxabs);
-        hipLaunchKernelGGL(k_pack_h, dim3((unsigned)h->packh_blocks), dim3(256), 0, s, h->packh_dev, h->packh_n);
         const int nopc = (int)(h->res.size() + h->lin.size());
-        hipLaunchKernelGGL(k_op_consts, dim3(cdiv(nopc, 64)), dim3(64), 0, s, h->maxabs, h->opc_desc_dev, nopc, h->opc_dev);
+        if ((long long)h->packh_blocks * 256 < nopc) return fail("internal: plane-pack grid smaller than the operator table");
+        hipLaunchKernelGGL(k_pack_h, dim3((unsigned)h->packh_blocks), dim3(256), 0, s, h->packh_dev, h->packh_n, (const float*)h->maxabs,
+                           (const OpConstDesc*)h->opc_desc_dev, nopc, h->opc_dev);
     }
     // the LDS image of the narrow run (k_fused_narrow_lds) is a COPY of arena pieces: re-gather it from the planes packed above,
     // into the same buffer (cached graphs keep its pointer) -- otherwise sample() after an optimizer step, load_state_dict or an
@@ -2390,6 +2392,21 @@ int dsg_train_profile(dsg_handle* h, float* ms5) {
     if (!h->tev_valid) return fail("dsg_train_profile: no profiled dsg_train_step yet (dsg_train_profile_enable first)");
     HIPCK(hipEventSynchronize(h->tev[5]));
     for (int i = 0; i < 5; ++i) HIPCK(hipEventElapsedTime(&ms5[i], h->tev[i], h->tev[i + 1]));
+    return 0;
+}
+
+int dsg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int maximize, long long step, void* stream) {
+    if (!p || !g || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return fail("dsg_adam_step: bad arguments");
+    if (n == 0) return 0;
+    if ((reinterpret_cast<unsigned long long>(p) | reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(exp_avg) |
+         reinterpret_cast<unsigned long long>(exp_avg_sq)) & 15ull)
+        return fail("dsg_adam_step: the four buffers must be 16-byte aligned");
+    const AdamArgs a{p, g, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, weight_decay, eps, (float)step, maximize};
+    const long long pieces = (n / 4 + 255) / 256;
+    const unsigned blocks = (unsigned)(pieces < 1 ? 1 : (pieces < 2048 ? pieces : 2048));
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    HIPCK(hipGetLastError());
     return 0;
 }
 

@@ -653,7 +653,13 @@ __device__ __forceinline__ float pack_elem(const PackDesc& d, long long idx) {
 
 constexpr int kPackPerBlock = 256 * 8;
 
-__global__ __launch_bounds__(256) void k_pack_grouped(const PackDesc* __restrict__ descs, int ndesc) {
+// `zero` (nzero floats): the max|W| words of the split path, cleared here for the k_maxabs launch that follows on the same stream (a
+// hipMemsetAsync of its own was a 5 us launch in every training step's re-pack)
+__global__ __launch_bounds__(256) void k_pack_grouped(const PackDesc* __restrict__ descs, int ndesc, float* __restrict__ zero, int nzero) {
+    {
+        const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (gi < nzero) zero[gi] = 0.f;
+    }
     int lo = 0, hi = ndesc - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -1044,6 +1050,50 @@ __global__ __launch_bounds__(256) void k_renorm_apply(float* y, size_t n, const 
 __global__ void k_ema(float* __restrict__ avg, const float* __restrict__ p, float decay, float om, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         avg[i] = __fadd_rn(__fmul_rn(decay, avg[i]), __fmul_rn(om, p[i]));
+}
+
+// Adam (classifier_free_MSR.py:209, torch.optim.Adam defaults; no amsgrad) over ONE flat range, element for element the arithmetic of
+// torch's fused kernel (ATen/native/cuda/fused_adam_utils.cuh, adam_math<float, float, 4, ORIGINAL, false>): the hyper-parameters are
+// doubles, so the two moment updates and the `+ eps` are evaluated in double and rounded once; the bias corrections are formed in
+// double from pow(beta, step) and handed on as floats; step size, square root, quotient and the parameter update are float operations.
+// torch's kernel gives a block 65 536 elements of a tensor: the 1.6 M-element flat parameter vector runs on 26 of 256 CUs (45 us); this
+// one is a plain grid-stride loop over 16-byte pieces (memory-bound: 4 reads + 3 writes per element).
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    size_t n;
+    double lr, beta1, beta2, weight_decay, eps;
+    float step;                 // the step count AFTER this update (1, 2, ...), as torch's float step tensor holds it
+    int maximize;
+};
+__device__ __forceinline__ void adam_one(float& param, float grad, float& exp_avg, float& exp_avg_sq, const AdamArgs& a, float bias_correction1,
+                                         float bias_correction2_sqrt) {
+    if (a.maximize) grad = -grad;
+    if (a.weight_decay != 0) grad += param * a.weight_decay;
+    exp_avg = a.beta1 * exp_avg + (1 - a.beta1) * grad;
+    exp_avg_sq = a.beta2 * exp_avg_sq + (1 - a.beta2) * grad * grad;
+    const float step_size = a.lr / bias_correction1;
+    const float denom = (sqrtf(exp_avg_sq) / bias_correction2_sqrt) + a.eps;
+    param -= step_size * exp_avg / denom;
+}
+__global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
+    const double bc1 = 1 - pow(a.beta1, (double)a.step), bc2 = 1 - pow(a.beta2, (double)a.step);
+    const float bias_correction1 = (float)bc1, bias_correction2_sqrt = (float)sqrt(bc2);
+    const size_t n4 = a.n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 p = ld4(a.p + 4 * i), m = ld4(a.m + 4 * i), v = ld4(a.v + 4 * i);
+        const float4 g = ld4(a.g + 4 * i);
+        adam_one(p.x, g.x, m.x, v.x, a, bias_correction1, bias_correction2_sqrt);
+        adam_one(p.y, g.y, m.y, v.y, a, bias_correction1, bias_correction2_sqrt);
+        adam_one(p.z, g.z, m.z, v.z, a, bias_correction1, bias_correction2_sqrt);
+        adam_one(p.w, g.w, m.w, v.w, a, bias_correction1, bias_correction2_sqrt);
+        st4(a.p + 4 * i, p); st4(a.m + 4 * i, m); st4(a.v + 4 * i, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const size_t i = 4 * n4 + threadIdx.x;
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        adam_one(p, a.g[i], m, v, a, bias_correction1, bias_correction2_sqrt);
+        a.p[i] = p; a.m[i] = m; a.v[i] = v;
+    }
 }
 
 }  // namespace dsg

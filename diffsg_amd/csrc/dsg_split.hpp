@@ -326,7 +326,7 @@ struct BlockArgsH {
     const float* m2;
     const float* m3;
     const float* msc;
-    const float* kc;         // device: { 2^-e1 / 16, 2^-e2 / 16, 2^-e3 / 16 } of this block, computed ONCE at bind time (k_op_consts)
+    const float* kc;         // device: { 2^-e1 / 16, 2^-e2 / 16, 2^-e3 / 16 } of this block, computed ONCE at bind time (by k_pack_h)
                              // from the same max|W| -- scale_exp is a log2 + floor + ldexp per stage, per wave, per block otherwise
 };
 
@@ -848,26 +848,12 @@ struct LinArgsH {
     LinArgs l;
     const uint4* Wh;   // [NT][ceil(KG/2)][2][64]
     const float* m;    // max|W|
-    const float* kc;   // device: { 2^-e (raw operand), 2^-e / 16 (LayerNorm + SiLU operand) } (k_op_consts)
+    const float* kc;   // device: { 2^-e (raw operand), 2^-e / 16 (LayerNorm + SiLU operand) } (written by k_pack_h)
 };
 
 // Bind-time constants of the split path: the un-scale factors of every block and Linear from max|W| (same arithmetic as the
 // kernels used per wave before: scale_exp / scale_exp_lin3 + ldexp).
-struct OpConstDesc { int w1, w2, w3, wsc; };   // parameter indices of lin1, lin2, lin3, shortcut (-1: none); Linear: w1 only
-__global__ void k_op_consts(const float* __restrict__ maxabs, const OpConstDesc* __restrict__ d, int n, float* __restrict__ out /* [n][4] */) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const OpConstDesc c = d[i];
-    if (c.w2 < 0) {          // Linear
-        const int e = scale_exp(maxabs[c.w1]);
-        out[4 * i + 0] = ldexpf(1.0f / kRawScale, -e); out[4 * i + 1] = ldexpf(1.0f / kActScale, -e); out[4 * i + 2] = 0.f; out[4 * i + 3] = 0.f;
-        return;
-    }
-    const int e1 = scale_exp(maxabs[c.w1]), e2 = scale_exp(maxabs[c.w2]);
-    const int e3 = c.wsc >= 0 ? scale_exp_lin3(maxabs[c.w3], maxabs[c.wsc]) : scale_exp(maxabs[c.w3]);
-    out[4 * i + 0] = ldexpf(1.0f / kActScale, -e1); out[4 * i + 1] = ldexpf(1.0f / kActScale, -e2);
-    out[4 * i + 2] = ldexpf(1.0f / kActScale, -e3); out[4 * i + 3] = 0.f;
-}
+struct OpConstDesc { int w1, w2, w3, wsc; };   // parameter indices of lin1, lin2, lin3, shortcut (-1: none); Linear: w1 only (written by k_pack_h)
 
 template <int NTO, int NTI, bool FINAL>
 __device__ __forceinline__ void linear_epilogue_h(const LinArgsH& ah, int tile, int lane, const f32x16 (&x)[NTI], float xmean, float xm2) {
@@ -1510,7 +1496,25 @@ struct PackHDesc {
     long long blk_begin;
 };
 
-__global__ __launch_bounds__(256) void k_pack_h(const PackHDesc* __restrict__ descs, int ndesc) {
+// Blocks [0, ceil(nopc / 256)) also write the un-scale constants of the operators (they need the same final
+// max|W| words as the packing, so they ride in this launch instead of one of their own).
+__global__ __launch_bounds__(256) void k_pack_h(const PackHDesc* __restrict__ descs, int ndesc, const float* __restrict__ maxabs,
+                                                const OpConstDesc* __restrict__ opc_desc, int nopc, float* __restrict__ opc_out) {
+    {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < nopc) {
+            const OpConstDesc c = opc_desc[i];
+            if (c.w2 < 0) {          // Linear
+                const int e = scale_exp(maxabs[c.w1]);
+                opc_out[4 * i + 0] = ldexpf(1.0f / kRawScale, -e); opc_out[4 * i + 1] = ldexpf(1.0f / kActScale, -e); opc_out[4 * i + 2] = 0.f; opc_out[4 * i + 3] = 0.f;
+            } else {
+                const int e1 = scale_exp(maxabs[c.w1]), e2 = scale_exp(maxabs[c.w2]);
+                const int e3 = c.wsc >= 0 ? scale_exp_lin3(maxabs[c.w3], maxabs[c.wsc]) : scale_exp(maxabs[c.w3]);
+                opc_out[4 * i + 0] = ldexpf(1.0f / kActScale, -e1); opc_out[4 * i + 1] = ldexpf(1.0f / kActScale, -e2);
+                opc_out[4 * i + 2] = ldexpf(1.0f / kActScale, -e3); opc_out[4 * i + 3] = 0.f;
+            }
+        }
+    }
     int lo = 0, hi = ndesc - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;

@@ -529,9 +529,12 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
         rstd1 = rsqrtf(m2 / n + kLnEps);
         if (w == 0 && h == 0 && live) reinterpret_cast<float2*>(a.rs1)[(size_t)tile * 32 + j] = make_float2(mean1, rstd1);
     }
-    // weight scales (bind-time maxima)
-    const int e3 = SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3), e2 = scale_exp(*ah.m2), e1 = scale_exp(*ah.m1);
-    const float winv3 = __int_as_float((127 - e3) << 23), winv2 = __int_as_float((127 - e2) << 23), winv1 = __int_as_float((127 - e1) << 23);
+    // weight scales 2^-e (bind-time maxima): evaluated where they are used -- kept from here they are three of the registers this
+    // kernel does not have (256 allocated, three spilled before)
+    auto winv_of = [&](int stage) -> float {
+        const int e = stage == 3 ? (SCLIN ? scale_exp_lin3(*ah.m3, *ah.msc) : scale_exp(*ah.m3)) : stage == 2 ? scale_exp(*ah.m2) : scale_exp(*ah.m1);
+        return __int_as_float((127 - e) << 23);
+    };
 
     // ---- dL/d(out): column sums, slice statistics of h2 / h1, row max
     if (live) slice_colsum(g, csb + 32 * w, lane, h);
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
     coop_mma<KS>(d, Bimg, wf, KS, lane);
     coop_load_w<KS>(wf, ah.W2Th + (size_t)w * KS * 128 + lane, KS);      // next stage's planes: requested now, used after three barriers
     {
-        const float post = sginv * winv3;
+        const float post = sginv * winv_of(3);
 #pragma unroll
         for (int r = 0; r < 16; ++r) d[0][r] *= post;
         float s1 = 0.f, s2 = 0.f;
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
     coop_mma<KS>(d, Bimg, wf, KS, lane);
     coop_load_w<KS>(wf, ah.W1Th + (size_t)w * KS * 128 + lane, KS);      // stage 1, first out tile (the in0 slice)
     {
-        const float post = sdinv * winv2;
+        const float post = sdinv * winv_of(2);
 #pragma unroll
         for (int r = 0; r < 16; ++r) d[0][r] *= post;
         float s1 = 0.f, s2 = 0.f;
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
             coop_mma<KS>(dx[t], Bimg, wf, KS, lane);
             if (t + 1 < DT) coop_load_w<KS>(wf, ah.W1Th + (size_t)(T + NT) * KS * 128 + lane, KS);
             else if (SCLIN) coop_load_w<KS>(wf, ah.WscTh + (size_t)w * KS * 128 + lane, KS);
-            const float post = sdinv * winv1;
+            const float post = sdinv * winv_of(1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx[t][0][r] *= post;
             slice_ln_bwd1(dx[t][0], xin[t], a.gamma1 + 32 * T, a.beta1 + 32 * T, mean1, rstd1, lane, h, csb + 7 * NP + 32 * T,

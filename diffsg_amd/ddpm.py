@@ -277,12 +277,26 @@ class DDPMCore(nn.Module):
         B, dev = y.shape[0], y.device
         if self.device_draws is not None and ts is None and noise is None and cond_mask is None:
             return self._forward_device_draws(hd, y, cond)
-        if ts is None:
-            ts = torch.randint(low=0, high=self.T, size=(1, B), device=dev)
-        if noise is None:
-            noise = torch.randn_like(y)
-        if cond_mask is None:
-            cond_mask = torch.bernoulli(torch.fill(torch.zeros(cond.shape[0], device=dev), 1 - self.uncond_prob))[:, None]
+        if ts is None or noise is None or cond_mask is None:
+            # The three draws of MSR.py:101-107, in the reference's order, from torch's generator -- enqueued on a side stream: they
+            # depend on nothing, and on the caller's stream they would queue up behind the previous step's optimizer and re-pack
+            # launches (seven small kernels, ~40 us of a 2.2 ms step at 32 768 rows).  The generator's state advances on the host in
+            # call order, so the numbers are the ones the same calls give on the caller's stream.
+            main = torch.cuda.current_stream(dev)
+            side = main if not getattr(self, "draws_on_side_stream", True) else getattr(self, "_draw_stream", None)
+            if side is None or side.device != dev:
+                side = self._draw_stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(side):
+                if ts is None:
+                    ts = torch.randint(low=0, high=self.T, size=(1, B), device=dev)
+                if noise is None:
+                    noise = torch.randn_like(y)
+                if cond_mask is None:
+                    cond_mask = torch.bernoulli(torch.fill(torch.zeros(cond.shape[0], device=dev), 1 - self.uncond_prob))[:, None]
+            if side is not main:
+                main.wait_stream(side)
+                for t in (ts, noise, cond_mask):
+                    t.record_stream(main)   # allocated on the side stream, consumed on the caller's
         y32 = y.detach().to(torch.float32).contiguous()
         c32 = cond.detach().to(dev, torch.float32).contiguous()
         ts32 = ts.to(dev).reshape(-1).to(torch.int32).contiguous()

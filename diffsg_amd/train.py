@@ -34,6 +34,8 @@ class FlatAdam(torch.optim.Adam):
     arithmetic as Adam over the ~330 separate tensors, in one kernel launch instead of one multi-tensor launch per chunk
     of tensors.  A torch `Optimizer`, so MultiStepLR drives it as it drives the reference's."""
 
+    native_step = True       # False: torch's own fused kernel (A/B measurements, tools/train_ab.py)
+
     def __init__(self, diffusion_model, lr=1e-3, **kw):
         self._ddpm = diffusion_model
         self._flat = torch.nn.Parameter(flatten_parameters(diffusion_model.model))
@@ -46,7 +48,34 @@ class FlatAdam(torch.optim.Adam):
         if bucket is None or not getattr(self._ddpm, "_grads_ready", False) or self._ddpm.model.param_list()[0].grad is None:
             return None                    # no backward since the last zero_grad
         self._flat.grad = bucket
-        out = super().step(closure)
+        group = self.param_groups[0]
+        plain = (self.native_step and closure is None and len(self.param_groups) == 1 and not group.get("amsgrad") and not group.get("capturable")
+                 and not group.get("differentiable") and not torch.is_tensor(group["lr"]) and self._flat.is_cuda)
+        if not plain:
+            st = self.state.get(self._flat)
+            if st and group.get("fused") and not st["step"].is_cuda:
+                st["step"] = st["step"].to(self._flat.device)       # torch's fused kernel counts on the device
+            out = super().step(closure)    # torch's own kernels for the variants dsg_adam_step does not cover
+        else:
+            # torch's fused kernel hands a block 65 536 elements of a tensor: the one flat tensor runs on 26 workgroups (45 us for 6.6 MB);
+            # dsg_adam_step is the same arithmetic element for element (tests: bit-identical trajectories) as a grid-wide loop, and the
+            # step count stays on the host (no `_foreach_add_` launch for it)
+            from . import _lib
+            st = self.state[self._flat]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(self._flat, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(self._flat, memory_format=torch.preserve_format)
+            if st["step"].is_cuda:         # a state loaded from a fused-Adam checkpoint: keep counting on the host
+                st["step"] = st["step"].detach().cpu()
+            st["step"] += 1
+            b1, b2 = group["betas"]
+            with torch.cuda.device(self._flat.device):
+                _lib.check(_lib.lib().dsg_adam_step(_lib.ptr(self._flat), _lib.ptr(bucket), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
+                                                    self._flat.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                    float(group["weight_decay"]), int(bool(group.get("maximize"))), int(st["step"].item()),
+                                                    _lib.stream_ptr()))
+            out = None
         self._ddpm.model.mark_weights_changed()   # in-place update through an alias: the per-parameter versions do not move
         return out
 

@@ -162,6 +162,13 @@ int dsg_train_step_seeded(dsg_handle* h, const float* y, const float* cond, unsi
 int dsg_train_profile_enable(dsg_handle* h, int on);
 int dsg_train_profile(dsg_handle* h, float* ms5);
 
+/* One Adam step (torch.optim.Adam, no amsgrad) over a flat float32 range: p, exp_avg, exp_avg_sq updated in place from g.  Element for
+ * element the arithmetic of torch's fused kernel (ATen/native/cuda/fused_adam_utils.cuh), so the trajectory of the reference's optimizer
+ * (classifier_free_MSR.py:209) is reproduced bit for bit; `step` is the update's number (1 for the first).  Replaces torch's
+ * multi_tensor_apply launch, which gives the 1.6 M-element flat parameter vector to 26 workgroups. */
+int dsg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int maximize, long long step, void* stream);
+
 /* avg = decay*avg + one_minus_decay*p over n floats   (ddpm_opt/ema.py:11-12). */
 int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_decay, long long n, void* stream);
 
