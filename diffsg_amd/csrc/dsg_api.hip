@@ -205,6 +205,9 @@ struct dsg_handle {
     // in float32 by the LDS form of the narrow run (dsg_narrow8.hpp); opt_v8: dsg_set_option(DSG_OPT_NARROW_VALU8)
     int v8_lo = -1, v8_hi = -1;
     bool opt_v8 = true;
+    // the section's image in global memory (V8SecL layout: raw nn.Linear matrices and parameter vectors), gathered at every bind; the LDS
+    // form of the narrow run stages it as one piece, small launches and the training forward read it from L1 / L2
+    float* v8_image = nullptr; NarrowLdsCopy* v8_copies_dev = nullptr; int v8_ncopies = 0;
     int nlds_ncopies = 0;              // entries of nlds_copies_dev: dsg_bind_weights re-gathers the image from the re-packed arena
     size_t nlds_image_cap = 0;         // uint4 capacity of nlds_image (grow-only: captured graphs hold the pointer)
 
@@ -984,28 +987,15 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
                 return off;
             };
             if (i == s_lo) {
-                // raw nn.Linear matrices (row-major [out][in]) and raw parameter vectors, in the order of V8SecL / V8BlockL
-                const Param* P = h->params.data();
-                const LinOpP& ld = h->lin[op.p];
-                lo.w1 = take(P[ld.l.w].ptr, 32);
-                take(P[ld.l.b].ptr, 2);
+                // the section's image as one piece (gathered at bind time into h->v8_image, dsg_bind_weights)
+                lo.w1 = take(h->v8_image, s_u4);
                 for (int k = s_lo + 1; k + 1 < s_hi; ++k) {
                     const ResP& r = h->res[h->ops[h->fuse_lo + k].p];
-                    const unsigned k1 = r.sclin ? 16 : 8;
-                    take(P[r.l1.w].ptr, 2 * k1); take(P[r.l2.w].ptr, 16); take(P[r.l3.w].ptr, 16);
-                    if (r.sclin) take(P[r.sc.w].ptr, 32);
-                    take(P[r.n1.w].ptr, k1 / 4); take(P[r.n1.b].ptr, k1 / 4);
-                    take(P[r.n2.w].ptr, 2); take(P[r.n2.b].ptr, 2); take(P[r.n3.w].ptr, 2); take(P[r.n3.b].ptr, 2);
-                    take(A + r.c2p, 2); take(A + r.c3p, 2);
                     if (tb_first < 0) tb_first = r.tb_off;
                     else if (r.tb_off != tb_last_end) { fits = false; break; }
                     tb_last_end = r.tb_off + pad32(r.N);
                 }
                 if (!fits) break;
-                const LinOpP& lu = h->lin[h->ops[h->fuse_lo + s_hi - 1].p];
-                take(P[lu.l.w].ptr, 32);
-                take(P[lu.l.b].ptr, 4);
-                if (used - lo.w1 != s_u4) return fail("internal: float32 section image is %u uint4, expected %u", used - lo.w1, s_u4);
             } else if (op.kind == OP_RES) {
                 const ResP& r = h->res[op.p];
                 const unsigned KG = groups_of(r.in0) + groups_of(r.in1), KS1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2, KS2 = (groups_of(r.N) + 1) / 2;
@@ -1093,8 +1083,16 @@ int launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
             }
             return h->nlds_tail ? 1 : 0;
         }
-        if (ntiles <= h->narrow_small_max_tiles) hipLaunchKernelGGL(k_fused_narrow_h<true>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
-        else hipLaunchKernelGGL(k_fused_narrow_h<false>, grid, block, 0, s, tab, h->fuse_hi - h->fuse_lo, ntiles);
+        // the 8-wide bottom of the net on the vector unit (float32, dsg_narrow8.hpp) from the global image: sampling launches below the
+        // LDS form's threshold, dsg_unet_forward, and the training forward (which stores what the backward pass reads)
+        const bool v8 = h->opt_v8 && h->v8_lo >= 0 && h->v8_ncopies > 0 && c.cond_pre;
+        const int v8nb = v8 ? h->d.n_blocks : 0, v8_at = v8 ? h->v8_lo - h->fuse_lo : -1, v8_n = v8 ? h->v8_hi - h->v8_lo : 0, nops = h->fuse_hi - h->fuse_lo;
+        const int st = c.train ? 1 : 0;
+        const bool pre = ntiles <= h->narrow_small_max_tiles;
+#define DSG_NARROW(PRE_, NB_) hipLaunchKernelGGL((k_fused_narrow_h<PRE_, NB_>), grid, block, 0, s, tab, nops, ntiles, v8_at, v8_n, (const float*)h->v8_image, st)
+        if (pre) { if (v8nb == 2) DSG_NARROW(true, 2); else if (v8nb == 3) DSG_NARROW(true, 3); else DSG_NARROW(true, 0); }
+        else { if (v8nb == 2) DSG_NARROW(false, 2); else if (v8nb == 3) DSG_NARROW(false, 3); else DSG_NARROW(false, 0); }
+#undef DSG_NARROW
     }
     else hipLaunchKernelGGL(k_fused_narrow, grid, block, 0, s, h->fused_dev, h->fuse_hi - h->fuse_lo, ntiles);
     return 0;
@@ -1729,6 +1727,8 @@ void dsg_destroy(dsg_handle* h) {
     if (h && h->nlds_ops_dev) (void)hipFree(h->nlds_ops_dev);
     if (h && h->nlds_copies_dev) (void)hipFree(h->nlds_copies_dev);
     if (h && h->nlds_image) (void)hipFree(h->nlds_image);
+    if (h && h->v8_image) (void)hipFree(h->v8_image);
+    if (h && h->v8_copies_dev) (void)hipFree(h->v8_copies_dev);
     if (h && h->seeds_dev) (void)hipFree(h->seeds_dev);
     if (h && h->red_chunks) (void)hipFree(h->red_chunks);
     if (h)
@@ -1772,9 +1772,35 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
         HIPCK(hipStreamSynchronize(s));
         for (int i = 0; i < n; ++i) h->params[i].ptr = ptrs[i];
         h->bound_ptrs.assign(ptrs, ptrs + n);
-        // the LDS image of the narrow run gathers raw parameter tensors (float32 section): new pointers, new copy list
-        h->fused_sig.valid = false;
-        h->nlds_ncopies = 0;
+        if (h->v8_lo >= 0) {
+            // copy list of the float32 section's image: raw matrices and vectors in the order of V8SecL / V8BlockL (dsg_narrow8.hpp)
+            const unsigned sec_u4 = (unsigned)(h->d.n_blocks == 3 ? V8SecL<3>::SIZE : V8SecL<2>::SIZE) / 4;
+            std::vector<NarrowLdsCopy> cp;
+            unsigned used = 0;
+            auto take = [&](const void* src, unsigned n_u4) { cp.push_back(NarrowLdsCopy{src, used, n_u4}); used += n_u4; };
+            const Param* P = h->params.data();
+            const float* A = h->arena;
+            const LinOpP& ld = h->lin[h->ops[h->v8_lo].p];
+            take(P[ld.l.w].ptr, 32); take(P[ld.l.b].ptr, 2);
+            for (int k = h->v8_lo + 1; k + 1 < h->v8_hi; ++k) {
+                const ResP& r = h->res[h->ops[k].p];
+                const unsigned k1 = r.sclin ? 16 : 8;
+                take(P[r.l1.w].ptr, 2 * k1); take(P[r.l2.w].ptr, 16); take(P[r.l3.w].ptr, 16);
+                if (r.sclin) take(P[r.sc.w].ptr, 32);
+                take(P[r.n1.w].ptr, k1 / 4); take(P[r.n1.b].ptr, k1 / 4);
+                take(P[r.n2.w].ptr, 2); take(P[r.n2.b].ptr, 2); take(P[r.n3.w].ptr, 2); take(P[r.n3.b].ptr, 2);
+                take(A + r.c2p, 2); take(A + r.c3p, 2);
+            }
+            const LinOpP& lu = h->lin[h->ops[h->v8_hi - 1].p];
+            take(P[lu.l.w].ptr, 32); take(P[lu.l.b].ptr, 4);
+            if (used != sec_u4) return fail("internal: float32 section image is %u uint4, expected %u", used, sec_u4);
+            if (!h->v8_image) {
+                HIPCK(hipMalloc(&h->v8_image, (size_t)sec_u4 * sizeof(uint4)));
+                HIPCK(hipMalloc(&h->v8_copies_dev, cp.size() * sizeof(NarrowLdsCopy)));
+            }
+            HIPCK(hipMemcpy(h->v8_copies_dev, cp.data(), cp.size() * sizeof(NarrowLdsCopy), hipMemcpyHostToDevice));
+            h->v8_ncopies = (int)cp.size();
+        }
         const Param* P = h->params.data();
         float* A = h->arena;
         std::vector<PackDesc> pd;
@@ -1916,6 +1942,9 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
     // the LDS image of the narrow run (k_fused_narrow_lds) is a COPY of arena pieces: re-gather it from the planes packed above,
     // into the same buffer (cached graphs keep its pointer) -- otherwise sample() after an optimizer step, load_state_dict or an
     // EMA swap would run the narrow run on the previous weights while every other block uses the new ones
+    if (h->v8_ncopies > 0)      // first: the LDS image below takes the section from this buffer
+        hipLaunchKernelGGL(k_narrow_image_build, dim3((unsigned)h->v8_ncopies), dim3(64), 0, s, (const NarrowLdsCopy*)h->v8_copies_dev,
+                           reinterpret_cast<uint4*>(h->v8_image));
     if (h->nlds_image && h->nlds_ncopies > 0)
         hipLaunchKernelGGL(k_narrow_image_build, dim3((unsigned)h->nlds_ncopies), dim3(256), 0, s, (const NarrowLdsCopy*)h->nlds_copies_dev, h->nlds_image);
     HIPCK(hipGetLastError());

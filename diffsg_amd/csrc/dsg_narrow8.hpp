@@ -22,7 +22,12 @@ typedef float v8f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const float v8_lf;
 typedef __attribute__((address_space(3))) const v8f4 v8_lf4;
 
-// float offsets inside one block's LDS record (the host lays the pieces out in this order: dsg_api.hip, plan of the narrow run)
+// The image of the section is read through `PF`: an LDS pointer (v8_lf*: the LDS form of the narrow run stages it with the rest of its
+// phase) or a global one (const float*: small launches and the training forward read the 11 KiB image from L1 / L2).
+__device__ __forceinline__ v8f4 v8_ld4(v8_lf* p) { return *(v8_lf4*)p; }
+__device__ __forceinline__ v8f4 v8_ld4(const float* p) { const float4 v = ld4(p); return v8f4{v.x, v.y, v.z, v.w}; }
+
+// float offsets inside one block's record (the host lays the pieces out in this order: dsg_api.hip, plan of the narrow run)
 template <bool UP> struct V8BlockL {
     static constexpr int K1 = UP ? 16 : 8;
     static constexpr int W1 = 0, W2 = W1 + 8 * K1, W3 = W2 + 64, WSC = W3 + 64, G1 = WSC + (UP ? 128 : 0), B1 = G1 + K1, G2 = B1 + K1, B2 = G2 + 8,
@@ -59,11 +64,11 @@ __device__ __forceinline__ void v8_gather(const float (&own)[4], float (&full)[8
 // of its stage (in flight under the LayerNorm / SiLU arithmetic), the second half behind the gather (in flight under the first half's
 // multiply-adds) -- four ds_read_b128 per request instead of two with a wait behind each pair, and never more than 32 weight registers live
 struct V8W { v8f4 r[4]; };
-template <int LDW>
-__device__ __forceinline__ V8W v8_wload(v8_lf* wl, int k0) {
+template <int LDW, typename PF>
+__device__ __forceinline__ V8W v8_wload(PF wl, int k0) {
     V8W w;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) w.r[o] = *(v8_lf4*)(wl + o * LDW + k0);
+    for (int o = 0; o < 4; ++o) w.r[o] = v8_ld4(wl + o * LDW + k0);
     return w;
 }
 // acc[o] += sum_{k < 4} W[row_o][k0 + k] * v[k]: each output's sum in feature order, the four outputs advance together (independent chains)
@@ -74,8 +79,8 @@ __device__ __forceinline__ void v8_dot4(float (&acc)[4], const V8W& w, const flo
         for (int o = 0; o < 4; ++o) acc[o] = fmaf(w.r[o][k], v[k], acc[o]);
 }
 // acc += W[:, k0 .. k0 + 7] v with the first half already in registers
-template <int LDW>
-__device__ __forceinline__ void v8_dot8(float (&acc)[4], v8_lf* wl, int k0, const V8W& w0, const float (&v)[8]) {
+template <int LDW, typename PF>
+__device__ __forceinline__ void v8_dot8(float (&acc)[4], PF wl, int k0, const V8W& w0, const float (&v)[8]) {
     const V8W w1 = v8_wload<LDW>(wl, k0 + 4);
     v8_dot4(acc, w0, v);
     v8_dot4(acc, w1, v + 4);
@@ -96,9 +101,10 @@ __device__ __forceinline__ void v8_stats(const float (&v)[4], float& mean, float
 // One ResidualBlock of width 8 (UNetCF.py:83-95).  x (+ its row statistics) in, x out; UP: the input is cat(x, sk) and the shortcut a Linear.
 // P: the block's LDS record; tb: its slice of the current step's time-table row (b1 + Wt silu(temb) + bt); cp: this lane's four values of the
 // block's precomputed condition embedding Wc silu(cond) (null on an unconditional tile: silu(0) = 0, only the bias bc, which sits in c2).
-template <bool UP>
-__device__ __forceinline__ void v8_block(v8_lf* P, v8_lf* tb, const int h, float (&x)[4], float& xmean, float& xm2, const float (&sk)[4], float smean,
-                                         float sm2, const float* __restrict__ cp) {
+// sv: what the training forward keeps for the backward pass (h1, h2: the pre-LayerNorm tensors of stages 2 and 3); a no-op otherwise.
+template <bool UP, typename PF, typename Save>
+__device__ __forceinline__ void v8_block(PF P, PF tb, const int h, float (&x)[4], float& xmean, float& xm2, const float (&sk)[4], float smean,
+                                         float sm2, const float* __restrict__ cp, const Save& sv, const int blk) {
     using L = V8BlockL<UP>;
     constexpr int K1 = L::K1;
     float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -114,10 +120,10 @@ __device__ __forceinline__ void v8_block(v8_lf* P, v8_lf* tb, const int h, float
     __builtin_amdgcn_sched_barrier(0);      // the section is one long basic block of loads nothing stores to: without these fences hipcc
                                             // requests the weights of later stages early and spills what the current stage needs
     {
-        v8_lf* const W1 = P + L::W1 + 4 * h * K1;
+        const PF W1 = P + L::W1 + 4 * h * K1;
         const V8W wx = v8_wload<K1>(W1, 0);
         const float c = v8_rsq(m2 * (1.0f / K1) + kLnEps), d = -mean * c;
-        const v8f4 g = *(v8_lf4*)(P + L::G1 + 4 * h), b = *(v8_lf4*)(P + L::B1 + 4 * h), t = *(v8_lf4*)(tb + 4 * h);
+        const v8f4 g = v8_ld4(P + L::G1 + 4 * h), b = v8_ld4(P + L::B1 + 4 * h), t = v8_ld4(tb + 4 * h);
         const float a[4] = {v8_act(x[0], c, d, g[0], b[0]), v8_act(x[1], c, d, g[1], b[1]), v8_act(x[2], c, d, g[2], b[2]), v8_act(x[3], c, d, g[3], b[3])};
         float f[8];
         v8_gather(a, f);
@@ -126,23 +132,24 @@ __device__ __forceinline__ void v8_block(v8_lf* P, v8_lf* tb, const int h, float
         if (UP) ws = v8_wload<K1>(W1, 8);
         v8_dot8<K1>(h1, W1, 0, wx, f);
         if (UP) {
-            const v8f4 gs = *(v8_lf4*)(P + L::G1 + 8 + 4 * h), bs = *(v8_lf4*)(P + L::B1 + 8 + 4 * h);
+            const v8f4 gs = v8_ld4(P + L::G1 + 8 + 4 * h), bs = v8_ld4(P + L::B1 + 8 + 4 * h);
             const float as[4] = {v8_act(sk[0], c, d, gs[0], bs[0]), v8_act(sk[1], c, d, gs[1], bs[1]), v8_act(sk[2], c, d, gs[2], bs[2]),
                                  v8_act(sk[3], c, d, gs[3], bs[3])};
             v8_gather(as, f);
             v8_dot8<K1>(h1, W1, 8, ws, f);
         }
     }
+    sv.h1(blk, h1);
     // ---- stage 2: h2 = W2 silu(LN2(h1)) + [b2 + bc] + Wc silu(cond)
     float h2[4];
     __builtin_amdgcn_sched_barrier(0);
     {
-        v8_lf* const W2 = P + L::W2 + 4 * h * 8;
+        const PF W2 = P + L::W2 + 4 * h * 8;
         const V8W w = v8_wload<8>(W2, 0);
         float mu, q;
         v8_stats(h1, mu, q);
         const float c = v8_rsq(q * 0.125f + kLnEps), d = -mu * c;
-        const v8f4 g = *(v8_lf4*)(P + L::G2 + 4 * h), b = *(v8_lf4*)(P + L::B2 + 4 * h), c2 = *(v8_lf4*)(P + L::C2 + 4 * h);
+        const v8f4 g = v8_ld4(P + L::G2 + 4 * h), b = v8_ld4(P + L::B2 + 4 * h), c2 = v8_ld4(P + L::C2 + 4 * h);
         const float a[4] = {v8_act(h1[0], c, d, g[0], b[0]), v8_act(h1[1], c, d, g[1], b[1]), v8_act(h1[2], c, d, g[2], b[2]), v8_act(h1[3], c, d, g[3], b[3])};
         float f[8];
         v8_gather(a, f);
@@ -150,16 +157,17 @@ __device__ __forceinline__ void v8_block(v8_lf* P, v8_lf* tb, const int h, float
         v8_dot8<8>(h2, W2, 0, w, f);
         h2[0] += cv.x; h2[1] += cv.y; h2[2] += cv.z; h2[3] += cv.w;
     }
+    sv.h2(blk, h2);
     // ---- stage 3: out = W3 silu(LN3(h2)) + b3 + shortcut(cat(x, sk))
     float o[4];
     __builtin_amdgcn_sched_barrier(0);
     {
-        v8_lf* const W3 = P + L::W3 + 4 * h * 8;
+        const PF W3 = P + L::W3 + 4 * h * 8;
         const V8W w = v8_wload<8>(W3, 0);
         float mu, q;
         v8_stats(h2, mu, q);
         const float c = v8_rsq(q * 0.125f + kLnEps), d = -mu * c;
-        const v8f4 g = *(v8_lf4*)(P + L::G3 + 4 * h), b = *(v8_lf4*)(P + L::B3 + 4 * h), c3 = *(v8_lf4*)(P + L::C3 + 4 * h);
+        const v8f4 g = v8_ld4(P + L::G3 + 4 * h), b = v8_ld4(P + L::B3 + 4 * h), c3 = v8_ld4(P + L::C3 + 4 * h);
         const float a[4] = {v8_act(h2[0], c, d, g[0], b[0]), v8_act(h2[1], c, d, g[1], b[1]), v8_act(h2[2], c, d, g[2], b[2]), v8_act(h2[3], c, d, g[3], b[3])};
         float f[8];
         v8_gather(a, f);
@@ -168,7 +176,7 @@ __device__ __forceinline__ void v8_block(v8_lf* P, v8_lf* tb, const int h, float
         if (UP) sx = v8_wload<16>(P + L::WSC + 4 * h * 16, 0);
         v8_dot8<8>(o, W3, 0, w, f);
         if (UP) {                                           // Linear shortcut over the raw concat (c3 = b3 + b_shortcut)
-            v8_lf* const WS = P + L::WSC + 4 * h * 16;
+            const PF WS = P + L::WSC + 4 * h * 16;
             v8_gather(x, f);
             const V8W ss = v8_wload<16>(WS, 8);
             v8_dot8<16>(o, WS, 0, sx, f);
@@ -181,7 +189,15 @@ __device__ __forceinline__ void v8_block(v8_lf* P, v8_lf* tb, const int h, float
     __builtin_amdgcn_sched_barrier(0);
     v8_stats(o, xmean, xm2);
     x[0] = o[0]; x[1] = o[1]; x[2] = o[2]; x[3] = o[3];
+    sv.out(blk, x, xmean, xm2);
 }
+
+struct V8NoSave {                 // sampling: nothing of the section leaves the registers
+    __device__ __forceinline__ void h1(int, const float (&)[4]) const {}
+    __device__ __forceinline__ void h2(int, const float (&)[4]) const {}
+    __device__ __forceinline__ void out(int, const float (&)[4], float, float) const {}
+    __device__ __forceinline__ void lin_down(const float (&)[4], float, float) const {}
+};
 
 struct V8Sec {                    // what the section needs beyond its LDS image
     const float* cond_pre;        // condition embedding of the section's FIRST block, [tiles per pass][64][4]
@@ -192,9 +208,10 @@ struct V8Sec {                    // what the section needs beyond its LDS image
 // xin: this lane's eight values of the 16-wide tensor that enters the section (fragment groups 0 and 1); xout: the same of the 16-wide
 // tensor that leaves it, with its row statistics.  (Plain arrays, not the f32x16 of the matrix-core operators: with a partially read and
 // element-wise rewritten 16-register vector in the interface hipcc kept two whole tuples alive across the section and spilled both.)
-template <int NB>
-__device__ __forceinline__ void v8_section(v8_lf* S, v8_lf* tb0, const V8Sec& sc, const int tile, const int lane, const float (&xin)[8], float (&xout)[8],
-                                           float& xmean, float& xm2) {
+// sv.lin_down / sv.out(blk, ...): the Downsample output and block blk's output (blk counts the section's blocks from 0), for the backward pass.
+template <int NB, typename PF, typename Save>
+__device__ __forceinline__ void v8_section(PF S, PF tb0, const V8Sec& sc, const int tile, const int lane, const float (&xin)[8], float (&xout)[8],
+                                           float& xmean, float& xm2, const Save& sv) {
     using L = V8SecL<NB>;
     using BD = V8BlockL<false>;
     using BU = V8BlockL<true>;
@@ -208,40 +225,41 @@ __device__ __forceinline__ void v8_section(v8_lf* S, v8_lf* tb0, const V8Sec& sc
         float f0[8], f1[8];
         v8_gather(o0, f0);
         v8_gather(o1, f1);
-        const v8f4 b = *(v8_lf4*)(S + L::LIND_B + 4 * h);
+        const v8f4 b = v8_ld4(S + L::LIND_B + 4 * h);
         x[0] = b[0]; x[1] = b[1]; x[2] = b[2]; x[3] = b[3];
-        v8_lf* const W = S + L::LIND_W + 4 * h * 16;
+        const PF W = S + L::LIND_W + 4 * h * 16;
         v8_dot8<16>(x, W, 0, v8_wload<16>(W, 0), f0);
         v8_dot8<16>(x, W, 8, v8_wload<16>(W, 8), f1);
         v8_stats(x, mean, m2);
+        sv.lin_down(x, mean, m2);
     }
     const float none[4] = {0.f, 0.f, 0.f, 0.f};
     int blk = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         sk[b][0] = x[0]; sk[b][1] = x[1]; sk[b][2] = x[2]; sk[b][3] = x[3]; skm[b] = mean; skq[b] = m2;
-        v8_block<false>(S + L::DOWN + b * BD::SIZE, tb0 + blk * kV8TbStride, h, x, mean, m2, none, 0.f, 0.f, cp ? cp + blk * sc.cp_stride : nullptr);
+        v8_block<false>(S + L::DOWN + b * BD::SIZE, tb0 + blk * kV8TbStride, h, x, mean, m2, none, 0.f, 0.f, cp ? cp + blk * sc.cp_stride : nullptr, sv, blk);
         ++blk;
     }
     sk[NB][0] = x[0]; sk[NB][1] = x[1]; sk[NB][2] = x[2]; sk[NB][3] = x[3]; skm[NB] = mean; skq[NB] = m2;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        v8_block<false>(S + L::MID + b * BD::SIZE, tb0 + blk * kV8TbStride, h, x, mean, m2, none, 0.f, 0.f, cp ? cp + blk * sc.cp_stride : nullptr);
+        v8_block<false>(S + L::MID + b * BD::SIZE, tb0 + blk * kV8TbStride, h, x, mean, m2, none, 0.f, 0.f, cp ? cp + blk * sc.cp_stride : nullptr, sv, blk);
         ++blk;
     }
 #pragma unroll
     for (int b = 0; b <= NB; ++b) {
         v8_block<true>(S + L::UP + b * BU::SIZE, tb0 + blk * kV8TbStride, h, x, mean, m2, sk[NB - b], skm[NB - b], skq[NB - b],
-                       cp ? cp + blk * sc.cp_stride : nullptr);
+                       cp ? cp + blk * sc.cp_stride : nullptr, sv, blk);
         ++blk;
     }
     {   // Upsample 8 -> 16: this lane's output features are 4h .. 4h+3 (group 0) and 8 + 4h .. 8 + 4h+3 (group 1)
         float f[8];
         v8_gather(x, f);
-        const v8f4 b0 = *(v8_lf4*)(S + L::LINU_B + 4 * h), b1 = *(v8_lf4*)(S + L::LINU_B + 8 + 4 * h);
+        const v8f4 b0 = v8_ld4(S + L::LINU_B + 4 * h), b1 = v8_ld4(S + L::LINU_B + 8 + 4 * h);
         float y0[4] = {b0[0], b0[1], b0[2], b0[3]}, y1[4] = {b1[0], b1[1], b1[2], b1[3]};
-        v8_lf* const W0 = S + L::LINU_W + 4 * h * 8;
-        v8_lf* const W1 = S + L::LINU_W + (8 + 4 * h) * 8;
+        const PF W0 = S + L::LINU_W + 4 * h * 8;
+        const PF W1 = S + L::LINU_W + (8 + 4 * h) * 8;
         v8_dot8<8>(y0, W0, 0, v8_wload<8>(W0, 0), f);
         v8_dot8<8>(y1, W1, 0, v8_wload<8>(W1, 0), f);
         // row statistics over 16 features, summed in fragment order as the matrix-core kernels do (linear_reg_h)

@@ -1125,8 +1125,31 @@ __device__ __forceinline__ void linear_reg_out_h(const LinArgsH& ah, const int t
                 make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
 }
 
-template <bool PRE>
-__global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles) {
+// What the training forward keeps of the float32 section for the backward pass: every operator's output with its row statistics and the
+// blocks' pre-LayerNorm tensors, at the places the matrix-core forms write them (8-wide fragment tensors: one float4 per lane).
+struct V8TableSave {
+    const FusedOpH* ops;          // the section's first operator (the Downsample Linear); block blk is ops[1 + blk]
+    int tile, lane;
+    bool on;
+    __device__ __forceinline__ void put(float* dst, const float (&v)[4]) const { st4(dst + (size_t)tile * 256 + lane * 4, make_float4(v[0], v[1], v[2], v[3])); }
+    __device__ __forceinline__ void stats(float* dst, float mean, float m2) const {
+        if (lane < 32) reinterpret_cast<float2*>(dst)[(size_t)tile * 32 + lane] = make_float2(mean, m2);
+    }
+    __device__ __forceinline__ void h1(int blk, const float (&v)[4]) const { if (on && ops[1 + blk].b.b.save_h1) put(ops[1 + blk].b.b.save_h1, v); }
+    __device__ __forceinline__ void h2(int blk, const float (&v)[4]) const { if (on && ops[1 + blk].b.b.save_h2) put(ops[1 + blk].b.b.save_h2, v); }
+    __device__ __forceinline__ void out(int blk, const float (&v)[4], float mean, float m2) const {
+        if (on) { put(ops[1 + blk].b.b.out, v); stats(ops[1 + blk].b.b.out_stats, mean, m2); }
+    }
+    __device__ __forceinline__ void lin_down(const float (&v)[4], float mean, float m2) const {
+        if (on) { put(ops[0].l.l.out, v); stats(ops[0].l.l.out_stats, mean, m2); }
+    }
+};
+
+// V8NB > 0: operators [v8_at, v8_at + v8_nops) of the run are the 8-wide bottom of the net (n_blocks = V8NB) and run on the vector unit in
+// float32 from the global image `v8_img` (dsg_narrow8.hpp); v8_store: the training forward (every tensor of the section is stored).
+template <bool PRE, int V8NB>
+__global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles, int v8_at, int v8_nops,
+                                                                     const float* __restrict__ v8_img, int v8_store) {
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (tile >= ntiles) return;
@@ -1135,10 +1158,59 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
     bool have_x = false;
     int entry = -1;                   // time-table entry of this wave's rows: read once, by the first block of the run
     const int lane_id = lane;
-    for (int i = 0; i < nops; ++i) {
+    int i = 0;
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+    const int stop = (V8NB > 0 && part == 0 && v8_at >= 0) ? v8_at : nops;
+    if (V8NB > 0 && part == 1 && v8_at >= 0) {
+        // the float32 section, between the two runs of the operator loop (as in k_fused_narrow_lds)
+        int lane = lane_id;
+        if (!PRE || V8NB > 0) asm volatile("" : "+v"(lane));
+        const int h = lane >> 5, j = lane & 31;
+        const LinArgs& la = ops[i].l.l;
+        const BlockArgs& b0 = ops[i + 1].b.b;
+        const BlockArgs& b1 = ops[i + 2].b.b;
+        if (!have_x) {                               // the section opens the run: its 16-wide input comes from memory
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (G < 2) v = ld4(la.in.data + ((size_t)seg_tile(la.in, tile) * 2 + G) * 256 + lane * 4);
+                x[0][4 * G] = v.x; x[0][4 * G + 1] = v.y; x[0][4 * G + 2] = v.z; x[0][4 * G + 3] = v.w;
+            }
+            have_x = true;
+        }
+        if (entry < 0) {
+            entry = 0;
+            if (b0.ts) {
+                int row = (tile % b0.tiles_per_pass) * 32 + j;
+                row = row < b0.nrows ? row : b0.nrows - 1;
+                entry = b0.ts[row];
+            } else if (b0.step_ptr) {
+                entry = *b0.step_ptr;
+            }
+        }
+        const V8Sec sc{b0.cond_pre, (long long)(b1.cond_pre - b0.cond_pre), b0.tiles_per_pass, b0.uncond_tiles};
+        const float* const tb0 = b0.tbias + (size_t)entry * b0.tb_stride;      // this lane's row of the time table, the first block's slice
+        const float xi[8] = {x[0][0], x[0][1], x[0][2], x[0][3], x[0][4], x[0][5], x[0][6], x[0][7]};
+        float xo[8];
+        const V8TableSave sv{ops + i, tile, lane, v8_store != 0};
+        v8_section<(V8NB > 0 ? V8NB : 2)>(v8_img, tb0, sc, tile, lane, xi, xo, xmean, xm2, sv);
+        x[0] = f32x16{xo[0], xo[1], xo[2], xo[3], xo[4], xo[5], xo[6], xo[7], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const FusedOpH& lz = ops[i + v8_nops - 1];
+        if (lz.store_out) {                          // the Upsample output is read from memory by somebody (training: the backward pass)
+            const LinArgs& a = lz.l.l;
+            if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
+#pragma unroll
+            for (int G = 0; G < 2; ++G)
+                st4(a.out + ((size_t)tile * 2 + G) * 256 + lane * 4, make_float4(x[0][4 * G], x[0][4 * G + 1], x[0][4 * G + 2], x[0][4 * G + 3]));
+        }
+        i += v8_nops;
+    }
+#pragma unroll 1
+    for (; i < stop; ++i) {
         // opaque per operator (see k_fused_narrow_lds): keeps the lane-derived indices of every operator body inside its body
         int lane = lane_id;
-        if (!PRE) asm volatile("" : "+v"(lane));
+        if (!PRE || V8NB > 0) asm volatile("" : "+v"(lane));
         const int h = lane >> 5, j = lane & 31;
         const FusedOpH& op = ops[i];
         if (entry < 0 && op.kind == 0) {
@@ -1168,17 +1240,18 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
             // skip tensors were stored by this wave earlier in the run: make sure those stores have landed
             if (op.b.b.in1.groups) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const bool st = op.store_out != 0;
+            const int N = (V8NB > 0 && op.N < 16) ? 16 : op.N;     // with the float32 section every 8-wide block is inside it
             if (op.sclin) {
-                switch (op.N) {
-                    case 4: resblock_body_h<4, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
-                    case 8: resblock_body_h<8, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                switch (N) {
+                    case 4: if (V8NB == 0) resblock_body_h<4, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                     case 16: resblock_body_h<16, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                     default: resblock_body_h<32, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                 }
             } else {
-                switch (op.N) {
-                    case 4: resblock_body_h<4, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
-                    case 8: resblock_body_h<8, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                switch (N) {
+                    case 4: if (V8NB == 0) resblock_body_h<4, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                     case 16: resblock_body_h<16, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                     default: resblock_body_h<32, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                 }
@@ -1201,6 +1274,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
         } else {
             linear_reg_h(op.l, tile, lane, x, xmean, xm2, op.store_out != 0);
         }
+    }
     }
 }
 
@@ -1302,7 +1376,7 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             v8_lf* const tb0 = (v8_lf*)(ldsf + ph.v8_tb);
             const float xi[8] = {x[0][0], x[0][1], x[0][2], x[0][3], x[0][4], x[0][5], x[0][6], x[0][7]};
             float xo[8];
-            v8_section<(V8NB > 0 ? V8NB : 2)>(S, tb0, sc, tile, lane, xi, xo, xmean, xm2);
+            v8_section<(V8NB > 0 ? V8NB : 2)>(S, tb0, sc, tile, lane, xi, xo, xmean, xm2, V8NoSave{});
             x[0] = f32x16{xo[0], xo[1], xo[2], xo[3], xo[4], xo[5], xo[6], xo[7], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (ph.v8_store) {                       // the section ends the phase: hand the 16-wide tensor on through memory
                 const LinArgs& lz = ops[i + ph.v8_nops - 1].l.l;

@@ -183,7 +183,8 @@ SAMPLING_STEP_KERNELS = [
 ]
 OTHER_HOT_KERNELS = [
     "dsg::k_res64_lds<false, 2>", "dsg::k_res64_lds<false, 1>", "dsg::k_res64_lds<true, 2>", "dsg::k_res64_lds<false, 0>",
-    "dsg::k_fused_narrow_h<true>", "dsg::k_fused_narrow_h<false>",
+    "dsg::k_fused_narrow_h<true, 0>", "dsg::k_fused_narrow_h<false, 0>", "dsg::k_fused_narrow_h<true, 2>", "dsg::k_fused_narrow_h<false, 2>",
+    "dsg::k_fused_narrow_h<true, 3>", "dsg::k_fused_narrow_h<false, 3>",
     "dsg::k_wgrad_h", "dsg::k_fused_narrow_bwd_h", "dsg::k_resblock_bwd_c<128, true>", "dsg::k_resblock_bwd_c<128, false>",
     "dsg::k_resblock_bwd_c<64, true>", "dsg::k_resblock_bwd_c<64, false>", "dsg::k_wide128_h<true, 0, 1>", "dsg::k_wide128_h<false, 0, 1>",
     "dsg::k_resblock_h<64, true>", "dsg::k_resblock_h<64, false>", "dsg::k_cond_embed_h", "dsg::k_colsum",

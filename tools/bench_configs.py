@@ -21,6 +21,8 @@ for name, B, T, omega in (("msr3", 8192, 1000, 1.0), ("msr3", 512, 20, 500.0), (
     d.apply(init_weights)
     d.to(dev)
     cond = torch.rand(B, cfg["cond_dim"], device=dev)
+    if os.environ.get("DSG_OPT_V8") is not None:         # A/B of the float32 8-wide section: DSG_OPT_V8=0 / 1
+        d.model.set_option("narrow_valu8", int(os.environ["DSG_OPT_V8"]))
     d.sample(cond, omega, seed=1)
     torch.cuda.synchronize()
     dt = 1e9
@@ -32,5 +34,6 @@ for name, B, T, omega in (("msr3", 8192, 1000, 1.0), ("msr3", 512, 20, 500.0), (
     out.append(dict(config=name, B=B, T=T, omega=omega, ms_per_call=dt * 1e3, steps_per_s=T / dt, row_steps_per_s=B * T / dt,
                     finite=bool(torch.isfinite(y).all())))
     print(json.dumps(out[-1]), file=sys.stderr)      # progress, one JSON object per line
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
 print(json.dumps(out))                               # stdout: ONE valid JSON document
