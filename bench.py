@@ -124,6 +124,29 @@ def _cpu_baseline_run(nthreads, sample_rows, steps, B_ref):
             "row_steps_per_s": row_steps}
 
 
+def config2_leg(dev):
+    """BASELINE.json config 2: MSR 3-cell reverse sampling, T = 1000, batch 8192, one GPU -- one timed DDPM.sample call after one
+    untimed call (tables, graphs), same arithmetic as the headline."""
+    from weights import CONFIGS
+    from diffsg_amd import UNet1D, generate_cosine_schedule, init_weights
+    from diffsg_amd.classifier_free_MSR import DDPM
+    cfg, T, B = CONFIGS["msr3"], 1000, 8192
+    torch.manual_seed(0)
+    m = UNet1D(**cfg, is_attn=(False,) * len(cfg["dims"]))
+    d = DDPM(T, m, cfg["input_dim"], 10.0, 1.0 - generate_cosine_schedule(T), dev, (1, cfg["input_dim"]), None)
+    d.apply(init_weights)
+    d.to(dev)
+    cond = torch.rand(B, cfg["cond_dim"], device=dev)
+    d.sample(cond, 1.0, seed=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    y = d.sample(cond, 1.0, seed=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "MSR-3c CFG reverse sampling, batch 8192 x D=C=3, T=1000, omega=1 (BASELINE config 2)", "value": T / dt, "unit": "steps/s",
+            "ms_per_step": dt / T * 1e3, "row_steps_per_s": B * T / dt, "finite": bool(torch.isfinite(y).all())}
+
+
 def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
     """MSR-80c training throughput (BASELINE config 5 shape): per GPU `B` rows, T=20, Adam(lr 5e-3); one step =
     DDPM.forward (q_sample + denoiser forward + backward in libdiffsg_hip) + ONE all-reduce of the flat 6.6 MB gradient
@@ -131,6 +154,10 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
     ddpm = build_model(dev, 20)
     from diffsg_amd.train import FlatAdam
     opt = FlatAdam(ddpm, lr=0.005)
+    # every rank draws its own ts / noise / mask: device-side Philox draws inside the fused step, the rank folded into the key
+    # (DDPM.device_draws; distributions checked against MSR.py:101-107 by tests/test_gpu_parity.py).  build_model() seeds torch's
+    # generator identically in every process: draws from it would repeat across ranks.
+    ddpm.device_draws = 1000 + rank
     g = torch.Generator().manual_seed(100 + rank)
     cond = torch.rand(B, 80, generator=g).to(dev)
     y = (torch.rand(B, 80, generator=g) * (20.0 / 80)).to(dev)
@@ -208,7 +235,7 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
         roof["achieved"] = per_row * B / (wg * 1e-3) / 1e9
         roof["frac"] = roof["achieved"] / PEAK_HBM_GBS
     return {"roofline": roof, "samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": B, "global_batch": world * B,
-            "steps": steps, "T": 20, "final_loss": float(loss.detach()), "achieved_tflops": sps / world * f_train / 1e12,
+            "steps": steps, "T": 20, "final_loss": float(loss.detach()), "draws": "device Philox per rank (dsg_train_step_seeded, seed 1000 + rank)", "achieved_tflops": sps / world * f_train / 1e12,
             "frac_f32_mfma": sps / world * f_train / 1e12 / PEAK_F32_TFLOPS, "grad_bucket_bytes": int(ddpm.grad_bucket.numel()) * 4,
             "collective": ("none (1 GPU)" if world == 1 else
                            "one all_reduce(AVG) per step over the flat bucket (RCCL)" if dist.get_backend() == "nccl" else
@@ -231,6 +258,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-f32-exact", action="store_true", help="skip the exact-float32 re-run of the same K steps")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE config-2 sub-record (MSR-3c, 8192 rows, T = 1000)")
     ap.add_argument("--warm-seconds", type=float, default=0.3, help="untimed clock warm-up before the timed steps")
     a = ap.parse_args()
 
@@ -316,8 +344,11 @@ def main():
 
     if rank == 0:
         # roofline of the dominant kernel: eager re-run of the same K steps with HIP events around every launch
+        torch.cuda.synchronize()
+        te = time.perf_counter()
         ddpm_k.sample(cond, a.omega, seed=2, profile=True)
         torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - te) / K * 1e3
         prof = ddpm_k.op_profile()
         # operators that ran inside the previous operator's launch (fused narrow run, block + Linear pairs) read only the
         # empty event pair (~5 us; the smallest real launch is ~14 us): fold their algorithmic work into the launch that did it
@@ -341,11 +372,12 @@ def main():
         mfma_x = 3.0 if split else 1.0                  # executed MFMA FLOP per algorithmic FLOP
         unit_peak = PEAK_F16_TFLOPS if split else PEAK_F32_TFLOPS
         step_ms = dt / K * 1e3
-        traffic = valu_per_mfma = tsrc = None
+        traffic = valu_per_mfma = tsrc = step_bytes = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic, valu_per_mfma = tj.get("hbm_bytes_per_launch"), tj.get("valu_per_mfma")
+            step_bytes = (tj.get("step_traffic") or {}).get("bytes_per_step")
             tsrc = "imported, not measured in this run: profiles/traffic.json <- " + tj.get("summary", "profiles/") + " (kernel " + tj.get("kernel", "?") + ")"
         large = 2 * ((B + 31) // 32) > 512
         panel = 2 * ((B + 31) // 32) >= 2048
@@ -374,14 +406,24 @@ def main():
                               "frac_mfma_unit": mfma_x * F_ALG * B / (step_ms * 1e-3) / 1e12 / unit_peak,
                               "frac_f32_equiv": F_ALG * B / (step_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                               "achieved_gbs_alg": BYT_ALG * B / (step_ms * 1e-3) / 1e9,
-                              "frac_hbm": BYT_ALG * B / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
-            "op_ms_per_step": {r[0]: r[3] / K for r in prof},
+                              "frac_hbm": BYT_ALG * B / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                              # the binding memory-side quantity: fabric traffic of the step's large kernels from the committed PMC summary
+                              # (imported like roofline.traffic; Infinity-Cache hits included), against the timed step of THIS run
+                              "traffic_bytes": step_bytes, "traffic_source": tsrc,
+                              "traffic_gbs": (step_bytes / (step_ms * 1e-3) / 1e9) if step_bytes else None,
+                              "frac_hbm_traffic": (step_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if step_bytes else None},
+            # per-operator HIP-event times of a separate EAGER run of the same K steps: an event pair adds a few microseconds to every
+            # launch and the launches do not overlap their tails as they do inside the replayed graph, so these sum ABOVE ms_per_step;
+            # `eager_profile_ms_per_step` is that run's own wall time per step (upper bounds, for ratios between operators)
+            "op_ms_per_step": {r[0]: r[3] / K for r in prof}, "eager_profile_ms_per_step": eager_ms,
             "ranks_seen": ev["ranks_seen"], "per_rank_steps_per_s": ev["per_rank_steps_per_s"],
         }
         if f32_exact is not None:
             out["f32_exact"] = f32_exact
         if train is not None:
             out["train"] = train
+        if world == 1 and not a.no_other_configs:
+            out["config2"] = config2_leg(dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

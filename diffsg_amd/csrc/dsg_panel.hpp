@@ -156,22 +156,9 @@ __device__ __forceinline__ void panel_wfrag(HFrag<NT>& w, const uint4* panel /* 
 // across the whole tile loop and spilled them)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
-// lo part of the split: v - float(half of `hi`), one v_fma_mix_f32 (f32 * 1.0 - f16): hipcc picks cvt + sub (two instructions) in
-// this context.  Not volatile: an ordinary instruction for the scheduler.
-__device__ __forceinline__ float sub_half_lo(float v, unsigned hi) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ float sub_half_hi(float v, unsigned hi) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hi));
-    return r;
-}
-
-// ASM_SPLIT: the hi/lo split exactly as panel_pipe_s does it (the lo part from the ROUNDED product through v_fma_mix; in the plain form
-// hipcc contracts `u * r - hi` into one fma, which moves the last bit of lo): a tile whose first panel is prepared here on one
-// occasion and inside panel_pipe_s on another must get the same bits (rows do not depend on their position in the batch)
+// (ASM_SPLIT is kept for the call sites of round 3: since round 4 every form splits through split_pair (dsg_split.hpp), whose inline-asm
+// operands are rounded float32 values, so a tile whose first operand is prepared here on one occasion and inside panel_pipe_s on
+// another gets the same bits either way.)
 template <bool LNACT, bool ASM_SPLIT = false>
 __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamma, const float* beta, int S, float c, float d, int h) {
     float v[8];
@@ -203,21 +190,7 @@ __device__ __forceinline__ BOp panel_prep(const float (&x)[8], const float* gamm
         for (int q = 0; q < 8; ++q) v[q] = x[q] * kRawScale;
     }
     BOp o;
-    if (ASM_SPLIT) {
-        unsigned hh[4], ll[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v0 = v[2 * q], v1 = v[2 * q + 1];
-            asm volatile("" : "+v"(v0), "+v"(v1));          // the rounded products, as values
-            const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
-            hh[q] = a;
-            ll[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(sub_half_lo(v0, a), sub_half_hi(v1, a)));
-        }
-        const uint4 uh = {hh[0], hh[1], hh[2], hh[3]}, ul = {ll[0], ll[1], ll[2], ll[3]};
-        o.hi = __builtin_bit_cast(h8, uh); o.lo = __builtin_bit_cast(h8, ul);
-        return o;
-    }
-    split8(v, o.hi, o.lo);
+    split8(v, o.hi, o.lo);      // (split_pair: the same three instructions per pair panel_pipe_s issues -- ASM_SPLIT is historical)
     return o;
 }
 
@@ -354,8 +327,8 @@ __device__ __forceinline__ void panel_pipe_s(f32x16 (&acc)[4], const uint4* pn /
                 v1 = u1 * __builtin_amdgcn_rcpf(fmaf(p1, kk, kk));
             } else { v0 = u0; v1 = u1; }
         } else {
-            const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
-            const unsigned er = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(sub_half_lo(v0, a), sub_half_hi(v1, a)));
+            unsigned a, er;
+            split_pair(v0, v1, a, er);
             hq[m] = __builtin_bit_cast(float, a); lq[m] = __builtin_bit_cast(float, er);
         }
     }

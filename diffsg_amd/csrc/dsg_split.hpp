@@ -56,16 +56,36 @@ __device__ __forceinline__ void load_hfrag(HFrag<NT>& w, const uint4* __restrict
     for (int nt = 0; nt < NT; ++nt) { w.hi[nt] = wp[nt * nt_stride]; w.lo[nt] = wp[nt * nt_stride + 64]; }
 }
 
-// 8 float32 values (already multiplied by the activation scale) -> hi / lo half vectors (round toward zero: the
-// residual is then exactly representable and hi + lo carries 22 bits)
+// Two float32 values -> their packed hi halves (fp16, round toward zero) and packed lo halves fp16(v - hi): THREE instructions.
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 take the float32 value and the half it was rounded to (a source operand read as fp16), subtract in
+// float32 and write the fp16 result straight into the low / high half of the destination.  Until round 4 the lo pair was
+// "convert hi back (2), subtract (2), pack (1)" in the compiler-scheduled kernels and "v_fma_mix_f32 (2), pack (1)" in the panel kernel:
+// 6 and 4 vector instructions per pair -- on kernels that sit at ~80 % of the vector issue port inside their MFMA loops.
+// The remainder v - hi has at most 13 significant bits, two more than fp16 holds: it is rounded to nearest even here (the
+// pack instruction truncated), so hi + lo is the 22-bit operand as before, half a unit of its last place closer to v on average.
+// Inline asm operands are values: a product feeding the split is rounded to float32 first in EVERY kernel form (hipcc cannot contract it
+// into the subtraction), so a row's bits do not depend on the form that computes it.
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+    // ONE statement, closed by a wait state: v_fma_mixhi_f16 writes half a register, and on gfx940+ a vector instruction that reads a
+    // register the instruction just before it wrote in part (dst_sel / op_sel destination) gets the old contents ("dst_sel forwarding"
+    // hazard).  hipcc pads that for instructions it emits itself, not for inline asm: without the s_nop the narrow kernels, where
+    // the consumer sometimes follows directly, returned rows off by 1e-3 (tools/dbg_split.py; the panel kernel, whose split
+    // pieces sit between MFMAs, never showed it).
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(l) : "v"(v0), "v"(v1), "v"(hi));
+    lo = l;
+}
+// 8 float32 values (already multiplied by the activation scale) -> hi / lo half vectors; hi + lo carries 22 bits
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+    unsigned hh[4], ll[4];
 #pragma unroll
-    for (int p = 0; p < 8; p += 2) {
-        const hp2 a = __builtin_amdgcn_cvt_pkrtz(v[p], v[p + 1]);
-        const hp2 b = __builtin_amdgcn_cvt_pkrtz(v[p] - (float)a[0], v[p + 1] - (float)a[1]);
-        hi[p] = (_Float16)a[0]; hi[p + 1] = (_Float16)a[1];
-        lo[p] = (_Float16)b[0]; lo[p + 1] = (_Float16)b[1];
-    }
+    for (int q = 0; q < 4; ++q) split_pair(v[2 * q], v[2 * q + 1], hh[q], ll[q]);
+    const uint4 uh = {hh[0], hh[1], hh[2], hh[3]}, ul = {ll[0], ll[1], ll[2], ll[3]};
+    hi = __builtin_bit_cast(h8, uh); lo = __builtin_bit_cast(h8, ul);
 }
 
 template <int NT>

@@ -30,12 +30,10 @@ __device__ __forceinline__ int wgrad_gexp(unsigned maxbits) {
 // planes.  Neighbouring lanes (rows r, r^1) first trade half of their data, so that every 32-bit word of a plane (two
 // consecutive rows of one feature) is written whole by ONE lane: even rows store features f0, f0+1, odd rows f0+2, f0+3.
 __device__ __forceinline__ void wsplit_store(_Float16* hi, _Float16* lo, int P, int f0, int r, const float4 v) {
-    const hp2 a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-    const hp2 b01 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)a01[0], v.y - (float)a01[1]);
-    const hp2 b23 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)a23[0], v.w - (float)a23[1]);
+    unsigned h01, h23, l01, l23;
+    split_pair(v.x, v.y, h01, l01);
+    split_pair(v.z, v.w, h23, l23);
     const bool odd = r & 1;
-    const unsigned h01 = __builtin_bit_cast(unsigned, a01), h23 = __builtin_bit_cast(unsigned, a23);
-    const unsigned l01 = __builtin_bit_cast(unsigned, b01), l23 = __builtin_bit_cast(unsigned, b23);
     // what the neighbour needs from me: an even row keeps (f0, f0+1) and gives away (f0+2, f0+3); an odd row the reverse
     const unsigned hs = odd ? h01 : h23, ls = odd ? l01 : l23;
     const unsigned hr = (unsigned)__builtin_amdgcn_mov_dpp((int)hs, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]: lane ^ 1

@@ -400,6 +400,35 @@ def test_default_sample_never_returns_saturated_results():
     assert torch.equal(ch, ch32)
 
 
+@pytest.mark.parametrize("policy", [None, (0, 0), (1 << 20, 1 << 20), (1 << 20, 0), (0, 1 << 20)])
+@pytest.mark.parametrize("v8", [1, 0])
+def test_every_narrow_run_form_vs_oracle(policy, v8):
+    """The narrow run has six forms: {small-launch, large-launch, LDS-resident} x {8-wide bottom of the net on the vector unit in
+    float32 (dsg_narrow8.hpp), or on the matrix cores like the rest}.  The goldens run the default (float32 section on) under two
+    launch policies; this test crosses all thresholds with both settings on a ragged 1 100-row batch against the CPU oracle -- the
+    case that caught the dst_sel forwarding hazard behind an inline-asm v_fma_mixhi_f16 in round 4 (rows off by 1e-3 in the forms
+    the goldens did not reach)."""
+    name, B, T, omega = "msr80", 1100, 4, 2.0
+    plan, p = synth_params(name, 5, "trained")
+    cfg = CONFIGS[name]
+    ddpm = make_ddpm(name, p, T)
+    if policy is not None:
+        ddpm.model.set_launch_policy(*policy)
+    ddpm.model.set_option("narrow_valu8", v8)
+    g = torch.Generator().manual_seed(9)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g)
+    y_T = torch.randn(B, cfg["input_dim"], generator=g)
+    z = torch.randn(T - 2, B, cfg["input_dim"], generator=g)
+    y0 = ddpm.sample(cond.cuda(), omega, y_T=y_T, noise=z)
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    zd = {i: z[j] for j, i in enumerate(range(T - 1, 1, -1))}
+    with torch.no_grad():
+        ref = O.ddpm_sample(p, plan, bufs, T, cond, omega, y_T, zd)
+    e = rel(y0, ref)
+    print(f"policy {policy} narrow_valu8={v8}: rel err vs oracle {e:.2e}")
+    assert e <= TOL
+
+
 def test_repacked_weights_reach_the_lds_image_of_the_narrow_run():
     """the LDS-resident narrow run (k_fused_narrow_lds) reads a gathered COPY of the packed planes.  After an
     in-place weight change (optimizer step, load_state_dict, EMA swap) dsg_bind_weights re-packs the arena; the copy must follow,

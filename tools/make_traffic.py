@@ -26,5 +26,25 @@ d = {"kernel": pat, "summary": cite,
      "vmem_rd_per_wave": vals.get("SQ_INSTS_VMEM_RD", 0) / vals["SQ_WAVES"] if "SQ_WAVES" in vals else None,
      "wait_any_share": vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in vals else None,
      "wait_inst_share": vals["SQ_WAIT_INST_ANY"] / vals["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in vals else None}
+# whole step: sum over the sections of the summary, each times its launches per reverse step ("name=count" arguments after the citation)
+step = {}
+if len(sys.argv) > 5:
+    want = dict(a.rsplit("=", 1) for a in sys.argv[5:])
+    sec, per = None, {}
+    for line in open(src):
+        if line.startswith("== "):
+            sec = line[3:].strip(); continue
+        m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+mean=(\S+)", line)
+        if sec in want and m:
+            per.setdefault(sec, {})[m.group(1)] = float(m.group(3))
+    total, parts = 0.0, {}
+    for k, cnt in want.items():
+        if k in per and "FETCH_SIZE" in per[k] and "WRITE_SIZE" in per[k]:
+            b = (2 * per[k]["FETCH_SIZE"] + per[k]["WRITE_SIZE"]) * 1024 * int(cnt)
+            parts[k] = int(b); total += b
+    step = {"bytes_per_step": int(total), "per_kernel_bytes": parts, "missing": [k for k in want if k not in parts],
+            "note": "sum of (2 x FETCH_SIZE + WRITE_SIZE) per dispatch x launches per reverse step over the step's large kernels; fabric-side "
+                    "traffic (Infinity-Cache hits included), an upper bound of the HBM bytes"}
+d["step_traffic"] = step
 json.dump(d, open(out, "w"), indent=1)
 print(json.dumps(d))
