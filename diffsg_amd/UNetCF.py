@@ -197,10 +197,19 @@ class UNet1D(nn.Module):
         self._native = _Native()
 
     # ------------------------------------------------------------------ native plumbing
-    def native_handle(self):
-        """Create (once) the dsg handle and (re)bind the current parameter tensors; returns the raw handle."""
+    def native_handle(self, twin=0):
+        """Create (once) the dsg handle and (re)bind the current parameter tensors; returns the raw handle.
+        twin > 0: a further handle of the SAME module (own workspace, own packed copy of the same weights): DDPM.forward runs the two
+        halves of a very large training batch on two handles and two streams at once (ddpm.py, `train_split_min_rows`)."""
         L = _lib.lib()
-        nat = self._native
+        if twin:
+            twins = self.__dict__.setdefault("_twins", {})
+            nat = twins.get(twin)
+            if nat is None:
+                nat = twins[twin] = _Native()
+                nat.epoch = self._native.epoch
+        else:
+            nat = self._native
         params = self._named_param_list()
         if not params[0][1].is_cuda:
             raise RuntimeError("UNet1D: parameters are not on a HIP device; libdiffsg_hip has no CPU path "
@@ -217,6 +226,14 @@ class UNet1D(nn.Module):
             if not hd:
                 raise RuntimeError("libdiffsg_hip: " + L.dsg_last_error().decode())
             nat.handle = hd
+            if twin:                       # a twin starts with the settings the primary handle was given
+                st = self.__dict__.get("_settings", {})
+                if "precision" in st:
+                    _lib.check(L.dsg_set_precision(hd, st["precision"]))
+                if "policy" in st:
+                    _lib.check(L.dsg_set_launch_policy(hd, *st["policy"]))
+                for code, val in st.get("options", {}).items():
+                    _lib.check(L.dsg_set_option(hd, code, val))
             n = L.dsg_param_count(hd)
             names = [L.dsg_param_name(hd, i).decode() for i in range(n)]
             if names != [k for k, _ in params]:
@@ -224,6 +241,8 @@ class UNet1D(nn.Module):
             for i, (k, v) in enumerate(params):
                 if v.numel() != L.dsg_param_numel(hd, i):
                     raise RuntimeError(f"size mismatch for {k}")
+        if twin:
+            nat.storage_keys = self._native.storage_keys        # so that an optimizer step reaches the twin's epoch too
         key = (nat.epoch,) + tuple((v.data_ptr(), v._version) for _, v in params)
         if key != nat.bound_key:
             for k, v in params:
@@ -259,6 +278,8 @@ class UNet1D(nn.Module):
         """Parameters were updated in place through an aliasing tensor (train.FlatAdam): re-pack on the next call.
         rebuild=True also drops the cached parameter list (new Parameter objects were assigned into sub-modules)."""
         self._native.epoch += 1
+        for nat in self.__dict__.get("_twins", {}).values():
+            nat.epoch += 1
         if rebuild:
             self._native.named_params = None
 
@@ -266,8 +287,10 @@ class UNet1D(nn.Module):
         """Arithmetic of the >= 64-wide blocks inside DDPM.sample: "split_f16" (default; float32-accurate hi/lo fp16
         split on the f16 matrix cores, f32 accumulate) or "f32" (exact v_mfma_f32_32x32x2_f32)."""
         code = {"split_f16": 0, "f32": 1}[mode]
-        _lib.check(_lib.lib().dsg_set_precision(self.native_handle(), code))
+        for hd in self._all_handles():
+            _lib.check(_lib.lib().dsg_set_precision(hd, code))
         self._native.precision = mode
+        self.__dict__.setdefault("_settings", {})["precision"] = code
 
     @property
     def precision(self):
@@ -291,13 +314,21 @@ class UNet1D(nn.Module):
         """Kernel forms by launch size (dsg_set_launch_policy): launches of at most `coop_max_tiles` 32-row tiles run
         the wide blocks cooperatively, at most `narrow_small_max_tiles` the small-launch narrow run; -1 = default,
         0 = always the large-launch forms (what a 65 536-row call uses)."""
-        _lib.check(_lib.lib().dsg_set_launch_policy(self.native_handle(), int(coop_max_tiles), int(narrow_small_max_tiles)))
+        for hd in self._all_handles():
+            _lib.check(_lib.lib().dsg_set_launch_policy(hd, int(coop_max_tiles), int(narrow_small_max_tiles)))
+        self.__dict__.setdefault("_settings", {})["policy"] = (int(coop_max_tiles), int(narrow_small_max_tiles))
 
     def set_option(self, name, value):
         """Per-handle kernel-form switches (dsg_set_option): "narrow_valu8" -- the 8-wide bottom of the net on the vector
         unit in float32 inside large sampling launches (default on)."""
         code = {"narrow_valu8": 1}[name]
-        _lib.check(_lib.lib().dsg_set_option(self.native_handle(), code, int(value)))
+        for hd in self._all_handles():
+            _lib.check(_lib.lib().dsg_set_option(hd, code, int(value)))
+        self.__dict__.setdefault("_settings", {}).setdefault("options", {})[code] = int(value)
+
+    def _all_handles(self):
+        """The primary handle and every twin that exists (per-handle settings apply to all of them)."""
+        return [self.native_handle()] + [self.native_handle(k) for k in self.__dict__.get("_twins", {})]
 
     def forward(self, x, t, cond, cond_mask):
         """

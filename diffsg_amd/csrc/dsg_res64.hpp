@@ -349,11 +349,15 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
         // ---- statistics + store
         float xmean, xm2;
         acc_stats<N, NT>(acc3, h, xmean, xm2);
+        // (the lane index as an opaque value at the two store sites: hipcc otherwise forms the per-lane 64-bit output addresses in the
+        // prologue, keeps them live across the whole tile loop and spills them in the 256-register variants)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
         if (live && (NTO == 0 || A.store_block_out)) {
-            if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
+            if (lane_o < 32) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + lane_o] = make_float2(xmean, xm2);
 #pragma unroll
             for (int G = 0; G < NG; ++G)
-                st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                st4(a.out + ((size_t)tile * NG + G) * 256 + lane_o * 4,
                     make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2], acc3[G >> 2][4 * (G & 3) + 3]));
         }
         if constexpr (NTO > 0) {
@@ -402,11 +406,11 @@ __global__ __launch_bounds__(512, 2) void k_res64_lds(const BlockLinArgsH A, con
                     for (int qq = 0; qq < 4; ++qq)
                         if (8 * G + 4 * h + qq < la.out_width) { const float dv = accL[G >> 2][4 * (G & 3) + qq] - m; sq = fmaf(dv, dv, sq); }
                 sq = xhalf_sum(sq);
-                if (h == 0) reinterpret_cast<float2*>(la.out_stats)[(size_t)tile * 32 + j] = make_float2(m, sq);
+                if (lane_o < 32) reinterpret_cast<float2*>(la.out_stats)[(size_t)tile * 32 + lane_o] = make_float2(m, sq);
 #pragma unroll
                 for (int G = 0; G < NTO * 4; ++G)
                     if (G < NGo)
-                        st4(la.out + ((size_t)tile * NGo + G) * 256 + lane * 4,
+                        st4(la.out + ((size_t)tile * NGo + G) * 256 + lane_o * 4,
                             make_float4(accL[G >> 2][4 * (G & 3)], accL[G >> 2][4 * (G & 3) + 1], accL[G >> 2][4 * (G & 3) + 2], accL[G >> 2][4 * (G & 3) + 3]));
             }
         }

@@ -510,13 +510,16 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] += gb[r];
     }
-    // LN1 statistics from the producers' per-row (mean, M2), combined over the concat (Chan), as k_resblock_bwd_h
-    float mean1, rstd1, wtot;
-    {
-        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
+    // LN1 statistics from the producers' per-row (mean, M2), combined over the concat (Chan), as k_resblock_bwd_h.  Evaluated where they
+    // are used (here for the record the weight-gradient kernels read, and again in front of stage 1's LayerNorm backward: two L2-hot
+    // loads and a dozen instructions) instead of carried across the whole kernel: three of the registers it does not have.
+    auto ln1_stats = [&](float& mean1, float& rstd1, float& wtot) {
+        int jj = j;
+        asm volatile("" : "+v"(jj));                   // (opaque: keeps hipcc from merging the two evaluations back into one long-lived pair)
+        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + jj];
         float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
         if (SCLIN) {
-            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
+            const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + jj];
             const float n1 = (float)a.in1.width, nt_ = n + n1;
             const float dd = s1.x - mean;
             m2 = m2 + s1.y + dd * dd * (n * n1 / nt_);
@@ -525,7 +528,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
         }
         mean1 = mean; wtot = n;
         rstd1 = rsqrtf(m2 / n + kLnEps);
-        if (w == 0 && h == 0 && live) reinterpret_cast<float2*>(a.rs1)[(size_t)tile * 32 + j] = make_float2(mean1, rstd1);
+    };
+    if (w == 0 && h == 0 && live) {
+        float m_, r_, w_;
+        ln1_stats(m_, r_, w_);
+        reinterpret_cast<float2*>(a.rs1)[(size_t)tile * 32 + j] = make_float2(m_, r_);
     }
     // weight scales 2^-e (bind-time maxima): evaluated where they are used -- kept from here they are three of the registers this
     // kernel does not have (256 allocated, three spilled before)
@@ -638,6 +645,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
 
     // ---- stage 1: d a1 = W1^T dh1 over the (concat) input: this wave's slice of in0 and, for an up block, of in1
     f32x16 dx[DT][1];
+    float mean1, rstd1, wtot;
+    ln1_stats(mean1, rstd1, wtot);
     {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -668,7 +677,11 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
     }
     // ---- shortcut: + Wsc^T g (Linear, the operand image of g once more) or + g (identity)
     if (SCLIN) {
-        slice_publish(Bimg, w, lane, g, sg);
+        // (an opaque copy of the row scale: hipcc otherwise keeps the sixteen products g * sg of the FIRST publish alive until here --
+        // they are values since the split takes rounded float32 operands -- and spills them; sixteen multiplies are cheaper)
+        float sg_again = sg;
+        asm volatile("" : "+v"(sg_again));
+        slice_publish(Bimg, w, lane, g, sg_again);
         __syncthreads();                                                 // C3
         const int e0 = scale_exp_lin3(*ah.m3, *ah.msc) + 4;
         const float pre = sg * __int_as_float((127 + e0) << 23), post = sginv * __int_as_float((127 - e0) << 23);

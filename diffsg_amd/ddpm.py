@@ -309,16 +309,58 @@ class DDPMCore(nn.Module):
         # calls before one backward ((m(a, c) + m(b, c)).backward()) must not share it.  Buffers return to the pool in _publish
         # (the common one-forward-one-backward loop reuses a single buffer); a call whose graph is dropped just loses its buffer
         work = self._grad_buffers(L, hd, dev)
-        loss = torch.empty((), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
-            _lib.check(L.dsg_train_step(hd, _lib.ptr(y32), _lib.ptr(c32), _lib.ptr(ts32), _lib.ptr(nz), _lib.ptr(mk),
-                                        _lib.ptr(self.sqrt_alphas_cumprod), _lib.ptr(self.sqrt_one_minus_alphas_cumprod),
-                                        self.T, _lib.ptr(work), _lib.ptr(loss), B, _lib.stream_ptr()))
+        sa, sb = _lib.ptr(self.sqrt_alphas_cumprod), _lib.ptr(self.sqrt_one_minus_alphas_cumprod)
+
+        def launch(handle, lo, hi, wk, ls):
+            _lib.check(L.dsg_train_step(handle, _lib.ptr(y32[lo:hi]), _lib.ptr(c32[lo:hi]), _lib.ptr(ts32[lo:hi]), _lib.ptr(nz[lo:hi]),
+                                        _lib.ptr(mk[lo:hi]), sa, sb, self.T, _lib.ptr(wk), _lib.ptr(ls), hi - lo, _lib.stream_ptr()))
+        loss = self._run_halves(launch, hd, B, dev, work, (y32, c32, ts32, nz, mk))
         self._keepalive = (y32, c32, ts32, nz, mk)
         if not torch.is_grad_enabled():
             self._grad_pool.append(work)
             return loss
         return _PublishGrads.apply(self._loss_anchor, loss, self, work)
+
+    #: Rows from which DDPM.forward runs the fused training step as TWO half batches on two handles and two streams at once
+    #: (None: never).  Measured (profiles/r04_train_split_ab.txt, same box): 3.81 -> 3.70 ms/step at 65 536 rows, but 2.24 -> 2.40 at
+    #: 32 768 and 1.58 -> 1.74 at 16 384 (the second weight re-pack, two side streams and the contention cost more than the
+    #: overlap of the two chains returns) -- hence the threshold.  Same arithmetic per row; the loss and the gradients are the
+    #: row-weighted means of the halves (float32 sums in another order than one launch: not bit-identical to the unsplit step,
+    #: deterministic run to run).
+    train_split_min_rows = 65536
+
+    def _splits(self, B):
+        return self.train_split_min_rows is not None and B >= self.train_split_min_rows and B >= 128
+
+    def _run_halves(self, launch, hd, B, dev, work, inputs):
+        """Enqueue the fused step for rows [0, B): one launch on the caller's stream, or two halves -- rows [0, nA) on the caller's
+        stream and handle, rows [nA, B) on a side stream and the module's twin handle -- joined and combined into `work`."""
+        with torch.cuda.device(dev):
+            if not self._splits(B):
+                loss = torch.empty((), device=dev, dtype=torch.float32)
+                launch(hd, 0, B, work, loss)
+                return loss
+            nA = (B // 2) // 32 * 32
+            main = torch.cuda.current_stream(dev)
+            side = getattr(self, "_split_stream", None)
+            if side is None or side.device != dev:
+                side = self._split_stream = torch.cuda.Stream(dev)
+            work_b = self._grad_pool.pop() if self._grad_pool else torch.empty_like(work)
+            losses = torch.empty(2, device=dev, dtype=torch.float32)
+            side.wait_stream(main)                      # the inputs (and the optimizer's last update) are ready for the side stream
+            with torch.cuda.stream(side):
+                hb = self.model.native_handle(twin=1)   # binds (re-packs) on the side stream
+                launch(hb, nA, B, work_b, losses[1:])
+            launch(hd, 0, nA, work, losses[:1])
+            main.wait_stream(side)
+            for t in tuple(inputs) + (work_b, losses):
+                t.record_stream(side)
+            # mean over all rows = row-weighted mean of the halves' means (MSR.py:112: mse_loss is a mean over rows x D)
+            a, b = nA / B, (B - nA) / B
+            work.mul_(a).add_(work_b, alpha=b)
+            loss = losses[0] * a + losses[1] * b
+            self._grad_pool.append(work_b)
+            return loss
 
     def _grad_buffers(self, L, hd, dev):
         total = L.dsg_param_total(hd)
@@ -337,17 +379,35 @@ class DDPMCore(nn.Module):
         c32 = cond.detach().to(dev, torch.float32).contiguous()
         L = _lib.lib()
         work = self._grad_buffers(L, hd, dev)
-        loss = torch.empty((), device=dev, dtype=torch.float32)
         call = self._draw_calls
         self._draw_calls += 1
         # data parallel: every rank must draw DIFFERENT ts / noise / mask for its rows (dp_context only de-correlates torch's
         # generator): the rank is folded into the Philox key, rank 0 keeps the plain seed
         seed = (int(self.device_draws) ^ (_dp_rank() * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
-        with torch.cuda.device(dev):
-            _lib.check(L.dsg_train_step_seeded(hd, _lib.ptr(y32), _lib.ptr(c32), seed, call,
-                                               float(1.0 - self.uncond_prob), _lib.ptr(self.sqrt_alphas_cumprod),
-                                               _lib.ptr(self.sqrt_one_minus_alphas_cumprod), self.T, _lib.ptr(work), _lib.ptr(loss), B,
-                                               _lib.stream_ptr()))
+        sa, sb = _lib.ptr(self.sqrt_alphas_cumprod), _lib.ptr(self.sqrt_one_minus_alphas_cumprod)
+
+        if self._splits(B):
+            # a split batch needs the draws of ALL its rows from one key: dsg_train_draws writes exactly what the seeded step would
+            # have drawn for B rows, then the halves run on explicit tensors
+            D = y32.shape[1]
+            buf = getattr(self, "_draw_bufs", None)
+            if buf is None or buf[0].numel() != B or buf[1].shape != (B, D) or buf[0].device != dev:
+                buf = self._draw_bufs = (torch.empty(B, device=dev, dtype=torch.int32), torch.empty(B, D, device=dev, dtype=torch.float32),
+                                         torch.empty(B, device=dev, dtype=torch.float32))
+            ts32, nz, mk = buf
+            with torch.cuda.device(dev):
+                _lib.check(L.dsg_train_draws(seed, call, self.T, float(1.0 - self.uncond_prob), B, D, _lib.ptr(ts32), _lib.ptr(nz), _lib.ptr(mk),
+                                             _lib.stream_ptr()))
+
+            def launch(handle, lo, hi, wk, ls):
+                _lib.check(L.dsg_train_step(handle, _lib.ptr(y32[lo:hi]), _lib.ptr(c32[lo:hi]), _lib.ptr(ts32[lo:hi]), _lib.ptr(nz[lo:hi]),
+                                            _lib.ptr(mk[lo:hi]), sa, sb, self.T, _lib.ptr(wk), _lib.ptr(ls), hi - lo, _lib.stream_ptr()))
+            loss = self._run_halves(launch, hd, B, dev, work, (y32, c32, ts32, nz, mk))
+        else:
+            def launch(handle, lo, hi, wk, ls):
+                _lib.check(L.dsg_train_step_seeded(handle, _lib.ptr(y32[lo:hi]), _lib.ptr(c32[lo:hi]), seed, call, float(1.0 - self.uncond_prob),
+                                                   sa, sb, self.T, _lib.ptr(wk), _lib.ptr(ls), hi - lo, _lib.stream_ptr()))
+            loss = self._run_halves(launch, hd, B, dev, work, (y32, c32))
         self._keepalive = (y32, c32)
         if not torch.is_grad_enabled():
             self._grad_pool.append(work)

@@ -1033,6 +1033,54 @@ def test_fused_optimizer_updates_are_seen_by_the_library():
     assert not torch.equal(out1, s0(x, t, cond, m))
 
 
+def test_split_training_step_is_the_unsplit_step():
+    """DDPM.train_split_min_rows: the fused step as two half batches on two handles and two streams (twin handle of the same module) gives
+    the loss and the gradients of one launch over all rows -- row-weighted means, float32 sums in another order -- with torch's draws
+    and with device-side draws, on a ragged batch; and an optimizer step reaches the twin's packed weights."""
+    name, T, B = "msr80", 20, 200 + 13
+    plan, p = synth_params(name, 5)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(3)
+    y = (torch.rand(B, cfg["input_dim"], generator=g) * 0.25).cuda()
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    ts = torch.randint(0, T, (1, B), generator=g).cuda()
+    noise = torch.randn(B, cfg["input_dim"], generator=g).cuda()
+    mask = (torch.rand(B, 1, generator=g) < 0.9).float().cuda()
+
+    def grads(ddpm, **kw):
+        for q in ddpm.model.parameters():
+            q.grad = None
+        loss = ddpm(y, cond, **kw)
+        loss.backward()
+        return float(loss.detach()), {k: q.grad.detach().clone() for k, q in ddpm.model.named_parameters()}
+
+    ref = make_ddpm(name, p, T)
+    ref.train_split_min_rows = None
+    sp = make_ddpm(name, p, T)
+    sp.train_split_min_rows = 128
+    l0, g0 = grads(ref, ts=ts, noise=noise, cond_mask=mask)
+    l1, g1 = grads(sp, ts=ts, noise=noise, cond_mask=mask)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    errs = grad_errs(g1, {k: v.cpu() for k, v in g0.items()})
+    assert max(errs.values()) <= 2e-5, max(errs.items(), key=lambda kv: kv[1])
+    # device-side draws: the split step draws all rows from one key, as the unsplit seeded step does
+    ref.device_draws = sp.device_draws = 7
+    l0, g0 = grads(ref)
+    l1, g1 = grads(sp)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    assert max(grad_errs(g1, {k: v.cpu() for k, v in g0.items()}).values()) <= 2e-5
+    # an optimizer step must reach BOTH packed copies of the weights
+    opt = torch.optim.Adam(sp.model.parameters(), lr=1e-2, fused=True)
+    sp.device_draws = None
+    la, _ = grads(sp, ts=ts, noise=noise, cond_mask=mask)
+    opt.step()
+    lb, _ = grads(sp, ts=ts, noise=noise, cond_mask=mask)
+    only_first = make_ddpm(name, {k: v.detach().cpu() for k, v in sp.model.state_dict().items()}, T)
+    only_first.train_split_min_rows = None
+    lc, _ = grads(only_first, ts=ts, noise=noise, cond_mask=mask)
+    assert la != lb and abs(lb - lc) <= 1e-6 * abs(lc)
+
+
 def test_flat_adam_is_adam_bit_for_bit():
     """train.FlatAdam (one flat tensor, one launch) makes exactly the updates torch.optim.Adam makes on the separate
     parameters, and the re-pointed parameters keep the state-dict layout and stay bound to the library."""

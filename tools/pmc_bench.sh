@@ -3,7 +3,7 @@
 OUT=${1:-gpurun_out/pmc_bench}
 export TMPDIR=/tmp
 mkdir -p $OUT
-ARGS="bench.py --steps 6 --warmup 2 --no-train --no-cpu-baseline"
+ARGS="bench.py --steps 6 --warmup 2 --no-train --no-cpu-baseline --no-f32-exact --no-other-configs"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/p1 -- python3 $ARGS > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/p2 -- python3 $ARGS > $OUT/p2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/p3 -- python3 $ARGS > $OUT/p3.log 2>&1

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 mkdir -p $OUT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-train --no-cpu-baseline > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-train --no-cpu-baseline --no-other-configs > $OUT/kt.log 2>&1
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_bench_sampling.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktt -o kt -- python3 tools/train_prof.py 10 32768 > $OUT/ktt.log 2>&1
 cp $(find $OUT/ktt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_train_32768.csv

@@ -22,6 +22,14 @@ def run(tag):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     torch.cuda.synchronize(); h0 = time.perf_counter(); one(); h1 = time.perf_counter(); torch.cuda.synchronize()
     print(f"{tag:58s} {dt*1e3:.3f} ms/step   host enqueue of one step {1e3*(h1-h0):.3f} ms", flush=True)
+if os.environ.get("SPLIT_AB"):
+    # split of the batch over two handles / streams (DDPM.train_split_min_rows), with the settings bench.py's train leg uses
+    FlatAdam.native_step = True; ddpm.device_draws = 1
+    for rnd in range(3):
+        for sp in (None, 16384):
+            type(ddpm).train_split_min_rows = sp
+            run(f"round {rnd}: B={B} train_split_min_rows={sp}")
+    sys.exit(0)
 for rnd in range(2):
     for nat in (False, True):
         for side in (False, True):
