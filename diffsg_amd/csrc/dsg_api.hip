@@ -2070,8 +2070,7 @@ static int enqueue_step(dsg_handle* h, const RunCtx& c, const UpdateArgs& u, boo
         double* p1 = chunks > 1 ? h->red_chunks : h->red;
         double* p2 = chunks > 1 ? h->red_chunks + (size_t)chunks * kRedBlocks : h->red + kRedBlocks;
         const size_t cn = chunks > 1 ? chunk_n : (size_t)0;
-        hipLaunchKernelGGL(k_renorm_sum, dim3(kRedBlocks, chunks), dim3(256), 0, s, (const float*)u.y, u.n, p1, cn);
-        hipLaunchKernelGGL(k_renorm_sqdiff, dim3(kRedBlocks, chunks), dim3(256), 0, s, (const float*)u.y, u.n, (const double*)p1, p2, cn);
+        hipLaunchKernelGGL(k_renorm_sum, dim3(kRedBlocks, chunks), dim3(256), 0, s, (const float*)u.y, u.n, p1, p2, cn);
         hipLaunchKernelGGL(k_renorm_apply, dim3(kRedBlocks, chunks), dim3(256), 0, s, u.y, u.n, (const double*)p1, (const double*)p2, cn,
                            (const CallParams*)u.cp, (const int*)u.step_ptr);      // + the trajectory record of the renormalised y
     }

@@ -970,26 +970,18 @@ __device__ __forceinline__ void renorm_visit(const float* y, size_t n, F&& f) {
     for (size_t i4 = t; i4 < n4; i4 += st) { const float4 v = ld4(y + 4 * i4); f(v.x); f(v.y); f(v.z); f(v.w); }
     for (size_t i = 4 * n4 + t; i < n; i += st) f(y[i]);
 }
-__global__ __launch_bounds__(256) void k_renorm_sum(const float* y, size_t n, double* __restrict__ part, size_t chunk_n = 0) {
-    __shared__ double sm[4];
-    renorm_chunk(y, n, chunk_n); part += (size_t)blockIdx.y * kRedBlocks;
-    double s = 0.0;
-    renorm_visit(y, n, [&](float v) { s += (double)v; });
-    s = block_sum(s, sm);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
-}
-
-__global__ __launch_bounds__(256) void k_renorm_sqdiff(const float* y, size_t n, const double* __restrict__ part,
-                                                       double* __restrict__ part2, size_t chunk_n = 0) {
+// Round 4: ONE pass for both moments (sum y and sum y^2 in float64, fixed block partials: deterministic); the variance is formed in
+// float64 as (sum y^2 - n mean^2) / (n - 1) by k_renorm_apply.  In float64 that loses ~(1 + mean^2 / var) x 1e-16 relative, far below the
+// float32 result it is rounded to; it replaces the two-pass form (k_renorm_sum, then k_renorm_sqdiff: one more launch and one more read
+// of y on each of the four early steps of every call).
+__global__ __launch_bounds__(256) void k_renorm_sum(const float* y, size_t n, double* __restrict__ part, double* __restrict__ part2, size_t chunk_n = 0) {
     __shared__ double sm[4];
     renorm_chunk(y, n, chunk_n); part += (size_t)blockIdx.y * kRedBlocks; part2 += (size_t)blockIdx.y * kRedBlocks;
-    double tot = 0.0;
-    for (int i = 0; i < kRedBlocks; ++i) tot += part[i];
-    const double mean = tot / (double)n;
-    double s = 0.0;
-    renorm_visit(y, n, [&](float v) { const double d = (double)v - mean; s += d * d; });
+    double s = 0.0, q = 0.0;
+    renorm_visit(y, n, [&](float v) { const double d = (double)v; s += d; q += d * d; });
     s = block_sum(s, sm);
-    if (threadIdx.x == 0) part2[blockIdx.x] = s;
+    q = block_sum(q, sm);
+    if (threadIdx.x == 0) { part[blockIdx.x] = s; part2[blockIdx.x] = q; }
 }
 
 // Sharded form of the early-step renorm (dsg_set_renorm_hook): the shard's (sum y, sum y^2, count) in float64 -- the caller
@@ -1028,8 +1020,9 @@ __global__ __launch_bounds__(256) void k_renorm_apply(float* y, size_t n, const 
     part += (size_t)blockIdx.y * kRedBlocks; part2 += (size_t)blockIdx.y * kRedBlocks;
     double tot = 0.0, tot2 = 0.0;
     for (int i = 0; i < kRedBlocks; ++i) { tot += part[i]; tot2 += part2[i]; }
-    const float mean = (float)(tot / (double)n);
-    const float sd = sqrtf((float)(tot2 / (double)(n - 1)));
+    const double mean_d = tot / (double)n;
+    const float mean = (float)mean_d;
+    const float sd = sqrtf((float)((tot2 - tot * mean_d) / (double)(n - 1)));      // unbiased, as torch.var (MSR.py:137)
     const size_t n4 = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(rec)) & 15) ? 0 : n / 4;
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
     for (size_t i4 = t; i4 < n4; i4 += st) {

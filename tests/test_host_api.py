@@ -179,7 +179,7 @@ SAMPLING_STEP_KERNELS = [
     "dsg::k_panel128_h<false, 0, 1>", "dsg::k_panel128_h<false, 1, 2>", "dsg::k_panel128_h<true, 0, 1>", "dsg::k_panel128_h<true, 2, 3>",
     "dsg::k_res64_dual", "dsg::k_res64_lds<true, 0>", "dsg::k_res64_lds<true, 4>",
     "dsg::k_fused_narrow_lds<2>", "dsg::k_fused_narrow_lds<3>", "dsg::k_fused_narrow_lds<0>",
-    "dsg::k_update", "dsg::k_renorm_sum", "dsg::k_renorm_sqdiff", "dsg::k_renorm_apply",
+    "dsg::k_update", "dsg::k_renorm_sum", "dsg::k_renorm_apply",
 ]
 OTHER_HOT_KERNELS = [
     "dsg::k_res64_lds<false, 2>", "dsg::k_res64_lds<false, 1>", "dsg::k_res64_lds<true, 2>", "dsg::k_res64_lds<false, 0>",
