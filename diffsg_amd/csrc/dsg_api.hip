@@ -205,6 +205,7 @@ struct dsg_handle {
     // in float32 by the LDS form of the narrow run (dsg_narrow8.hpp); opt_v8: dsg_set_option(DSG_OPT_NARROW_VALU8)
     int v8_lo = -1, v8_hi = -1;
     bool opt_v8 = true;
+    bool opt_time_beside = true;       // dsg_set_option(DSG_OPT_TRAIN_TIME_BESIDE): see the tail of dsg_train_step
     // the section's image in global memory (V8SecL layout: raw nn.Linear matrices and parameter vectors), gathered at every bind; the LDS
     // form of the narrow run stages it as one piece, small launches and the training forward read it from L1 / L2
     float* v8_image = nullptr; NarrowLdsCopy* v8_copies_dev = nullptr; int v8_ncopies = 0;
@@ -246,9 +247,12 @@ struct dsg_handle {
     // side_stream beside the rest of the activation-gradient chain, see dsg_train_step
     std::vector<int> wg_forks = {3, 6};
     std::vector<int> wg_part_end;      // units [wg_part_end[k-1], wg_part_end[k]) = part k; the rest runs on the caller's stream
+    int wg_onehot_end = 0;             // ... and opens with the final part's time-table units: [wg_part_end.back(), wg_onehot_end),
+    int wg_blocks_end = 0;             // then its residual blocks' other units [wg_onehot_end, wg_blocks_end), then the plain Linears'
     std::vector<int> wg_fork_ops;      // operator index after whose backward kernel part k starts
     int wg_early_lds = 40960;
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t time_stream = nullptr; hipEvent_t ev_tail[2] = {nullptr, nullptr};   // the tail of dsg_train_step
     FusedBwdOpH* fbwd_dev = nullptr; int fbwd_n = 0;   // operator table of the fused narrow backward (split path), cached with the descriptors
     ColsumDesc* cs_desc_dev = nullptr; ColsumUnit* cs_unit_dev = nullptr; int cs_units = 0;
     // the descriptor tables depend only on (rows, T, precision mode) and the workspace addresses: built once, reused every step
@@ -1250,7 +1254,8 @@ int ensure_train_workspace(dsg_handle* h, int rows, int T) {
     HIPCK(hipMalloc(&h->tr_slabs, (size_t)max_chunks * h->slab_stride * sizeof(float)));
     HIPCK(hipMemset(h->tr_slabs, 0, (size_t)max_chunks * h->slab_stride * sizeof(float)));
     HIPCK(hipMalloc(&h->tr_gsum, h->slab_stride * sizeof(float)));
-    HIPCK(hipMalloc(&h->tr_gmax, (size_t)(1 + kMaxWgParts) * kMaxGmax * sizeof(unsigned)));   // + one set per early weight-gradient part
+    // + one set per early weight-gradient part + the complete set of the step's tail (the blocks' slots AND the Linears')
+    HIPCK(hipMalloc(&h->tr_gmax, (size_t)(2 + kMaxWgParts) * kMaxGmax * sizeof(unsigned)));
     h->gmax_ld = (int)tiles;
     HIPCK(hipMalloc(&h->tr_gmax_t, (size_t)kMaxGmax * h->gmax_ld * sizeof(unsigned)));
     {   // per-tile column sums of the residual blocks, one contiguous [tile][slot] region per block:
@@ -1481,13 +1486,25 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
         std::stable_sort(ou.begin(), ou.end(), [](const OpUnits& a, const OpUnits& b) { return a.cost > b.cost; });
         h->wg_part_end.clear();
         const int nparts = (int)h->wg_fork_ops.size();
+        // the final part opens with its time-table (one-hot) units: once they are through, every dTB row of the step is complete and
+        // the time path can run on the side stream beside the rest of the final launch (dsg_train_step)
+        // ... then the other units of its residual blocks, then the plain Linears' (the scale of a block's G operands is known when
+        // the block's backward kernel has run, a Linear's only after k_colsum)
         for (int part = 0; part <= nparts; ++part) {
-            for (const OpUnits& o : ou) {
-                const int pt = op_part[wd_op[o.u.front().first]];
-                if (pt != (part < nparts ? part : -1)) continue;
-                for (int c0 = 0; c0 < h->tr_chunks; c0 += 8)
-                    for (const auto& u : o.u)
-                        for (int c = c0; c < c0 + 8 && c < h->tr_chunks; ++c) wu.push_back(WgradUnit{u.first, u.second, c, 0});
+            for (int pass = (part < nparts ? 2 : 0); pass < 3; ++pass) {
+                for (const OpUnits& o : ou) {
+                    const int op1 = wd_op[o.u.front().first];          // operator index + 1
+                    if (op_part[op1] != (part < nparts ? part : -1)) continue;
+                    const bool block = h->ops[op1 - 1].kind == OP_RES;
+                    for (int c0 = 0; c0 < h->tr_chunks; c0 += 8)
+                        for (const auto& u : o.u) {
+                            const int cls = wd[u.first].amode == A_ONEHOT ? 0 : (block ? 1 : 2);
+                            if (part == nparts && cls != pass) continue;
+                            for (int c = c0; c < c0 + 8 && c < h->tr_chunks; ++c) wu.push_back(WgradUnit{u.first, u.second, c, 0});
+                        }
+                }
+                if (part == nparts && pass == 0) h->wg_onehot_end = (int)wu.size();
+                if (part == nparts && pass == 1) h->wg_blocks_end = (int)wu.size();
             }
             if (part < nparts) h->wg_part_end.push_back((int)wu.size());
         }
@@ -1746,6 +1763,8 @@ void dsg_destroy(dsg_handle* h) {
     if (h->fbwd_dev) (void)hipFree(h->fbwd_dev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->time_stream) (void)hipStreamDestroy(h->time_stream);
+    for (auto& e : h->ev_tail) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -1980,6 +1999,7 @@ int dsg_set_option(dsg_handle* h, int option, int value) {
                 h->opt_v8 = value != 0;
             }
             return 0;
+        case DSG_OPT_TRAIN_TIME_BESIDE: h->opt_time_beside = value != 0; return 0;
         default: return fail("dsg_set_option: unknown option %d", option);
     }
 }
@@ -2308,6 +2328,10 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
         HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        int pr_least = 0, pr_greatest = 0;
+        HIPCK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        HIPCK(hipStreamCreateWithPriority(&h->time_stream, hipStreamNonBlocking, pr_greatest));   // short dependent launches beside a full-chip one
+        for (auto& e : h->ev_tail) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // the G and A operands of a part are final once the backward kernel of its last block is enqueued: its weight gradients run
     // on the side stream from there, beside the remaining chain kernels (one wave per SIMD below 65 536 rows: latency-bound,
@@ -2354,30 +2378,41 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
             launch_lin_bwd(l.l.K, op.kind == OP_FINAL, a, s);
         }
     }
-    // ---- weight / bias / LayerNorm gradients: two grouped launches into per-chunk slabs, then a fixed-order reduce
+    // ---- weight / bias / LayerNorm gradients: grouped launches into per-chunk slabs, then a fixed-order reduce.
+    // Small batches: everything in order on the caller's stream.  With the side stream (>= 32 768 rows) the tail runs on two streams:
+    //   caller's stream       max|G| of the blocks -> the blocks' units (ONE launch, longest first) ----------------> reduce (parameters)
+    //   time stream           time-table units -> column sums (k_cs_reduce, k_colsum) -> max|G| of everything ->      ^
+    //   (high priority)       the Linears' units -> [early parts done] -> reduce (dTB) -> time path ------------------+
+    // A residual block's G operands have their scale from the block's own backward kernel; only the plain Linears' wait for k_colsum.
+    // The time path (UNetCF.py:35-44 backward: ~10 short dependent launches) needs nothing but the dTB rows; its five results go
+    // into slab 0 at their parameters' offsets, which no unit writes and which are zero in every other slab
+    // (ensure_train_workspace clears the slabs once), so the one fixed-order reduce at the end delivers them with everything else.
     mark(2);
-    hipLaunchKernelGGL(k_cs_reduce, dim3(cdiv(h->cs_slots, 256), h->tr_chunks), dim3(256), 0, s, h->tr_cs, h->cs_map_dev, h->cs_slots,
+    const bool time_beside = h->use_split && next_part > 0 && h->side_stream && h->opt_time_beside;
+    hipStream_t cs_stream = time_beside ? h->time_stream : s;
+    unsigned* const gm_all = time_beside ? h->tr_gmax + (size_t)(1 + kMaxWgParts) * kMaxGmax : h->tr_gmax;
+    auto units = [&](int lo, int hi, const unsigned* gm, hipStream_t us) {
+        if (hi > lo)
+            hipLaunchKernelGGL(k_wgrad_h, dim3(hi - lo), dim3(256), 0, us, h->wg_desc_dev, h->wg_unit_dev + lo, gm, h->tr_slabs, h->slab_stride,
+                               tiles, h->tr_chunks);
+    };
+    const int u0 = next_part ? h->wg_part_end[next_part - 1] : 0;
+    if (time_beside) {
+        // the blocks' slots are complete; the Linears' are not yet, and nothing reads them from this set
+        hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, s, h->tr_gmax_t, h->gmax_ld, h->tr_gmax);
+        HIPCK(hipEventRecord(h->ev_tail[0], s));
+        HIPCK(hipStreamWaitEvent(h->time_stream, h->ev_tail[0], 0));
+        units(u0, h->wg_onehot_end, h->tr_gmax, h->time_stream);
+    }
+    hipLaunchKernelGGL(k_cs_reduce, dim3(cdiv(h->cs_slots, 256), h->tr_chunks), dim3(256), 0, cs_stream, h->tr_cs, h->cs_map_dev, h->cs_slots,
                        h->tr_slabs, h->slab_stride, tiles, h->tr_chunks);
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->cs_units, 4)), dim3(256), 0, s, h->cs_desc_dev, h->cs_unit_dev, h->cs_units, h->tr_slabs,
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->cs_units, 4)), dim3(256), 0, cs_stream, h->cs_desc_dev, h->cs_unit_dev, h->cs_units, h->tr_slabs,
                        h->slab_stride, tiles, h->tr_chunks, B, h->tr_gmax_t, h->gmax_ld);
-    hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, s, h->tr_gmax_t, h->gmax_ld, h->tr_gmax);
+    hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, cs_stream, h->tr_gmax_t, h->gmax_ld, gm_all);
     mark(3);
-    if (h->use_split) {
-        const int u0 = next_part ? h->wg_part_end[next_part - 1] : 0;
-        if (next_part) HIPCK(hipEventRecord(h->ev_join, h->side_stream));
-        hipLaunchKernelGGL(k_wgrad_h, dim3(h->wg_units - u0), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev + u0, h->tr_gmax, h->tr_slabs,
-                           h->slab_stride, tiles, h->tr_chunks);
-        if (next_part) HIPCK(hipStreamWaitEvent(s, h->ev_join, 0));
-    } else
-        hipLaunchKernelGGL(k_wgrad, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_slabs, h->slab_stride, tiles,
-                           h->tr_chunks);
-    mark(4);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((h->slab_stride + 255) / 256 < 4096 ? (h->slab_stride + 255) / 256 : 4096)), dim3(256),
-                       0, s, h->tr_slabs, h->slab_stride, h->tr_chunks, h->tr_gsum, h->slab_stride);
-
-    // ---- time path backward on the [T x .] tables (TimeEmbedding, UNetCF.py:35-44, and the per-block time_emb Linear)
-    {
-        float* G = h->tr_gsum;
+    const size_t dtb0 = (size_t)h->total_params, dtb_n = h->slab_stride - dtb0;
+    auto reduce_blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)); };
+    auto time_path = [&](float* G, hipStream_t ts) {
         float* emb = h->tr_tsave;
         float* h1pre = emb + (size_t)T * 2 * half;
         float* h1s = h1pre + (size_t)T * td;
@@ -2386,19 +2421,44 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
         float* d_h1s = d_st + (size_t)T * td;
         float* tpart = d_h1s + (size_t)T * td;   // [kTimeChunks][T][td]
         // all blocks at once: their dTB rows are contiguous from the first block's dtb_off
-        const float* dtb_all = G + h->res[0].dtb_off;
-        hipLaunchKernelGGL(k_time_wgrad, dim3(2048), dim3(256), 0, s, dtb_all, T, h->st, td, h->tw_dst_dev, G, h->tw_rows);
-        hipLaunchKernelGGL(k_time_dgrad, dim3(cdiv(T * td, 256), kTimeChunks), dim3(256), 0, s, dtb_all, T, h->tw_src_dev, td, tpart, h->tw_rows);
+        const float* dtb_all = h->tr_gsum + h->res[0].dtb_off;
+        hipLaunchKernelGGL(k_time_wgrad, dim3(2048), dim3(256), 0, ts, dtb_all, T, h->st, td, h->tw_dst_dev, G, h->tw_rows);
+        hipLaunchKernelGGL(k_time_dgrad, dim3(cdiv(T * td, 256), kTimeChunks), dim3(256), 0, ts, dtb_all, T, h->tw_src_dev, td, tpart, h->tw_rows);
         const unsigned eb = (unsigned)cdiv(T * td, 256);
-        hipLaunchKernelGGL(k_time_dgrad_finish, dim3(eb), dim3(256), 0, s, tpart, tpre, d_st, (size_t)T * td);  // d temb (pre-Swish)
-        small_gemm(d_st, 1, td, h1s, td, 1, G + P[h->temb_l2w].off, td, 1, td, td, T, 0, s);                   // d lin2.weight
-        hipLaunchKernelGGL(k_col_sum_small, dim3(cdiv(td, 256)), dim3(256), 0, s, d_st, T, td, (long long)td, G + P[h->temb_l2b].off);
-        small_gemm(d_st, td, 1, P[h->temb_l2w].ptr, td, 1, d_h1s, td, 1, T, td, td, 0, s);                     // d h1 (post-Swish)
-        hipLaunchKernelGGL(k_mul_silu_grad, dim3(eb), dim3(256), 0, s, d_h1s, h1pre, (size_t)T * td);
-        small_gemm(d_h1s, 1, td, emb, 2 * half, 1, G + P[h->temb_l1w].off, 2 * half, 1, td, 2 * half, T, 0, s);  // d lin1.weight
-        hipLaunchKernelGGL(k_col_sum_small, dim3(cdiv(td, 256)), dim3(256), 0, s, d_h1s, T, td, (long long)td, G + P[h->temb_l1b].off);
+        hipLaunchKernelGGL(k_time_dgrad_finish, dim3(eb), dim3(256), 0, ts, tpart, tpre, d_st, (size_t)T * td);  // d temb (pre-Swish)
+        small_gemm(d_st, 1, td, h1s, td, 1, G + P[h->temb_l2w].off, td, 1, td, td, T, 0, ts);                   // d lin2.weight
+        hipLaunchKernelGGL(k_col_sum_small, dim3(cdiv(td, 256)), dim3(256), 0, ts, d_st, T, td, (long long)td, G + P[h->temb_l2b].off);
+        small_gemm(d_st, td, 1, P[h->temb_l2w].ptr, td, 1, d_h1s, td, 1, T, td, td, 0, ts);                     // d h1 (post-Swish)
+        hipLaunchKernelGGL(k_mul_silu_grad, dim3(eb), dim3(256), 0, ts, d_h1s, h1pre, (size_t)T * td);
+        small_gemm(d_h1s, 1, td, emb, 2 * half, 1, G + P[h->temb_l1w].off, 2 * half, 1, td, 2 * half, T, 0, ts);  // d lin1.weight
+        hipLaunchKernelGGL(k_col_sum_small, dim3(cdiv(td, 256)), dim3(256), 0, ts, d_h1s, T, td, (long long)td, G + P[h->temb_l1b].off);
+    };
+    if (time_beside) {
+        units(h->wg_onehot_end, h->wg_blocks_end, h->tr_gmax, s);
+        units(h->wg_blocks_end, h->wg_units, gm_all, h->time_stream);
+        HIPCK(hipEventRecord(h->ev_join, h->side_stream));                 // the early parts: the other blocks' time-table units
+        HIPCK(hipStreamWaitEvent(h->time_stream, h->ev_join, 0));
+        hipLaunchKernelGGL(k_reduce_slabs, reduce_blocks(dtb_n), dim3(256), 0, h->time_stream, h->tr_slabs + dtb0, h->slab_stride, h->tr_chunks,
+                           h->tr_gsum + dtb0, dtb_n);
+        time_path(h->tr_slabs, h->time_stream);
+        HIPCK(hipEventRecord(h->ev_tail[1], h->time_stream));
+        HIPCK(hipStreamWaitEvent(s, h->ev_tail[1], 0));
+        mark(4);
+        hipLaunchKernelGGL(k_reduce_slabs, reduce_blocks(dtb0), dim3(256), 0, s, h->tr_slabs, h->slab_stride, h->tr_chunks, grads_flat, dtb0);
+    } else {
+        if (h->use_split) {
+            if (next_part) HIPCK(hipEventRecord(h->ev_join, h->side_stream));
+            units(u0, h->wg_units, h->tr_gmax, s);
+            if (next_part) HIPCK(hipStreamWaitEvent(s, h->ev_join, 0));
+        } else
+            hipLaunchKernelGGL(k_wgrad, dim3(h->wg_units), dim3(256), 0, s, h->wg_desc_dev, h->wg_unit_dev, h->tr_slabs, h->slab_stride, tiles,
+                               h->tr_chunks);
+        mark(4);
+        hipLaunchKernelGGL(k_reduce_slabs, reduce_blocks(h->slab_stride), dim3(256), 0, s, h->tr_slabs, h->slab_stride, h->tr_chunks,
+                           h->tr_gsum, h->slab_stride);
+        time_path(h->tr_gsum, s);
+        HIPCK(hipMemcpyAsync(grads_flat, h->tr_gsum, (size_t)h->total_params * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    HIPCK(hipMemcpyAsync(grads_flat, h->tr_gsum, (size_t)h->total_params * sizeof(float), hipMemcpyDeviceToDevice, s));
     mark(5);
     if (h->train_prof) h->tev_valid = true;
     HIPCK(hipGetLastError());

@@ -86,8 +86,11 @@ int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_ma
  *   DSG_OPT_NARROW_VALU8   1 (default): in large sampling launches the 8-wide bottom of the net (Downsample 16 -> 8, the 8-wide
  *                          Down / Middle / Up blocks of UNetCF.py:278-311, Upsample 8 -> 16) runs on the vector unit in exact
  *                          float32 with its skip tensors in registers (csrc/dsg_narrow8.hpp); 0: on the matrix cores like the rest
- *                          of the narrow run.  Cached step graphs are dropped when the value changes. */
-enum { DSG_OPT_NARROW_VALU8 = 1 };
+ *                          of the narrow run.  Cached step graphs are dropped when the value changes.
+ *   DSG_OPT_TRAIN_TIME_BESIDE  1 (default): in training steps that use the side stream (>= 32 768 rows) the time-path backward
+ *                          (TimeEmbedding and the per-block time_emb Linear, UNetCF.py:35-44) runs on the side stream beside the last
+ *                          weight-gradient launch; 0: behind it on the caller's stream.  Same gradients bit for bit either way. */
+enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2 };
 int dsg_set_option(dsg_handle* h, int option, int value);
 
 /* Pre-size the workspace for up to `max_rows` batch rows and `max_entries` time-table rows. */

@@ -862,6 +862,39 @@ def test_train_step_large_launch_split_vs_exact_f32():
     assert errs[worst] <= GTOL, (worst, errs[worst])
 
 
+def test_time_path_beside_the_last_weight_gradient_launch_gives_the_same_bits():
+    """dsg_set_option(DSG_OPT_TRAIN_TIME_BESIDE): at the BASELINE training shape the time-path backward runs on the side stream beside
+    the last weight-gradient launch and delivers its results through slab 0 of the fixed-order reduce; loss and every gradient --
+    the TimeEmbedding's and the per-block time_emb Linears' included -- are bit-identical to the serial order, step after step."""
+    name, B, T = "msr80", 32768 + 17, 20
+    plan, p = synth_params(name, 13)
+    ddpm = make_ddpm(name, p, T)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(4)
+    y = (torch.rand(B, cfg["input_dim"], generator=g) * 0.25).cuda()
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    for rnd in range(2):
+        ts = torch.randint(0, T, (1, B), generator=g).cuda()
+        noise = torch.randn(B, cfg["input_dim"], generator=g).cuda()
+        mask = (torch.rand(B, 1, generator=g) < 0.9).float().cuda()
+        first = None
+        for v in (1, 0, 1):
+            ddpm.model.set_option("train_time_beside", v)
+            for q in ddpm.model.parameters():
+                q.grad = None
+            loss = ddpm(y, cond, ts=ts, noise=noise, cond_mask=mask)
+            loss.backward()
+            got = (float(loss.detach()), {k: q.grad.detach().clone() for k, q in ddpm.model.named_parameters()})
+            if first is None:
+                first = got
+                continue
+            assert got[0] == first[0], (rnd, v)
+            for k in first[1]:
+                assert torch.equal(got[1][k], first[1][k]), (rnd, v, k)
+        time_w = [k for k in first[1] if "time" in k and k.endswith("weight")]
+        assert time_w and all(float(first[1][k].abs().max()) > 0 for k in time_w)
+
+
 @pytest.mark.parametrize("name,B", [("msr80", 100), ("co3", 77)])
 def test_train_step_exact_f32_mode(name, B):
     """precision="f32": exact f32 MFMA forward, data gradients and weight gradients (k_resblock_bwd / k_wgrad), same oracle."""
