@@ -206,6 +206,7 @@ struct dsg_handle {
     int v8_lo = -1, v8_hi = -1;
     bool opt_v8 = true;
     bool opt_time_beside = true;       // dsg_set_option(DSG_OPT_TRAIN_TIME_BESIDE): see the tail of dsg_train_step
+    int opt_wgrad_form = 1;            // dsg_set_option(DSG_OPT_WGRAD_FORM)
     // the section's image in global memory (V8SecL layout: raw nn.Linear matrices and parameter vectors), gathered at every bind; the LDS
     // form of the narrow run stages it as one piece, small launches and the training forward read it from L1 / L2
     float* v8_image = nullptr; NarrowLdsCopy* v8_copies_dev = nullptr; int v8_ncopies = 0;
@@ -2000,6 +2001,7 @@ int dsg_set_option(dsg_handle* h, int option, int value) {
             }
             return 0;
         case DSG_OPT_TRAIN_TIME_BESIDE: h->opt_time_beside = value != 0; return 0;
+        case DSG_OPT_WGRAD_FORM: h->opt_wgrad_form = value != 0; return 0;
         default: return fail("dsg_set_option: unknown option %d", option);
     }
 }
@@ -2345,7 +2347,7 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
             hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, h->side_stream, h->tr_gmax_t, h->gmax_ld, gm);
             if (u1 > u0)
                 hipLaunchKernelGGL(k_wgrad_h, dim3(u1 - u0), dim3(256), h->wg_early_lds, h->side_stream, h->wg_desc_dev, h->wg_unit_dev + u0,
-                                   gm, h->tr_slabs, h->slab_stride, tiles, h->tr_chunks);
+                                   gm, h->tr_slabs, h->slab_stride, tiles, h->tr_chunks, h->opt_wgrad_form);
             ++next_part;
         }
         return 0;
@@ -2394,7 +2396,7 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
     auto units = [&](int lo, int hi, const unsigned* gm, hipStream_t us) {
         if (hi > lo)
             hipLaunchKernelGGL(k_wgrad_h, dim3(hi - lo), dim3(256), 0, us, h->wg_desc_dev, h->wg_unit_dev + lo, gm, h->tr_slabs, h->slab_stride,
-                               tiles, h->tr_chunks);
+                               tiles, h->tr_chunks, h->opt_wgrad_form);
     };
     const int u0 = next_part ? h->wg_part_end[next_part - 1] : 0;
     if (time_beside) {

@@ -254,6 +254,21 @@ struct Seg {
 };
 __device__ __forceinline__ int seg_tile(const Seg& s, int tile) { return (s.wrap && tile >= s.wrap) ? tile - s.wrap : tile; }
 
+// A pointer that a kernel reads from a descriptor TABLE in memory (operator tables of the fused narrow kernels, the weight-gradient
+// descriptors) is a generic pointer to hipcc, and every access through it becomes a FLAT instruction.  A FLAT access counts on the
+// LDS counter as well as on the vector-memory counter and may return out of order with LDS data, so hipcc waits for ALL of a wave's
+// outstanding memory operations at every LDS read that follows one -- the prefetches of these latency-bound kernels stopped
+// overlapping with anything that touched LDS.  as_global() declares such a pointer global: an address-space cast there and back
+// with an empty asm in between (hipcc folds a bare round trip away; behind the asm it infers the address space of every access
+// and also keeps the base in scalar registers: `global_load v, v_off, s[base]`).  No instruction is emitted.  The pointer must be
+// wave-uniform (a descriptor field is) and must not have been redirected to LDS; globalize() does it for a descriptor's pointers.
+template <typename T> __device__ __forceinline__ T* as_global(T* p) {
+    auto g = (__attribute__((address_space(1))) T*)p;
+    asm("" : "+s"(g));
+    return (T*)g;
+}
+__device__ __forceinline__ void globalize(Seg& s) { s.data = as_global(s.data); s.stats = as_global(s.stats); }
+
 // ---------------------------------------------------------------------------------------------
 // ResidualBlock forward (UNetCF.py:83-95), one wave per 32-row tile:
 //   h1 = W1 silu(LN1(x)) + [b1 + time bias]           time bias row chosen by step (sampling) or ts[row]
@@ -297,6 +312,18 @@ struct BlockArgs {
     // float divisions per wave and block otherwise (~30 VALU; the narrow blocks have ~170 VALU of real work)
     float chan_w, chan_f, inv_nin;
 };
+// tensors, indices and flags (what stays in global memory when a kernel keeps the block's planes and vectors in LDS) / the rest
+__device__ __forceinline__ void globalize_io(BlockArgs& a) {
+    globalize(a.in0); globalize(a.in1);
+    a.step_ptr = as_global(a.step_ptr); a.ts = as_global(a.ts); a.condfrag = as_global(a.condfrag); a.cond_pre = as_global(a.cond_pre);
+    a.out = as_global(a.out); a.out_stats = as_global(a.out_stats); a.save_h1 = as_global(a.save_h1); a.save_h2 = as_global(a.save_h2);
+    a.range_flag = as_global(a.range_flag);
+}
+__device__ __forceinline__ void globalize_params(BlockArgs& a) {
+    a.W1 = as_global(a.W1); a.gamma1 = as_global(a.gamma1); a.beta1 = as_global(a.beta1); a.tbias = as_global(a.tbias);
+    a.W2 = as_global(a.W2); a.gamma2 = as_global(a.gamma2); a.beta2 = as_global(a.beta2); a.c2 = as_global(a.c2); a.Wc = as_global(a.Wc);
+    a.W3 = as_global(a.W3); a.gamma3 = as_global(a.gamma3); a.beta3 = as_global(a.beta3); a.c3 = as_global(a.c3); a.Wsc = as_global(a.Wsc);
+}
 
 template <int N, bool SCLIN>
 __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile, const int lane) {
@@ -463,6 +490,13 @@ struct LinArgs {
     int* range_flag;        // split path: see BlockArgs::range_flag
     float inv_in_w, inv_out_w;   // 1 / in_width, 1 / out_width (host)
 };
+__device__ __forceinline__ void globalize_io(LinArgs& a) {
+    globalize(a.in); a.in_rm = as_global(a.in_rm); a.out = as_global(a.out); a.out_stats = as_global(a.out_stats); a.out_rm = as_global(a.out_rm);
+    a.advance_step = as_global(a.advance_step); a.range_flag = as_global(a.range_flag);
+}
+__device__ __forceinline__ void globalize_params(LinArgs& a) {
+    a.W = as_global(a.W); a.bias = as_global(a.bias); a.gamma = as_global(a.gamma); a.beta = as_global(a.beta);
+}
 
 enum { IN_FRAG = 0, IN_ROWMAJOR = 1 };
 enum { OUT_FRAG = 0, OUT_ROWMAJOR = 1 };

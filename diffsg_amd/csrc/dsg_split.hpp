@@ -349,6 +349,13 @@ struct BlockArgsH {
     const float* kc;         // device: { 2^-e1 / 16, 2^-e2 / 16, 2^-e3 / 16 } of this block, computed ONCE at bind time (by k_pack_h)
                              // from the same max|W| -- scale_exp is a log2 + floor + ldexp per stage, per wave, per block otherwise
 };
+// (dsg_kernels.hpp, as_global) LDS == true: the planes and vectors were redirected to an LDS image, only the rest is global
+template <bool LDS>
+__device__ __forceinline__ void globalize(BlockArgsH& a) {
+    globalize_io(a.b);
+    a.m1 = as_global(a.m1); a.m2 = as_global(a.m2); a.m3 = as_global(a.m3); a.msc = as_global(a.msc); a.kc = as_global(a.kc);
+    if (!LDS) { globalize_params(a.b); a.W1h = as_global(a.W1h); a.W2h = as_global(a.W2h); a.W3h = as_global(a.W3h); a.Wsch = as_global(a.Wsch); }
+}
 
 // Needs cond_pre: the condition embedding Wc silu(cond*mask) is precomputed per call (sampling) or per step (training)
 // and added here, never multiplied.
@@ -870,6 +877,13 @@ struct LinArgsH {
     const float* m;    // max|W|
     const float* kc;   // device: { 2^-e (raw operand), 2^-e / 16 (LayerNorm + SiLU operand) } (written by k_pack_h)
 };
+template <bool LDS>      // LDS: Wh and the bias were redirected to an LDS image
+__device__ __forceinline__ void globalize(LinArgsH& a) {
+    globalize_io(a.l);
+    a.m = as_global(a.m); a.kc = as_global(a.kc);
+    a.l.W = as_global(a.l.W); a.l.gamma = as_global(a.l.gamma); a.l.beta = as_global(a.l.beta);
+    if (!LDS) { a.l.bias = as_global(a.l.bias); a.Wh = as_global(a.Wh); }
+}
 
 // Bind-time constants of the split path: the un-scale factors of every block and Linear from max|W| (same arithmetic as the
 // kernels used per wave before: scale_exp / scale_exp_lin3 + ldexp).
@@ -1151,9 +1165,11 @@ struct V8TableSave {
     const FusedOpH* ops;          // the section's first operator (the Downsample Linear); block blk is ops[1 + blk]
     int tile, lane;
     bool on;
-    __device__ __forceinline__ void put(float* dst, const float (&v)[4]) const { st4(dst + (size_t)tile * 256 + lane * 4, make_float4(v[0], v[1], v[2], v[3])); }
+    __device__ __forceinline__ void put(float* dst, const float (&v)[4]) const {
+        st4(as_global(dst) + (size_t)tile * 256 + lane * 4, make_float4(v[0], v[1], v[2], v[3]));
+    }
     __device__ __forceinline__ void stats(float* dst, float mean, float m2) const {
-        if (lane < 32) reinterpret_cast<float2*>(dst)[(size_t)tile * 32 + lane] = make_float2(mean, m2);
+        if (lane < 32) reinterpret_cast<float2*>(as_global(dst))[(size_t)tile * 32 + lane] = make_float2(mean, m2);
     }
     __device__ __forceinline__ void h1(int blk, const float (&v)[4]) const { if (on && ops[1 + blk].b.b.save_h1) put(ops[1 + blk].b.b.save_h1, v); }
     __device__ __forceinline__ void h2(int blk, const float (&v)[4]) const { if (on && ops[1 + blk].b.b.save_h2) put(ops[1 + blk].b.b.save_h2, v); }
@@ -1194,7 +1210,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
 #pragma unroll
             for (int G = 0; G < 4; ++G) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (G < 2) v = ld4(la.in.data + ((size_t)seg_tile(la.in, tile) * 2 + G) * 256 + lane * 4);
+                if (G < 2) v = ld4(as_global(la.in.data) + ((size_t)seg_tile(la.in, tile) * 2 + G) * 256 + lane * 4);
                 x[0][4 * G] = v.x; x[0][4 * G + 1] = v.y; x[0][4 * G + 2] = v.z; x[0][4 * G + 3] = v.w;
             }
             have_x = true;
@@ -1204,13 +1220,13 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
             if (b0.ts) {
                 int row = (tile % b0.tiles_per_pass) * 32 + j;
                 row = row < b0.nrows ? row : b0.nrows - 1;
-                entry = b0.ts[row];
+                entry = as_global(b0.ts)[row];
             } else if (b0.step_ptr) {
-                entry = *b0.step_ptr;
+                entry = *as_global(b0.step_ptr);
             }
         }
-        const V8Sec sc{b0.cond_pre, (long long)(b1.cond_pre - b0.cond_pre), b0.tiles_per_pass, b0.uncond_tiles};
-        const float* const tb0 = b0.tbias + (size_t)entry * b0.tb_stride;      // this lane's row of the time table, the first block's slice
+        const V8Sec sc{as_global(b0.cond_pre), (long long)(b1.cond_pre - b0.cond_pre), b0.tiles_per_pass, b0.uncond_tiles};
+        const float* const tb0 = as_global(b0.tbias) + (size_t)entry * b0.tb_stride;      // this lane's row of the time table, the first block's slice
         const float xi[8] = {x[0][0], x[0][1], x[0][2], x[0][3], x[0][4], x[0][5], x[0][6], x[0][7]};
         float xo[8];
         const V8TableSave sv{ops + i, tile, lane, v8_store != 0};
@@ -1219,10 +1235,10 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
         const FusedOpH& lz = ops[i + v8_nops - 1];
         if (lz.store_out) {                          // the Upsample output is read from memory by somebody (training: the backward pass)
             const LinArgs& a = lz.l.l;
-            if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
+            if (h == 0) reinterpret_cast<float2*>(as_global(a.out_stats))[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
 #pragma unroll
             for (int G = 0; G < 2; ++G)
-                st4(a.out + ((size_t)tile * 2 + G) * 256 + lane * 4, make_float4(x[0][4 * G], x[0][4 * G + 1], x[0][4 * G + 2], x[0][4 * G + 3]));
+                st4(as_global(a.out) + ((size_t)tile * 2 + G) * 256 + lane * 4, make_float4(x[0][4 * G], x[0][4 * G + 1], x[0][4 * G + 2], x[0][4 * G + 3]));
         }
         i += v8_nops;
     }
@@ -1239,14 +1255,16 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
             if (b0.ts) {
                 int row = (tile % b0.tiles_per_pass) * 32 + j;
                 row = row < b0.nrows ? row : b0.nrows - 1;
-                entry = b0.ts[row];
+                entry = as_global(b0.ts)[row];
             } else if (b0.step_ptr) {
-                entry = *b0.step_ptr;
+                entry = *as_global(b0.step_ptr);
             }
         }
         if (op.kind == 0) {
+            BlockArgsH b = op.b;              // every pointer of the record is global (dsg_kernels.hpp, as_global)
+            globalize<false>(b);
             if (!have_x) {  // first operator of the run: bring its (<= 32 wide) input into registers once
-                const Seg& s0 = op.b.b.in0;
+                const Seg& s0 = b.b.in0;
                 const float2 st = reinterpret_cast<const float2*>(s0.stats)[(size_t)seg_tile(s0, tile) * 32 + j];
                 xmean = st.x; xm2 = st.y;
 #pragma unroll
@@ -1258,29 +1276,31 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
                 have_x = true;
             }
             // skip tensors were stored by this wave earlier in the run: make sure those stores have landed
-            if (op.b.b.in1.groups) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (b.b.in1.groups) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const bool st = op.store_out != 0;
             const int N = (V8NB > 0 && op.N < 16) ? 16 : op.N;     // with the float32 section every 8-wide block is inside it
             if (op.sclin) {
                 switch (N) {
-                    case 4: if (V8NB == 0) resblock_body_h<4, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
-                    case 8: if (V8NB == 0) resblock_body_h<8, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
-                    case 16: resblock_body_h<16, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
-                    default: resblock_body_h<32, true, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 4: if (V8NB == 0) resblock_body_h<4, true, true, true, PRE>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, true, true, true, PRE>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 16: resblock_body_h<16, true, true, true, PRE>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    default: resblock_body_h<32, true, true, true, PRE>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                 }
             } else {
                 switch (N) {
-                    case 4: if (V8NB == 0) resblock_body_h<4, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
-                    case 8: if (V8NB == 0) resblock_body_h<8, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
-                    case 16: resblock_body_h<16, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
-                    default: resblock_body_h<32, false, true, true, PRE>(op.b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 4: if (V8NB == 0) resblock_body_h<4, false, true, true, PRE>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, false, true, true, PRE>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    case 16: resblock_body_h<16, false, true, true, PRE>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
+                    default: resblock_body_h<32, false, true, true, PRE>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, entry); break;
                 }
             }
         } else if (!have_x || op.l.l.in_groups > 4) {
             // Linear whose input is wider than one tile (the entry of the run): memory in, memory out, then reload
-            linear_body_h<1, IN_FRAG, OUT_FRAG, false>(op.l, tile, lane);
+            LinArgsH l = op.l;
+            globalize<false>(l);
+            linear_body_h<1, IN_FRAG, OUT_FRAG, false>(l, tile, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const LinArgs& a = op.l.l;
+            const LinArgs& a = l.l;
             const int NG = (a.out_width + 7) / 8;
             const float2 st = reinterpret_cast<const float2*>(a.out_stats)[(size_t)tile * 32 + j];
             xmean = st.x; xm2 = st.y;
@@ -1292,7 +1312,9 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
             }
             have_x = true;
         } else {
-            linear_reg_h(op.l, tile, lane, x, xmean, xm2, op.store_out != 0);
+            LinArgsH l = op.l;
+            globalize<false>(l);
+            linear_reg_h(l, tile, lane, x, xmean, xm2, op.store_out != 0);
         }
     }
     }
@@ -1384,14 +1406,14 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (G < 2) v = ld4(la.in.data + ((size_t)seg_tile(la.in, tile) * 2 + G) * 256 + lane * 4);
+                    if (G < 2) v = ld4(as_global(la.in.data) + ((size_t)seg_tile(la.in, tile) * 2 + G) * 256 + lane * 4);
                     x[0][4 * G] = v.x; x[0][4 * G + 1] = v.y; x[0][4 * G + 2] = v.z; x[0][4 * G + 3] = v.w;
                 }
                 have_x = true;
             }
             const BlockArgs& b0 = ops[i + 1].b.b;
             const BlockArgs& b1 = ops[i + 2].b.b;
-            const V8Sec sc{b0.cond_pre, (long long)(b1.cond_pre - b0.cond_pre), b0.tiles_per_pass, b0.uncond_tiles};
+            const V8Sec sc{as_global(b0.cond_pre), (long long)(b1.cond_pre - b0.cond_pre), b0.tiles_per_pass, b0.uncond_tiles};
             v8_lf* const S = (v8_lf*)(ldsf + ph.v8_sec);
             v8_lf* const tb0 = (v8_lf*)(ldsf + ph.v8_tb);
             const float xi[8] = {x[0][0], x[0][1], x[0][2], x[0][3], x[0][4], x[0][5], x[0][6], x[0][7]};
@@ -1400,10 +1422,10 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             x[0] = f32x16{xo[0], xo[1], xo[2], xo[3], xo[4], xo[5], xo[6], xo[7], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (ph.v8_store) {                       // the section ends the phase: hand the 16-wide tensor on through memory
                 const LinArgs& lz = ops[i + ph.v8_nops - 1].l.l;
-                if (h == 0) reinterpret_cast<float2*>(lz.out_stats)[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
+                if (h == 0) reinterpret_cast<float2*>(as_global(lz.out_stats))[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
 #pragma unroll
                 for (int G = 0; G < 2; ++G)
-                    st4(lz.out + ((size_t)tile * 2 + G) * 256 + lane * 4, make_float4(x[0][4 * G], x[0][4 * G + 1], x[0][4 * G + 2], x[0][4 * G + 3]));
+                    st4(as_global(lz.out) + ((size_t)tile * 2 + G) * 256 + lane * 4, make_float4(x[0][4 * G], x[0][4 * G + 1], x[0][4 * G + 2], x[0][4 * G + 3]));
             }
             i += ph.v8_nops;
         }
@@ -1423,6 +1445,7 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             b.b.gamma1 = ldsf + lo.g1; b.b.beta1 = ldsf + lo.b1; b.b.gamma2 = ldsf + lo.g2; b.b.beta2 = ldsf + lo.b2;
             b.b.gamma3 = ldsf + lo.g3; b.b.beta3 = ldsf + lo.b3; b.b.c2 = ldsf + lo.c2; b.b.c3 = ldsf + lo.c3;
             b.b.tbias = ldsf + lo.tb;            // the staged row of this step: entry 0
+            globalize<true>(b);
             if (!have_x) {  // first operator of the phase: bring its (<= 32 wide) input into registers once
                 const Seg& s0 = b.b.in0;
                 const float2 st = reinterpret_cast<const float2*>(s0.stats)[(size_t)seg_tile(s0, tile) * 32 + j];
@@ -1460,10 +1483,12 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             // the 64-wide Linear that consumes the run's last tensor (Upsample): input from registers, output to memory
             LinArgsH l = op.l;
             l.Wh = lds + lo.w1; l.l.bias = ldsf + lo.c2;
+            globalize<true>(l);
             linear_reg_out_h<2>(l, tile, lane, x, xmean, xm2);
         } else {
             LinArgsH l = op.l;
             l.Wh = lds + lo.w1; l.l.bias = ldsf + lo.c2;
+            globalize<true>(l);
             if (!have_x || l.l.in_groups > 4) {
                 // Linear whose input is wider than one tile (the entry of the run) or the first operator of a phase: memory in, memory
                 // out, then reload

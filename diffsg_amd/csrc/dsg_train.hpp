@@ -335,6 +335,16 @@ struct BlockBwdArgs {
     size_t cs_stride;
     int ntiles;
 };
+// (dsg_kernels.hpp, as_global) for records read from an operator table in memory
+__device__ __forceinline__ void globalize(BlockBwdArgs& a) {
+    globalize(a.in0); globalize(a.in1);
+    a.h1 = as_global(a.h1); a.h2 = as_global(a.h2); a.gout_a = as_global(a.gout_a); a.gout_b = as_global(a.gout_b);
+    a.W3T = as_global(a.W3T); a.W2T = as_global(a.W2T); a.W1T = as_global(a.W1T); a.WscT = as_global(a.WscT);
+    a.gamma1 = as_global(a.gamma1); a.beta1 = as_global(a.beta1); a.gamma2 = as_global(a.gamma2); a.beta2 = as_global(a.beta2);
+    a.gamma3 = as_global(a.gamma3); a.beta3 = as_global(a.beta3);
+    a.gin0 = as_global(a.gin0); a.gin1 = as_global(a.gin1); a.du1 = as_global(a.du1); a.dh1 = as_global(a.dh1); a.dh2 = as_global(a.dh2);
+    a.rs1 = as_global(a.rs1); a.rs2 = as_global(a.rs2); a.rs3 = as_global(a.rs3); a.cs = as_global(a.cs);
+}
 
 // The four data-gradient GEMMs of a block go through a policy object (`gemm.run<NGin, NTin, NTout>(out, in, which, accumulate)`,
 // which = 3, 2, 1 for W3^T, W2^T, W1^T and 0 for the Linear shortcut; o0 = first output tile): exact f32 MFMA here, split-f16 in dsg_train_split.hpp.
@@ -680,6 +690,10 @@ struct LinBwdArgs {
     float* rs;               // LNBWD only: (mean, rstd)
     int ntiles;
 };
+__device__ __forceinline__ void globalize(LinBwdArgs& a) {
+    a.gout_a = as_global(a.gout_a); a.gout_b = as_global(a.gout_b); a.WT = as_global(a.WT); globalize(a.in);
+    a.gamma = as_global(a.gamma); a.beta = as_global(a.beta); a.gin = as_global(a.gin); a.du = as_global(a.du); a.rs = as_global(a.rs);
+}
 
 template <int OT, bool LNBWD>
 __device__ __forceinline__ void linear_bwd_body(const LinBwdArgs& a, int tile, int lane) {
@@ -1012,10 +1026,11 @@ struct ColsumUnit { int desc; int group; int chunk; int pad; };
 __global__ __launch_bounds__(256) void k_colsum(const ColsumDesc* __restrict__ descs, const ColsumUnit* __restrict__ units, int nunits,
                                                 float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks, int nrows,
                                                 unsigned* __restrict__ gmax_t, int gmax_ld) {
-    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: the descriptor lives in scalar registers
     if (u >= nunits) return;
     const ColsumUnit un = units[u];
-    const ColsumDesc d = descs[un.desc];
+    ColsumDesc d = descs[un.desc];
+    d.P0 = as_global(d.P0); d.P1 = as_global(d.P1); globalize(d.x0); globalize(d.x1); d.rs = as_global(d.rs);
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int G = un.group;
     const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;

@@ -167,12 +167,216 @@ __device__ __forceinline__ void wgrad_unit_h(const WgradDesc& d, const WgradUnit
     }
 }
 
+// ---- TB == 1 units (out tiles NTp in {2, 4}), round-4 form.  The kernel is bound by the number of instructions a wave issues per
+// 32-row interval, not by the matrix cores (measured with the pieces switched off one at a time, profiles/r04_wgrad_switches.txt: MFMAs
+// 5 %, operand transforms 37 %, loop skeleton and addressing 35 %), so this form issues about half of them:
+//   * the image is ROW-major, [32 batch rows][128 features] f16 per plane, 256-byte rows with the 16-byte chunks XOR-swizzled
+//     (cdna_hip_programming.md T10, image (b)): a lane of the fragment layout stores its four features of its row as ONE 8-byte
+//     write per plane -- no lane exchange, no byte permutes -- and the MFMA operand (feature i, rows 16 s + 8 h + 0..7) is two
+//     transposing reads (ds_read_b64_tr_b16) per plane, conflict-free;
+//   * everything that does not depend on the tile is computed once per unit: item sources (base + tile * stride), write
+//     offsets, read addresses (the k16-step and the plane are instruction offsets), LayerNorm vectors (staged in LDS);
+//   * groups that belong to the image but hold nothing (padding of N or K to a tile) are zeroed once, not per interval.
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s4v lds_s4;
+__device__ __forceinline__ unsigned wimg_off(unsigned row, unsigned ch) { return 256u * row + 16u * (ch ^ (((row & 3u) << 2) | ((row >> 2) & 3u))); }
+__device__ __forceinline__ h8 wimg_tr8(const char* p0, const char* p1) {
+    const s4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)const_cast<char*>(p0));
+    const s4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)const_cast<char*>(p1));
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    const s8v r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(h8, r);
+}
+constexpr unsigned kWimgGH = 0, kWimgGL = 8192, kWimgAH = 16384, kWimgAL = 24576, kWimgVec = 32768;   // byte offsets of the planes, + 1 KiB of vectors
+
+struct WgradRegs { float4 g0[4], av[4]; float2 ms; int oh; };   // one interval's raw operands of a wave (k_wgrad_h, TB == 1 form)
+
+__device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUnit& un, char* __restrict__ img, f32x16 (&acc)[4], float gscale,
+                                              int ntiles, int nchunks, int wave, int lane, int NTp, int KT, int g_lo, int ngr, int my_nt,
+                                              int my_part, int rsplit) {
+    const int h = lane >> 5, j = lane & 31;
+    const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+    const int t_lo = un.chunk * tiles_per_chunk;
+    const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
+    const int ngg = NTp * 4, nag = KT * 4;   // groups held by the images
+    const int mode = d.amode;
+    const bool hasg1 = d.G1 != nullptr;
+    float* const gam = reinterpret_cast<float*>(img + kWimgVec);
+    float* const bet = gam + 128;
+    if (mode == A_LNSILU && threadIdx.x < 128) {
+        const int f = threadIdx.x, ok = (f >> 3) < ngr;
+        gam[f] = ok ? d.gamma[8 * g_lo + f] : 0.f;
+        bet[f] = ok ? d.beta[8 * g_lo + f] : 0.f;
+    }
+    // this wave's items: feature group wave + 4 i of G and of the k-block of A; the write offset is the same for both.  An item that
+    // does not exist (N or K end inside the tile) still LOADS -- from the wave's first item / the block's last group, a line that is
+    // being read anyway -- so that the loads of an interval are one straight run of instructions; only its transform is skipped.
+    const unsigned sw = (((unsigned)j & 3u) << 2) | (((unsigned)j >> 2) & 3u);
+    unsigned wofs[4];
+    bool gok[4], aok[4];
+    size_t goff[4];                // uniform offsets (floats): the lane's part is added at the load (scalar base + vector offset)
+    const float* ap[4];            // uniform
+    size_t astr[4];
+    const unsigned lane4 = lane * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = wave + 4 * i;
+        wofs[i] = 256u * j + 16u * ((unsigned)g ^ sw) + 8u * h;
+        gok[i] = g < d.NG && g < ngg;
+        aok[i] = g < nag && g < ngr;
+        goff[i] = (size_t)(gok[i] ? g : wave) * 256;
+        const int G = g_lo + (g < ngr ? g : ngr - 1);
+        const bool first = G < d.a0.groups;
+        const Seg& sg = first ? d.a0 : d.a1;
+        ap[i] = mode == A_ONEHOT ? d.G0 : sg.data + (size_t)(first ? G : G - d.a0.groups) * 256;   // one-hot: nothing to read, any valid line
+        astr[i] = mode == A_ONEHOT ? 0 : (size_t)sg.groups * 256;
+        // padding groups of the image: zero, once
+        const uint2 z = make_uint2(0u, 0u);
+        if (g < ngg && !gok[i]) { *reinterpret_cast<uint2*>(img + kWimgGH + wofs[i]) = z; *reinterpret_cast<uint2*>(img + kWimgGL + wofs[i]) = z; }
+        if (g < nag && !aok[i]) { *reinterpret_cast<uint2*>(img + kWimgAH + wofs[i]) = z; *reinterpret_cast<uint2*>(img + kWimgAL + wofs[i]) = z; }
+    }
+    const size_t gstr = (size_t)d.NG * 256;
+    // operand reads: lane 4 q + p of a 16-lane group supplies row q, features 4 p .. 4 p + 3 of its block; the lane's group takes
+    // features 16 sub .. + 15 of the tile and rows 8 h + 4 e .. + 3 of the step (e = 0, 1: elements 0-3, 4-7 of the operand)
+    const unsigned li = lane & 15, q = li >> 2, pp = li & 3, sub = (lane >> 4) & 1;
+    const char* rb[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        rb[e] = img + 256u * (8u * h + 4u * e + q) + 16u * ((2u * sub + (pp >> 1)) ^ ((2u * h + e) & 3u)) + 8u * (pp & 1u);
+    const unsigned tq_g = 64u * ((unsigned)my_nt ^ q);
+    unsigned tq_a[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) tq_a[kt] = 64u * ((unsigned)kt ^ q);
+
+    // The second gradient tensor (a skip consumer's: few descriptors) is read one interval ahead only; where there is none the loads
+    // repeat the first tensor's lines and a zero factor drops them -- every load of an interval is unconditional, so that no register
+    // has two reaching definitions (hipcc resolved those with copies behind vmcnt(0) waits).
+    float4 g1[4];
+    const float* const G1p = hasg1 ? d.G1 : d.G0;
+    const float g1s = hasg1 ? gscale : 0.f;
+    auto fetch_g1 = [&](int t) {
+        const float* const gb = G1p + (size_t)t * gstr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g1[i] = ld4(gb + goff[i] + lane4);
+    };
+    auto fetch = [&](WgradRegs& R, int t) {
+        const float* const gb = d.G0 + (size_t)t * gstr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R.g0[i] = ld4(gb + goff[i] + lane4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R.av[i] = ld4(ap[i] + (size_t)t * astr[i] + lane4);
+        if (mode == A_ONEHOT) {
+            const int row = t * 32 + j;
+            R.oh = d.ts[row < d.nrows ? row : d.nrows - 1];
+        }
+        if (mode == A_LNSILU) R.ms = reinterpret_cast<const float2*>(d.rs)[(size_t)t * 32 + j];
+    };
+    auto put = [&](unsigned plane_hi, unsigned plane_lo, unsigned off, const float4 v) {
+        unsigned h01, h23, l01, l23;
+        split_pair(v.x, v.y, h01, l01);
+        split_pair(v.z, v.w, h23, l23);
+        *reinterpret_cast<uint2*>(img + plane_hi + off) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(img + plane_lo + off) = make_uint2(l01, l23);
+    };
+    auto stage = [&](const WgradRegs& R, int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (gok[i]) {
+                // (g0 + g1) * 2^e as g0 * 2^e + g1 * 2^e: the scale is a power of two, the same bits
+                const float4 v = R.g0[i];
+                put(kWimgGH, kWimgGL, wofs[i], make_float4(fmaf(g1[i].x, g1s, v.x * gscale), fmaf(g1[i].y, g1s, v.y * gscale),
+                                                           fmaf(g1[i].z, g1s, v.z * gscale), fmaf(g1[i].w, g1s, v.w * gscale)));
+            }
+        const bool live = t * 32 + j < d.nrows;        // forward tensors of padded rows are not zero
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (aok[i]) {
+                float4 v;
+                if (mode == A_ONEHOT) {
+                    const int e = R.oh, f = 8 * (g_lo + wave + 4 * i) + 4 * h;
+                    v = make_float4(e == f ? 1.f : 0.f, e == f + 1 ? 1.f : 0.f, e == f + 2 ? 1.f : 0.f, e == f + 3 ? 1.f : 0.f);
+                } else if (mode == A_LNSILU) {
+                    const float4 x = R.av[i];
+                    const float4 gm = *reinterpret_cast<const float4*>(gam + 8 * (wave + 4 * i) + 4 * h);
+                    const float4 bt = *reinterpret_cast<const float4*>(bet + 8 * (wave + 4 * i) + 4 * h);
+                    const float c = R.ms.y, dd = -R.ms.x * R.ms.y;
+                    v = make_float4(silu_scaled(fmaf(fmaf(x.x, c, dd), gm.x, bt.x)), silu_scaled(fmaf(fmaf(x.y, c, dd), gm.y, bt.y)),
+                                    silu_scaled(fmaf(fmaf(x.z, c, dd), gm.z, bt.z)), silu_scaled(fmaf(fmaf(x.w, c, dd), gm.w, bt.w)));
+                } else {
+                    const float4 x = R.av[i];
+                    v = make_float4(kRawScale * x.x, kRawScale * x.y, kRawScale * x.z, kRawScale * x.w);
+                }
+                if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                put(kWimgAH, kWimgAL, wofs[i], v);
+            }
+    };
+    // the MFMAs of an interval.  The k tiles go in pairs, a pair's four plane reads ahead of its six MFMAs; the second tile of a
+    // pair may lie beyond KT: its accumulator then collects whatever the image holds there and is never written out.
+    auto mma = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (rsplit == 2 && s != my_part) continue;      // two waves per out tile: one k16-step each
+            const h8 ghi = wimg_tr8(rb[0] + tq_g + (kWimgGH + 4096u * s), rb[1] + tq_g + (kWimgGH + 4096u * s));
+            const h8 glo = wimg_tr8(rb[0] + tq_g + (kWimgGL + 4096u * s), rb[1] + tq_g + (kWimgGL + 4096u * s));
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2)
+                if (kp < KT) {
+                    h8 ahi[2], alo[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        ahi[k] = wimg_tr8(rb[0] + tq_a[kp + k] + (kWimgAH + 4096u * s), rb[1] + tq_a[kp + k] + (kWimgAH + 4096u * s));
+                        alo[k] = wimg_tr8(rb[0] + tq_a[kp + k] + (kWimgAL + 4096u * s), rb[1] + tq_a[kp + k] + (kWimgAL + 4096u * s));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        DSG_MFMA_H(acc[kp + k], ghi, ahi[k]);
+                        DSG_MFMA_H(acc[kp + k], ghi, alo[k]);
+                        DSG_MFMA_H(acc[kp + k], glo, ahi[k]);
+                    }
+                }
+        }
+    };
+    // Two register sets: the loads of interval t + 2 are issued when interval t's MFMAs start and are read a whole interval
+    // later (one set gave them the MFMA phase only: ~1 000 cycles against >= 2 000 of memory latency).  Every fetch is
+    // unconditional -- past the chunk's end it re-reads the last tile -- so that no register of a set has two reaching definitions.
+    WgradRegs R0, R1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g1[i] = R0.av[i] = R1.av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    R0.ms = R1.ms = make_float2(0.f, 0.f); R0.oh = R1.oh = -1;
+    __syncthreads();                         // the LayerNorm vectors
+    if (t_lo >= t_hi) return;
+    const int t_last = t_hi - 1;
+    auto clampt = [&](int t) { return t < t_last ? t : t_last; };
+    fetch(R0, t_lo); fetch_g1(t_lo);
+    fetch(R1, clampt(t_lo + 1));
+    stage(R0, t_lo);
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; t += 2) {
+        // image: tile t; R1: tile t + 1; R0: free
+        fetch(R0, clampt(t + 2));
+        fetch_g1(clampt(t + 1));
+        mma();
+        __syncthreads();                     // everyone is done reading the image
+        if (t + 1 < t_hi) stage(R1, t + 1);
+        __syncthreads();
+        // image: tile t + 1; R0: tile t + 2; R1: free
+        fetch(R1, clampt(t + 3));
+        fetch_g1(clampt(t + 2));
+        if (t + 1 < t_hi) mma();
+        __syncthreads();
+        if (t + 2 < t_hi) stage(R0, t + 2);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void k_wgrad_h(const WgradDesc* __restrict__ descs, const WgradUnit* __restrict__ units,
                                                  const unsigned* __restrict__ gmax, float* __restrict__ slabs, size_t slab_stride, int ntiles,
-                                                 int nchunks) {
-    __shared__ __attribute__((aligned(16))) _Float16 img[kWhLdsHalfs];
+                                                 int nchunks, int form) {
+    __shared__ __attribute__((aligned(16))) _Float16 img[kWhLdsHalfs];     // >= the 33 KiB of the TB == 1 form
     const WgradUnit un = units[blockIdx.x];
-    const WgradDesc d = descs[un.desc];
+    WgradDesc d = descs[un.desc];
+    d.G0 = as_global(d.G0); d.G1 = as_global(d.G1); globalize(d.a0); globalize(d.a1);          // dsg_kernels.hpp, as_global
+    d.rs = as_global(d.rs); d.gamma = as_global(d.gamma); d.beta = as_global(d.beta); d.ts = as_global(d.ts);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
     const int NT = (d.N + 31) / 32;
@@ -191,7 +395,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h(const WgradDesc* __restrict_
     f32x16 acc[4];
     acc_zero<4>(acc);
     if (NTp == 1) wgrad_unit_h<2>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
-    else wgrad_unit_h<1>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+    else if (form == 0) wgrad_unit_h<1>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+    else wgrad_unit_h1(d, un, reinterpret_cast<char*>(img), acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
 
     // ---- waves that split the rows of one n-tile add their partial tiles through LDS, then the first writes the slab
     if (rsplit > 1) {
@@ -248,6 +453,11 @@ struct BlockBwdArgsH {
     unsigned* gmax_t; int gmax_ld;                    // per-tile max|G| words [slot][tile] (operand scales of k_wgrad_h)
     int slot_out, slot_h2, slot_h1;                   // slots of dout, dh2, dh1
 };
+__device__ __forceinline__ void globalize(BlockBwdArgsH& a) {
+    globalize(a.b);
+    a.W3Th = as_global(a.W3Th); a.W2Th = as_global(a.W2Th); a.W1Th = as_global(a.W1Th); a.WscTh = as_global(a.WscTh);
+    a.m1 = as_global(a.m1); a.m2 = as_global(a.m2); a.m3 = as_global(a.m3); a.msc = as_global(a.msc); a.gmax_t = as_global(a.gmax_t);
+}
 
 template <int NT>
 __device__ __forceinline__ void row_scale(const f32x16 (&g)[NT], float& s, float& sinv, unsigned& mbits) {
@@ -730,24 +940,28 @@ __global__ __launch_bounds__(256, 2) void k_fused_narrow_bwd_h(const FusedBwdOpH
         const FusedBwdOpH& op = ops[i];
         if (i) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous operator's stores (this wave's own) have landed
         if (op.kind == 0) {
+            BlockBwdArgsH b = op.b;           // every pointer of the record is global (dsg_kernels.hpp, as_global)
+            globalize(b);
             if (op.sclin) {
                 switch (op.N) {
-                    case 4: resblock_bwd_body<4, true, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
-                    case 8: resblock_bwd_body<8, true, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
-                    case 16: resblock_bwd_body<16, true, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
-                    default: resblock_bwd_body<32, true, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, true, tile}, tile, lane); break;
+                    case 4: resblock_bwd_body<4, true, BwdGemmSplit, true>(b.b, BwdGemmSplit{b, lane, true, tile}, tile, lane); break;
+                    case 8: resblock_bwd_body<8, true, BwdGemmSplit, true>(b.b, BwdGemmSplit{b, lane, true, tile}, tile, lane); break;
+                    case 16: resblock_bwd_body<16, true, BwdGemmSplit, true>(b.b, BwdGemmSplit{b, lane, true, tile}, tile, lane); break;
+                    default: resblock_bwd_body<32, true, BwdGemmSplit, true>(b.b, BwdGemmSplit{b, lane, true, tile}, tile, lane); break;
                 }
             } else {
                 switch (op.N) {
-                    case 4: resblock_bwd_body<4, false, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
-                    case 8: resblock_bwd_body<8, false, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
-                    case 16: resblock_bwd_body<16, false, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
-                    default: resblock_bwd_body<32, false, BwdGemmSplit, true>(op.b.b, BwdGemmSplit{op.b, lane, false, tile}, tile, lane); break;
+                    case 4: resblock_bwd_body<4, false, BwdGemmSplit, true>(b.b, BwdGemmSplit{b, lane, false, tile}, tile, lane); break;
+                    case 8: resblock_bwd_body<8, false, BwdGemmSplit, true>(b.b, BwdGemmSplit{b, lane, false, tile}, tile, lane); break;
+                    case 16: resblock_bwd_body<16, false, BwdGemmSplit, true>(b.b, BwdGemmSplit{b, lane, false, tile}, tile, lane); break;
+                    default: resblock_bwd_body<32, false, BwdGemmSplit, true>(b.b, BwdGemmSplit{b, lane, false, tile}, tile, lane); break;
                 }
             }
         } else {
-            if (op.ot <= 1) linear_bwd_body<1, false>(op.l, tile, lane);
-            else linear_bwd_body<2, false>(op.l, tile, lane);
+            LinBwdArgs l = op.l;
+            globalize(l);
+            if (op.ot <= 1) linear_bwd_body<1, false>(l, tile, lane);
+            else linear_bwd_body<2, false>(l, tile, lane);
         }
     }
 }

@@ -30,6 +30,14 @@ if os.environ.get("SPLIT_AB"):
             type(ddpm).train_split_min_rows = sp
             run(f"round {rnd}: B={B} train_split_min_rows={sp}")
     sys.exit(0)
+if os.environ.get("WGRAD_AB"):
+    # the two forms of the wide weight-gradient units (DSG_OPT_WGRAD_FORM)
+    FlatAdam.native_step = True; ddpm.device_draws = 1
+    for rnd in range(2):
+        for v in (0, 1):
+            ddpm.model.set_option("wgrad_form", v)
+            run(f"round {rnd}: B={B} wgrad_form={v}")
+    sys.exit(0)
 if os.environ.get("TIME_AB"):
     # the time-path backward beside the last weight-gradient launch (DSG_OPT_TRAIN_TIME_BESIDE) against behind it
     FlatAdam.native_step = True; ddpm.device_draws = 1
