@@ -207,6 +207,7 @@ struct dsg_handle {
     bool opt_v8 = true;
     bool opt_time_beside = true;       // dsg_set_option(DSG_OPT_TRAIN_TIME_BESIDE): see the tail of dsg_train_step
     int opt_wgrad_form = 1;            // dsg_set_option(DSG_OPT_WGRAD_FORM)
+    bool opt_wg_narrow_part = false;   // dsg_set_option(DSG_OPT_WGRAD_NARROW_PART); read when the descriptor tables are (re)built
     // the section's image in global memory (V8SecL layout: raw nn.Linear matrices and parameter vectors), gathered at every bind; the LDS
     // form of the narrow run stages it as one piece, small launches and the training forward read it from L1 / L2
     float* v8_image = nullptr; NarrowLdsCopy* v8_copies_dev = nullptr; int v8_ncopies = 0;
@@ -248,12 +249,13 @@ struct dsg_handle {
     // side_stream beside the rest of the activation-gradient chain, see dsg_train_step
     std::vector<int> wg_forks = {3, 6};
     std::vector<int> wg_part_end;      // units [wg_part_end[k-1], wg_part_end[k]) = part k; the rest runs on the caller's stream
+    long long* r2_dev = nullptr; int r2_n = 0; long long r2_total = 0;   // [starts | prefix]: the parameter ranges the last reduce covers
     int wg_onehot_end = 0;             // ... and opens with the final part's time-table units: [wg_part_end.back(), wg_onehot_end),
     int wg_blocks_end = 0;             // then its residual blocks' other units [wg_onehot_end, wg_blocks_end), then the plain Linears'
     std::vector<int> wg_fork_ops;      // operator index after whose backward kernel part k starts
     int wg_early_lds = 40960;
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t time_stream = nullptr; hipEvent_t ev_tail[2] = {nullptr, nullptr};   // the tail of dsg_train_step
+    hipStream_t time_stream = nullptr; hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr};   // the tail of dsg_train_step
     FusedBwdOpH* fbwd_dev = nullptr; int fbwd_n = 0;   // operator table of the fused narrow backward (split path), cached with the descriptors
     ColsumDesc* cs_desc_dev = nullptr; ColsumUnit* cs_unit_dev = nullptr; int cs_units = 0;
     // the descriptor tables depend only on (rows, T, precision mode) and the workspace addresses: built once, reused every step
@@ -1383,6 +1385,14 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
         }
         if (k < h->wg_forks.size())                   // fewer blocks than the last fork asks for: those stay in the final launch
             for (size_t i = 0; i < op_part.size(); ++i) if (op_part[i] == (int)k) op_part[i] = -1;
+        // one more part: the residual blocks of the fused narrow run (17 of MSR-80c's 27 blocks, ~2 700 small units).  Their backward is
+        // one launch (k_fused_narrow_bwd_h); behind it the chain still has the 64- and 128-wide down blocks to go.
+        if (k == h->wg_forks.size() && h->opt_wg_narrow_part && h->fuse_hi - h->fuse_lo >= 2 && (int)h->wg_fork_ops.size() < kMaxWgParts) {
+            int lowest = -1;
+            for (int oi = h->fuse_hi - 1; oi >= h->fuse_lo; --oi)
+                if (h->ops[oi].kind == OP_RES && op_part[oi + 1] < 0) { op_part[oi + 1] = (int)k; lowest = oi; }
+            if (lowest >= 0) h->wg_fork_ops.push_back(lowest);
+        }
     }
     std::vector<ColsumDesc> cd;
     std::vector<int> bwd_slots;        // slots tracked by the block backward kernels
@@ -1562,6 +1572,25 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
     HIPCK(hipMemcpyAsync(h->cs_unit_dev, cu.data(), cu.size() * sizeof(ColsumUnit), hipMemcpyHostToDevice, s));
     HIPCK(hipStreamSynchronize(s));  // host vectors go out of scope
     memcpy(h->td_key, key, sizeof key);
+    {   // the ranges of the flat gradient that the slabs hold: everything but what the time path produces (dsg_train_step)
+        std::vector<std::pair<long long, long long>> skip;
+        for (const ResP& r : h->res) skip.push_back({P[r.te.w].off, P[r.te.w].numel});
+        for (int pi : {h->temb_l1w, h->temb_l1b, h->temb_l2w, h->temb_l2b}) skip.push_back({P[pi].off, P[pi].numel});
+        std::sort(skip.begin(), skip.end());
+        std::vector<long long> tab;      // starts, then prefix sums
+        std::vector<long long> starts, prefix;
+        long long at = 0, acc = 0;
+        for (const auto& sk : skip) {
+            if (sk.first > at) { starts.push_back(at); prefix.push_back(acc); acc += sk.first - at; }
+            at = std::max(at, sk.first + sk.second);
+        }
+        if (h->total_params > at) { starts.push_back(at); prefix.push_back(acc); acc += h->total_params - at; }
+        h->r2_n = (int)starts.size(); h->r2_total = acc;
+        tab = starts; tab.insert(tab.end(), prefix.begin(), prefix.end());
+        if (h->r2_dev) (void)hipFree(h->r2_dev);
+        HIPCK(hipMalloc(&h->r2_dev, tab.size() * sizeof(long long)));
+        HIPCK(hipMemcpy(h->r2_dev, tab.data(), tab.size() * sizeof(long long), hipMemcpyHostToDevice));
+    }
     h->td_B = B; h->td_T = T; h->td_rows = h->tr_rows; h->td_split = h->use_split; h->td_valid = true;
     return 0;
 }
@@ -1756,7 +1785,7 @@ void dsg_destroy(dsg_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev, h->maxabs,
-                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->opc_desc_dev, h->opc_dev, h->fusedh_dev, h->fusedh_train_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->ce_dev, h->ctile_dev};
+                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->opc_desc_dev, h->opc_dev, h->fusedh_dev, h->fusedh_train_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->r2_dev, h->ce_dev, h->ctile_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -2002,6 +2031,9 @@ int dsg_set_option(dsg_handle* h, int option, int value) {
             return 0;
         case DSG_OPT_TRAIN_TIME_BESIDE: h->opt_time_beside = value != 0; return 0;
         case DSG_OPT_WGRAD_FORM: h->opt_wgrad_form = value != 0; return 0;
+        case DSG_OPT_WGRAD_NARROW_PART:
+            if ((value != 0) != h->opt_wg_narrow_part) { (void)hipDeviceSynchronize(); h->opt_wg_narrow_part = value != 0; h->td_valid = false; }
+            return 0;
         default: return fail("dsg_set_option: unknown option %d", option);
     }
 }
@@ -2382,13 +2414,13 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
     }
     // ---- weight / bias / LayerNorm gradients: grouped launches into per-chunk slabs, then a fixed-order reduce.
     // Small batches: everything in order on the caller's stream.  With the side stream (>= 32 768 rows) the tail runs on two streams:
-    //   caller's stream       max|G| of the blocks -> the blocks' units (ONE launch, longest first) ----------------> reduce (parameters)
-    //   time stream           time-table units -> column sums (k_cs_reduce, k_colsum) -> max|G| of everything ->      ^
-    //   (high priority)       the Linears' units -> [early parts done] -> reduce (dTB) -> time path ------------------+
+    //   caller's stream       max|G| of the blocks -> the blocks' units (ONE launch, longest first) -> the Linears' units -> reduce (parameters)
+    //   time stream           time-table units -> column sums (k_cs_reduce, k_colsum) -> max|G| of everything --^                ^
+    //   (high priority)       -> [early parts done] -> reduce (dTB) -> time path ----------------------------------------------+
     // A residual block's G operands have their scale from the block's own backward kernel; only the plain Linears' wait for k_colsum.
     // The time path (UNetCF.py:35-44 backward: ~10 short dependent launches) needs nothing but the dTB rows; its five results go
-    // into slab 0 at their parameters' offsets, which no unit writes and which are zero in every other slab
-    // (ensure_train_workspace clears the slabs once), so the one fixed-order reduce at the end delivers them with everything else.
+    // straight into the caller's gradient bucket, and the fixed-order reduce at the end covers every OTHER parameter
+    // (k_reduce_ranges: the time_emb weights are ~40 % of the parameters and nothing in the slabs belongs to them).
     mark(2);
     const bool time_beside = h->use_split && next_part > 0 && h->side_stream && h->opt_time_beside;
     hipStream_t cs_stream = time_beside ? h->time_stream : s;
@@ -2437,16 +2469,19 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
     };
     if (time_beside) {
         units(h->wg_onehot_end, h->wg_blocks_end, h->tr_gmax, s);
-        units(h->wg_blocks_end, h->wg_units, gm_all, h->time_stream);
+        HIPCK(hipEventRecord(h->ev_tail[2], h->time_stream));              // column sums done: the Linears' scales
+        HIPCK(hipStreamWaitEvent(s, h->ev_tail[2], 0));
+        units(h->wg_blocks_end, h->wg_units, gm_all, s);
         HIPCK(hipEventRecord(h->ev_join, h->side_stream));                 // the early parts: the other blocks' time-table units
         HIPCK(hipStreamWaitEvent(h->time_stream, h->ev_join, 0));
         hipLaunchKernelGGL(k_reduce_slabs, reduce_blocks(dtb_n), dim3(256), 0, h->time_stream, h->tr_slabs + dtb0, h->slab_stride, h->tr_chunks,
                            h->tr_gsum + dtb0, dtb_n);
-        time_path(h->tr_slabs, h->time_stream);
+        time_path(grads_flat, h->time_stream);       // straight into the caller's bucket: the last reduce leaves these regions out
         HIPCK(hipEventRecord(h->ev_tail[1], h->time_stream));
         HIPCK(hipStreamWaitEvent(s, h->ev_tail[1], 0));
         mark(4);
-        hipLaunchKernelGGL(k_reduce_slabs, reduce_blocks(dtb0), dim3(256), 0, s, h->tr_slabs, h->slab_stride, h->tr_chunks, grads_flat, dtb0);
+        hipLaunchKernelGGL(k_reduce_ranges, reduce_blocks((size_t)h->r2_total), dim3(256), 0, s, h->tr_slabs, h->slab_stride, h->tr_chunks, grads_flat,
+                           (const long long*)h->r2_dev, (const long long*)(h->r2_dev + h->r2_n), h->r2_n, h->r2_total);
     } else {
         if (h->use_split) {
             if (next_part) HIPCK(hipEventRecord(h->ev_join, h->side_stream));

@@ -369,6 +369,181 @@ __device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUni
     }
 }
 
+// ---- NTp == 1 units (one out tile: the 4- to 32-wide Linears of the narrow blocks), the same construction over 64-row intervals: the
+// four waves take one k16-step each.  G image [64 rows][32 features] with 72-byte rows (the 8-byte pad spreads a wave's row writes over
+// the banks), A image as in the wide form.  KTM = 2: at most 64 in-features (every narrow block), four A items per wave; KTM = 4: eight.
+constexpr unsigned kWimg2GH = 0, kWimg2GL = 4608, kWimg2AH = 9216, kWimg2AL = 25600, kWimg2Vec = 41984;   // 43 008 B in all
+template <int KTM>
+struct WgradRegs2 { float4 g0[2], av[2 * KTM]; float2 ms[2]; int oh[2]; };
+
+template <int KTM>
+__device__ __forceinline__ void wgrad_unit_h2(const WgradDesc& d, const WgradUnit& un, char* __restrict__ img, f32x16 (&acc)[4], float gscale,
+                                              int ntiles, int nchunks, int wave, int lane, int KT, int g_lo, int ngr) {
+    constexpr int NA = 2 * KTM;
+    const int h = lane >> 5, j = lane & 31;
+    const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+    const int t_lo = un.chunk * tiles_per_chunk;
+    const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
+    const int nag = KT * 4;
+    const int mode = d.amode;
+    const bool hasg1 = d.G1 != nullptr;
+    float* const gam = reinterpret_cast<float*>(img + kWimg2Vec);
+    float* const bet = gam + 128;
+    if (mode == A_LNSILU && threadIdx.x < 128) {
+        const int f = threadIdx.x, ok = (f >> 3) < ngr;
+        gam[f] = ok ? d.gamma[8 * g_lo + f] : 0.f;
+        bet[f] = ok ? d.beta[8 * g_lo + f] : 0.f;
+    }
+    const unsigned sw = (((unsigned)j & 3u) << 2) | (((unsigned)j >> 2) & 3u);
+    const unsigned lane4 = lane * 4;
+    // G items: (group wave, tile i) ; A items: (group wave + 4 (i % KTM), tile i / KTM)
+    unsigned gw[2], aw[NA];
+    bool aok[NA];
+    const float* ap[NA];
+    size_t astr[NA];
+    const bool gok = wave < d.NG;
+    const size_t goff = (size_t)(gok ? wave : 0) * 256;
+    const uint2 z = make_uint2(0u, 0u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gw[i] = 72u * (32u * i + j) + 16u * wave + 8u * h;
+        if (!gok) { *reinterpret_cast<uint2*>(img + kWimg2GH + gw[i]) = z; *reinterpret_cast<uint2*>(img + kWimg2GL + gw[i]) = z; }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int gi = wave + 4 * (i % KTM), tt = i / KTM;
+        aw[i] = 256u * (32u * tt + j) + 16u * ((unsigned)gi ^ sw) + 8u * h;
+        aok[i] = gi < nag && gi < ngr;
+        const int G = g_lo + (gi < ngr ? gi : ngr - 1);
+        const bool first = G < d.a0.groups;
+        const Seg& sg = first ? d.a0 : d.a1;
+        ap[i] = mode == A_ONEHOT ? d.G0 : sg.data + (size_t)(first ? G : G - d.a0.groups) * 256;
+        astr[i] = mode == A_ONEHOT ? 0 : (size_t)sg.groups * 256;
+        if (gi < nag && !aok[i]) { *reinterpret_cast<uint2*>(img + kWimg2AH + aw[i]) = z; *reinterpret_cast<uint2*>(img + kWimg2AL + aw[i]) = z; }
+    }
+    const size_t gstr = (size_t)d.NG * 256;
+    // operand reads of this wave's k16-step (s = wave)
+    const unsigned li = lane & 15, q = li >> 2, pp = li & 3, sub = (lane >> 4) & 1;
+    const char* rg[2];
+    const char* rb[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned row = 16u * wave + 8u * h + 4u * e + q;
+        rg[e] = img + 72u * row + 32u * sub + 8u * pp;
+        rb[e] = img + 256u * row + 16u * ((2u * sub + (pp >> 1)) ^ ((2u * h + e) & 3u)) + 8u * (pp & 1u);
+    }
+    unsigned tq_a[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) tq_a[kt] = 64u * ((unsigned)kt ^ q);
+
+    const int t_last = t_hi - 1;
+    auto clampt = [&](int t) { return t < t_last ? t : t_last; };
+    float4 g1[2];
+    const float* const G1p = hasg1 ? d.G1 : d.G0;
+    const float g1s = hasg1 ? gscale : 0.f;
+    auto fetch_g1 = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) g1[i] = ld4(G1p + (size_t)clampt(t0 + i) * gstr + goff + lane4);
+    };
+    auto fetch = [&](WgradRegs2<KTM>& R, int t0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) R.g0[i] = ld4(d.G0 + (size_t)clampt(t0 + i) * gstr + goff + lane4);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) R.av[i] = ld4(ap[i] + (size_t)clampt(t0 + i / KTM) * astr[i] + lane4);
+        if (mode == A_ONEHOT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { const int row = clampt(t0 + i) * 32 + j; R.oh[i] = d.ts[row < d.nrows ? row : d.nrows - 1]; }
+        }
+        if (mode == A_LNSILU) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) R.ms[i] = reinterpret_cast<const float2*>(d.rs)[(size_t)clampt(t0 + i) * 32 + j];
+        }
+    };
+    auto put = [&](unsigned plane_hi, unsigned plane_lo, unsigned off, const float4 v) {
+        unsigned h01, h23, l01, l23;
+        split_pair(v.x, v.y, h01, l01);
+        split_pair(v.z, v.w, h23, l23);
+        *reinterpret_cast<uint2*>(img + plane_hi + off) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(img + plane_lo + off) = make_uint2(l01, l23);
+    };
+    auto stage = [&](const WgradRegs2<KTM>& R, int t0) {
+        if (gok) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float keep = t0 + i < t_hi ? 1.f : 0.f;        // a tile beyond the chunk: zero rows
+                const float4 v = R.g0[i];
+                put(kWimg2GH, kWimg2GL, gw[i], make_float4(keep * fmaf(g1[i].x, g1s, v.x * gscale), keep * fmaf(g1[i].y, g1s, v.y * gscale),
+                                                           keep * fmaf(g1[i].z, g1s, v.z * gscale), keep * fmaf(g1[i].w, g1s, v.w * gscale)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            if (aok[i]) {
+                const int tt = i / KTM, tile = t0 + tt, gi = wave + 4 * (i % KTM);
+                const bool live = tile < t_hi && tile * 32 + j < d.nrows;   // forward tensors of padded rows are not zero
+                float4 v;
+                if (mode == A_ONEHOT) {
+                    const int e = R.oh[tt], f = 8 * (g_lo + gi) + 4 * h;
+                    v = make_float4(e == f ? 1.f : 0.f, e == f + 1 ? 1.f : 0.f, e == f + 2 ? 1.f : 0.f, e == f + 3 ? 1.f : 0.f);
+                } else if (mode == A_LNSILU) {
+                    const float4 x = R.av[i];
+                    const float4 gm = *reinterpret_cast<const float4*>(gam + 8 * gi + 4 * h);
+                    const float4 bt = *reinterpret_cast<const float4*>(bet + 8 * gi + 4 * h);
+                    const float c = R.ms[tt].y, dd = -R.ms[tt].x * R.ms[tt].y;
+                    v = make_float4(silu_scaled(fmaf(fmaf(x.x, c, dd), gm.x, bt.x)), silu_scaled(fmaf(fmaf(x.y, c, dd), gm.y, bt.y)),
+                                    silu_scaled(fmaf(fmaf(x.z, c, dd), gm.z, bt.z)), silu_scaled(fmaf(fmaf(x.w, c, dd), gm.w, bt.w)));
+                } else {
+                    const float4 x = R.av[i];
+                    v = make_float4(kRawScale * x.x, kRawScale * x.y, kRawScale * x.z, kRawScale * x.w);
+                }
+                if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                put(kWimg2AH, kWimg2AL, aw[i], v);
+            }
+    };
+    auto mma = [&]() {
+        const h8 ghi = wimg_tr8(rg[0] + kWimg2GH, rg[1] + kWimg2GH);
+        const h8 glo = wimg_tr8(rg[0] + kWimg2GL, rg[1] + kWimg2GL);
+#pragma unroll
+        for (int kp = 0; kp < KTM; kp += 2)
+            if (kp < KT) {
+                h8 ahi[2], alo[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    ahi[k] = wimg_tr8(rb[0] + tq_a[kp + k] + kWimg2AH, rb[1] + tq_a[kp + k] + kWimg2AH);
+                    alo[k] = wimg_tr8(rb[0] + tq_a[kp + k] + kWimg2AL, rb[1] + tq_a[kp + k] + kWimg2AL);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    DSG_MFMA_H(acc[kp + k], ghi, ahi[k]);
+                    DSG_MFMA_H(acc[kp + k], ghi, alo[k]);
+                    DSG_MFMA_H(acc[kp + k], glo, ahi[k]);
+                }
+            }
+    };
+    WgradRegs2<KTM> R0, R1;
+    __syncthreads();                         // the LayerNorm vectors, the zeroed padding
+    if (t_lo >= t_hi) return;
+    fetch(R0, t_lo); fetch_g1(t_lo);
+    fetch(R1, t_lo + 2);
+    stage(R0, t_lo);
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; t += 4) {
+        // image: tiles t, t + 1; R1: t + 2, t + 3; R0: free
+        fetch(R0, t + 4);
+        fetch_g1(t + 2);
+        mma();
+        __syncthreads();
+        if (t + 2 < t_hi) stage(R1, t + 2);
+        __syncthreads();
+        fetch(R1, t + 6);
+        fetch_g1(t + 4);
+        if (t + 2 < t_hi) mma();
+        __syncthreads();
+        if (t + 4 < t_hi) stage(R0, t + 4);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void k_wgrad_h(const WgradDesc* __restrict__ descs, const WgradUnit* __restrict__ units,
                                                  const unsigned* __restrict__ gmax, float* __restrict__ slabs, size_t slab_stride, int ntiles,
                                                  int nchunks, int form) {
@@ -394,7 +569,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h(const WgradDesc* __restrict_
 
     f32x16 acc[4];
     acc_zero<4>(acc);
-    if (NTp == 1) wgrad_unit_h<2>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+    if (NTp == 1 && form == 0) wgrad_unit_h<2>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+    else if (NTp == 1 && KT <= 2) wgrad_unit_h2<2>(d, un, reinterpret_cast<char*>(img), acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
+    else if (NTp == 1) wgrad_unit_h2<4>(d, un, reinterpret_cast<char*>(img), acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
     else if (form == 0) wgrad_unit_h<1>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
     else wgrad_unit_h1(d, un, reinterpret_cast<char*>(img), acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
 

@@ -90,7 +90,7 @@ int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_ma
  *   DSG_OPT_TRAIN_TIME_BESIDE  1 (default): in training steps that use the side stream (>= 32 768 rows) the time-path backward
  *                          (TimeEmbedding and the per-block time_emb Linear, UNetCF.py:35-44) runs on the side stream beside the last
  *                          weight-gradient launch; 0: behind it on the caller's stream.  Same gradients bit for bit either way. */
-enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2, DSG_OPT_WGRAD_FORM = 3 };
+enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2, DSG_OPT_WGRAD_FORM = 3, DSG_OPT_WGRAD_NARROW_PART = 4 };
 int dsg_set_option(dsg_handle* h, int option, int value);
 
 /* Pre-size the workspace for up to `max_rows` batch rows and `max_entries` time-table rows. */

@@ -38,6 +38,14 @@ if os.environ.get("WGRAD_AB"):
             ddpm.model.set_option("wgrad_form", v)
             run(f"round {rnd}: B={B} wgrad_form={v}")
     sys.exit(0)
+if os.environ.get("PART_AB"):
+    # the narrow run's weight gradients as a third early part beside the end of the chain (DSG_OPT_WGRAD_NARROW_PART)
+    FlatAdam.native_step = True; ddpm.device_draws = 1
+    for rnd in range(2):
+        for v in (0, 1):
+            ddpm.model.set_option("wgrad_narrow_part", v)
+            run(f"round {rnd}: B={B} wgrad_narrow_part={v}")
+    sys.exit(0)
 if os.environ.get("TIME_AB"):
     # the time-path backward beside the last weight-gradient launch (DSG_OPT_TRAIN_TIME_BESIDE) against behind it
     FlatAdam.native_step = True; ddpm.device_draws = 1
