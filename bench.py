@@ -223,8 +223,10 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
         early = 6 if (B + 31) // 32 >= 1024 else 0
         if early:
             blocks = blocks[:-early]
-            roof["kernel"] = ("k_wgrad_h, final launch: dW = G^T A of every Linear except the last six residual blocks' "
-                              "(those run on a side stream beside the activation-gradient chain) + the time-table one-hot GEMM")
+            roof["kernel"] = ("k_wgrad_h, the step's tail: dW = G^T A of every Linear except the last six residual blocks' (those run on a "
+                              "side stream beside the activation-gradient chain).  `avg_launch_ms` = the phase between the end of the chain and "
+                              "the closing reduce on the caller's stream (the blocks' units, then the plain Linears'); the side stream runs the "
+                              "time-table units, the column sums and the time-path backward beside it (DESIGN.md 5)")
             roof["algorithmic_tflops"] = None
         per_row = 0
         for n, i0, i1 in blocks:

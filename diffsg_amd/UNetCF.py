@@ -321,8 +321,9 @@ class UNet1D(nn.Module):
     def set_option(self, name, value):
         """Per-handle kernel-form switches (dsg_set_option): "narrow_valu8" -- the 8-wide bottom of the net on the vector
         unit in float32 inside large sampling launches (default on); "train_time_beside" -- the time-path backward of large
-        training steps on the side stream beside the last weight-gradient launch (default on)."""
-        code = {"narrow_valu8": 1, "train_time_beside": 2, "wgrad_form": 3, "wgrad_narrow_part": 4}[name]
+        training steps on the side stream beside the last weight-gradient launch (default on); "wgrad_narrow_part" -- the narrow
+        run's weight gradients as a third early part (default off)."""
+        code = {"narrow_valu8": 1, "train_time_beside": 2, "wgrad_narrow_part": 4}[name]
         for hd in self._all_handles():
             _lib.check(_lib.lib().dsg_set_option(hd, code, int(value)))
         self.__dict__.setdefault("_settings", {}).setdefault("options", {})[code] = int(value)

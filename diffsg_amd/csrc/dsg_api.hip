@@ -206,7 +206,6 @@ struct dsg_handle {
     int v8_lo = -1, v8_hi = -1;
     bool opt_v8 = true;
     bool opt_time_beside = true;       // dsg_set_option(DSG_OPT_TRAIN_TIME_BESIDE): see the tail of dsg_train_step
-    int opt_wgrad_form = 1;            // dsg_set_option(DSG_OPT_WGRAD_FORM)
     bool opt_wg_narrow_part = false;   // dsg_set_option(DSG_OPT_WGRAD_NARROW_PART); read when the descriptor tables are (re)built
     // the section's image in global memory (V8SecL layout: raw nn.Linear matrices and parameter vectors), gathered at every bind; the LDS
     // form of the narrow run stages it as one piece, small launches and the training forward read it from L1 / L2
@@ -1793,7 +1792,7 @@ void dsg_destroy(dsg_handle* h) {
     if (h->fbwd_dev) (void)hipFree(h->fbwd_dev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->time_stream) (void)hipStreamDestroy(h->time_stream);
+    if (h->time_stream && h->time_stream != h->side_stream) (void)hipStreamDestroy(h->time_stream);
     for (auto& e : h->ev_tail) if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -2030,7 +2029,6 @@ int dsg_set_option(dsg_handle* h, int option, int value) {
             }
             return 0;
         case DSG_OPT_TRAIN_TIME_BESIDE: h->opt_time_beside = value != 0; return 0;
-        case DSG_OPT_WGRAD_FORM: h->opt_wgrad_form = value != 0; return 0;
         case DSG_OPT_WGRAD_NARROW_PART:
             if ((value != 0) != h->opt_wg_narrow_part) { (void)hipDeviceSynchronize(); h->opt_wg_narrow_part = value != 0; h->td_valid = false; }
             return 0;
@@ -2362,9 +2360,10 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
         HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        int pr_least = 0, pr_greatest = 0;
-        HIPCK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-        HIPCK(hipStreamCreateWithPriority(&h->time_stream, hipStreamNonBlocking, pr_greatest));   // short dependent launches beside a full-chip one
+        // The step's tail runs on the side stream too, behind the early parts.  (A separate high-priority stream measured 2 % faster in
+        // a process of its own and 2.2x SLOWER -- 4.3 ms per step -- as soon as a second handle was alive in the process, bench.py's
+        // sampling model: profiles/r04_train_tail_ab.txt.  No stream priorities.)
+        h->time_stream = h->side_stream;
         for (auto& e : h->ev_tail) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // the G and A operands of a part are final once the backward kernel of its last block is enqueued: its weight gradients run
@@ -2379,7 +2378,7 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
             hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, h->side_stream, h->tr_gmax_t, h->gmax_ld, gm);
             if (u1 > u0)
                 hipLaunchKernelGGL(k_wgrad_h, dim3(u1 - u0), dim3(256), h->wg_early_lds, h->side_stream, h->wg_desc_dev, h->wg_unit_dev + u0,
-                                   gm, h->tr_slabs, h->slab_stride, tiles, h->tr_chunks, h->opt_wgrad_form);
+                                   gm, h->tr_slabs, h->slab_stride, tiles, h->tr_chunks);
             ++next_part;
         }
         return 0;
@@ -2415,8 +2414,8 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
     // ---- weight / bias / LayerNorm gradients: grouped launches into per-chunk slabs, then a fixed-order reduce.
     // Small batches: everything in order on the caller's stream.  With the side stream (>= 32 768 rows) the tail runs on two streams:
     //   caller's stream       max|G| of the blocks -> the blocks' units (ONE launch, longest first) -> the Linears' units -> reduce (parameters)
-    //   time stream           time-table units -> column sums (k_cs_reduce, k_colsum) -> max|G| of everything --^                ^
-    //   (high priority)       -> [early parts done] -> reduce (dTB) -> time path ----------------------------------------------+
+    //   side stream (behind   time-table units -> column sums (k_cs_reduce, k_colsum) -> max|G| of everything --^                ^
+    //   the early parts)      -> reduce (dTB) -> time path ----------------------------------------------------------------------+
     // A residual block's G operands have their scale from the block's own backward kernel; only the plain Linears' wait for k_colsum.
     // The time path (UNetCF.py:35-44 backward: ~10 short dependent launches) needs nothing but the dTB rows; its five results go
     // straight into the caller's gradient bucket, and the fixed-order reduce at the end covers every OTHER parameter
@@ -2428,7 +2427,7 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
     auto units = [&](int lo, int hi, const unsigned* gm, hipStream_t us) {
         if (hi > lo)
             hipLaunchKernelGGL(k_wgrad_h, dim3(hi - lo), dim3(256), 0, us, h->wg_desc_dev, h->wg_unit_dev + lo, gm, h->tr_slabs, h->slab_stride,
-                               tiles, h->tr_chunks, h->opt_wgrad_form);
+                               tiles, h->tr_chunks);
     };
     const int u0 = next_part ? h->wg_part_end[next_part - 1] : 0;
     if (time_beside) {
@@ -2472,8 +2471,6 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
         HIPCK(hipEventRecord(h->ev_tail[2], h->time_stream));              // column sums done: the Linears' scales
         HIPCK(hipStreamWaitEvent(s, h->ev_tail[2], 0));
         units(h->wg_blocks_end, h->wg_units, gm_all, s);
-        HIPCK(hipEventRecord(h->ev_join, h->side_stream));                 // the early parts: the other blocks' time-table units
-        HIPCK(hipStreamWaitEvent(h->time_stream, h->ev_join, 0));
         hipLaunchKernelGGL(k_reduce_slabs, reduce_blocks(dtb_n), dim3(256), 0, h->time_stream, h->tr_slabs + dtb0, h->slab_stride, h->tr_chunks,
                            h->tr_gsum + dtb0, dtb_n);
         time_path(grads_flat, h->time_stream);       // straight into the caller's bucket: the last reduce leaves these regions out

@@ -17,7 +17,7 @@
 namespace dsg {
 
 constexpr int kWhTarget = 13;
-constexpr int kWhLdsHalfs = 2 * (32 + 128) * (32 * 2 + 8);   // the 2-tile form (46 080 B); the 1-tile form needs 40 960 B
+constexpr int kWhLdsBytes = 43008;      // the one-out-tile form's images + vectors (wgrad_unit_h2); the wide form needs 33 792 B
 
 __device__ __forceinline__ int wgrad_gexp(unsigned maxbits) {
     const int be = (int)((maxbits >> 23) & 0xff);              // biased exponent of max|G|; 0 = zero or denormal
@@ -26,148 +26,7 @@ __device__ __forceinline__ int wgrad_gexp(unsigned maxbits) {
     return e < -100 ? -100 : (e > 100 ? 100 : e);
 }
 
-// lane (row r of the interval, half h) splits its 4 features f0..f0+3 into hi / lo halves and stores them into the transposed
-// planes.  Neighbouring lanes (rows r, r^1) first trade half of their data, so that every 32-bit word of a plane (two
-// consecutive rows of one feature) is written whole by ONE lane: even rows store features f0, f0+1, odd rows f0+2, f0+3.
-__device__ __forceinline__ void wsplit_store(_Float16* hi, _Float16* lo, int P, int f0, int r, const float4 v) {
-    unsigned h01, h23, l01, l23;
-    split_pair(v.x, v.y, h01, l01);
-    split_pair(v.z, v.w, h23, l23);
-    const bool odd = r & 1;
-    // what the neighbour needs from me: an even row keeps (f0, f0+1) and gives away (f0+2, f0+3); an odd row the reverse
-    const unsigned hs = odd ? h01 : h23, ls = odd ? l01 : l23;
-    const unsigned hr = (unsigned)__builtin_amdgcn_mov_dpp((int)hs, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]: lane ^ 1
-    const unsigned lr = (unsigned)__builtin_amdgcn_mov_dpp((int)ls, 0xB1, 0xf, 0xf, true);
-    const unsigned hm = odd ? h23 : h01, lm = odd ? l23 : l01;                                // what I keep
-    const unsigned he = odd ? hr : hm, ho = odd ? hm : hr;                                    // even-row / odd-row pair
-    const unsigned le = odd ? lr : lm, lo_ = odd ? lm : lr;
-    const int fb = f0 + (odd ? 2 : 0), r2 = r & ~1;
-    unsigned* ph = reinterpret_cast<unsigned*>(hi + fb * P + r2);
-    unsigned* pl = reinterpret_cast<unsigned*>(lo + fb * P + r2);
-    ph[0] = __builtin_amdgcn_perm(ho, he, 0x05040100u);        // feature fb:     (even row, odd row)
-    ph[P / 2] = __builtin_amdgcn_perm(ho, he, 0x07060302u);    // feature fb + 1
-    pl[0] = __builtin_amdgcn_perm(lo_, le, 0x05040100u);
-    pl[P / 2] = __builtin_amdgcn_perm(lo_, le, 0x07060302u);
-}
-
-// One unit.  TB row tiles per barrier interval (single image, next interval prefetched into registers under the MFMAs).
-//   TB == 1: out tiles NTp in {2, 4}; wave -> (n-tile, part); an interval has two k16-steps.
-//   TB == 2: NTp == 1; the four waves take one k16-step each.
-template <int TB>
-__device__ __forceinline__ void wgrad_unit_h(const WgradDesc& d, const WgradUnit& un, _Float16* __restrict__ img, f32x16 (&acc)[4], float gscale,
-                                             int ntiles, int nchunks, int wave, int lane, int NTp, int KT, int g_lo, int ngr, int my_nt,
-                                             int my_part, int rsplit) {
-    constexpr int P = 32 * TB + 8;
-    constexpr int GF = TB == 1 ? 128 : 32;
-    constexpr int NGW = TB == 1 ? 4 : 2;     // G items (float4) per wave per interval
-    constexpr int NAW = TB == 1 ? 4 : 8;     // A items per wave per interval
-    _Float16* Ghi = img;
-    _Float16* Glo = Ghi + GF * P;
-    _Float16* Ahi = Glo + GF * P;
-    _Float16* Alo = Ahi + 128 * P;
-    const int h = lane >> 5, j = lane & 31;
-    const int tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
-    const int t_lo = un.chunk * tiles_per_chunk;
-    const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
-    const int ngg = NTp * 4, nag = KT * 4;   // groups held by the images
-    float4 g0[NGW], g1[NGW], av[NAW];
-    float2 ms[TB];                          // (mean, rstd) of this lane's row in each tile of the interval
-    // raw loads only; the transforms run in stage() after the MFMAs of the current interval
-    auto fetch = [&](int t0) {
-#pragma unroll
-        for (int i = 0; i < NGW; ++i) {
-            const int item = wave + 4 * i, g = TB == 1 ? item : (item & 3), tt = TB == 1 ? 0 : (item >> 2);
-            g0[i] = make_float4(0.f, 0.f, 0.f, 0.f); g1[i] = g0[i];
-            if (g < d.NG && g < ngg && t0 + tt < t_hi) {
-                g0[i] = ld4(d.G0 + ((size_t)(t0 + tt) * d.NG + g) * 256 + lane * 4);
-                if (d.G1) g1[i] = ld4(d.G1 + ((size_t)(t0 + tt) * d.NG + g) * 256 + lane * 4);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NAW; ++i) {
-            const int item = wave + 4 * i, gi = TB == 1 ? item : (item & 15), tt = TB == 1 ? 0 : (item >> 4);
-            av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int tile = t0 + tt, G = g_lo + gi;
-            if (gi < nag && gi < ngr && tile < t_hi) {
-                if (d.amode == A_ONEHOT) {
-                    const int row = tile * 32 + j;
-                    av[i].x = __int_as_float(row < d.nrows ? d.ts[row] : -1);
-                } else {
-                    const bool first = G < d.a0.groups;
-                    const Seg& sg = first ? d.a0 : d.a1;
-                    const int gl = first ? G : G - d.a0.groups;
-                    av[i] = ld4(sg.data + ((size_t)tile * sg.groups + gl) * 256 + lane * 4);
-                }
-            }
-        }
-#pragma unroll
-        for (int tt = 0; tt < TB; ++tt) {
-            ms[tt] = make_float2(0.f, 0.f);
-            if (d.amode == A_LNSILU && t0 + tt < t_hi) ms[tt] = reinterpret_cast<const float2*>(d.rs)[(size_t)(t0 + tt) * 32 + j];
-        }
-    };
-    auto stage = [&](int t0) {
-#pragma unroll
-        for (int i = 0; i < NGW; ++i) {
-            const int item = wave + 4 * i, g = TB == 1 ? item : (item & 3), tt = TB == 1 ? 0 : (item >> 2);
-            if (g < ngg) {
-                const float4 v = make_float4((g0[i].x + g1[i].x) * gscale, (g0[i].y + g1[i].y) * gscale, (g0[i].z + g1[i].z) * gscale,
-                                             (g0[i].w + g1[i].w) * gscale);
-                wsplit_store(Ghi, Glo, P, 8 * g + 4 * h, 32 * tt + j, v);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NAW; ++i) {
-            const int item = wave + 4 * i, gi = TB == 1 ? item : (item & 15), tt = TB == 1 ? 0 : (item >> 4);
-            if (gi < nag) {
-                const int tile = t0 + tt, G = g_lo + gi;
-                const bool live = gi < ngr && tile < t_hi && tile * 32 + j < d.nrows;   // forward tensors of padded rows are not zero
-                float4 v = av[i];
-                if (d.amode == A_ONEHOT) {
-                    const int e = __float_as_int(av[i].x), f = 8 * G + 4 * h;
-                    v = make_float4(e == f ? 1.f : 0.f, e == f + 1 ? 1.f : 0.f, e == f + 2 ? 1.f : 0.f, e == f + 3 ? 1.f : 0.f);
-                } else if (d.amode == A_LNSILU) {
-                    const int Gc = gi < ngr ? G : g_lo;
-                    const float4 gm = ld4(d.gamma + 8 * Gc + 4 * h), bt = ld4(d.beta + 8 * Gc + 4 * h);
-                    const float2 m2 = TB == 1 ? ms[0] : (tt ? ms[TB - 1] : ms[0]);
-                    const float c = m2.y, dd = -m2.x * m2.y;
-                    v = make_float4(silu_scaled(fmaf(fmaf(v.x, c, dd), gm.x, bt.x)), silu_scaled(fmaf(fmaf(v.y, c, dd), gm.y, bt.y)),
-                                    silu_scaled(fmaf(fmaf(v.z, c, dd), gm.z, bt.z)), silu_scaled(fmaf(fmaf(v.w, c, dd), gm.w, bt.w)));
-                } else {
-                    v = make_float4(kRawScale * v.x, kRawScale * v.y, kRawScale * v.z, kRawScale * v.w);
-                }
-                if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                wsplit_store(Ahi, Alo, P, 8 * gi + 4 * h, 32 * tt + j, v);
-            }
-        }
-    };
-    if (t_lo < t_hi) { fetch(t_lo); stage(t_lo); }
-    __syncthreads();
-    const int spp = 2 * TB / rsplit;          // k16-steps of this wave per interval
-    for (int t0 = t_lo; t0 < t_hi; t0 += TB) {
-        const bool more = t0 + TB < t_hi;
-        if (more) fetch(t0 + TB);
-        for (int s = my_part * spp; s < (my_part + 1) * spp; ++s) {
-            const int off = 16 * s + 8 * h;
-            const h8 ghi = *reinterpret_cast<const h8*>(Ghi + (32 * my_nt + j) * P + off);
-            const h8 glo = *reinterpret_cast<const h8*>(Glo + (32 * my_nt + j) * P + off);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-                if (kt < KT) {
-                    const h8 ahi = *reinterpret_cast<const h8*>(Ahi + (32 * kt + j) * P + off);
-                    const h8 alo = *reinterpret_cast<const h8*>(Alo + (32 * kt + j) * P + off);
-                    DSG_MFMA_H(acc[kt], ghi, ahi);
-                    DSG_MFMA_H(acc[kt], ghi, alo);
-                    DSG_MFMA_H(acc[kt], glo, ahi);
-                }
-        }
-        __syncthreads();                     // everyone is done reading the image
-        if (more) stage(t0 + TB);
-        __syncthreads();
-    }
-}
-
-// ---- TB == 1 units (out tiles NTp in {2, 4}), round-4 form.  The kernel is bound by the number of instructions a wave issues per
+// ---- Units with 2 or 4 out tiles (NTp): one 32-row tile per barrier interval.  The kernel is bound by the number of instructions a wave issues per
 // 32-row interval, not by the matrix cores (measured with the pieces switched off one at a time, profiles/r04_wgrad_switches.txt: MFMAs
 // 5 %, operand transforms 37 %, loop skeleton and addressing 35 %), so this form issues about half of them:
 //   * the image is ROW-major, [32 batch rows][128 features] f16 per plane, 256-byte rows with the 16-byte chunks XOR-swizzled
@@ -546,8 +405,8 @@ __device__ __forceinline__ void wgrad_unit_h2(const WgradDesc& d, const WgradUni
 
 __global__ __launch_bounds__(256, 2) void k_wgrad_h(const WgradDesc* __restrict__ descs, const WgradUnit* __restrict__ units,
                                                  const unsigned* __restrict__ gmax, float* __restrict__ slabs, size_t slab_stride, int ntiles,
-                                                 int nchunks, int form) {
-    __shared__ __attribute__((aligned(16))) _Float16 img[kWhLdsHalfs];     // >= the 33 KiB of the TB == 1 form
+                                                 int nchunks) {
+    __shared__ __attribute__((aligned(16))) char img[kWhLdsBytes];
     const WgradUnit un = units[blockIdx.x];
     WgradDesc d = descs[un.desc];
     d.G0 = as_global(d.G0); d.G1 = as_global(d.G1); globalize(d.a0); globalize(d.a1);          // dsg_kernels.hpp, as_global
@@ -569,11 +428,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h(const WgradDesc* __restrict_
 
     f32x16 acc[4];
     acc_zero<4>(acc);
-    if (NTp == 1 && form == 0) wgrad_unit_h<2>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
-    else if (NTp == 1 && KT <= 2) wgrad_unit_h2<2>(d, un, reinterpret_cast<char*>(img), acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
-    else if (NTp == 1) wgrad_unit_h2<4>(d, un, reinterpret_cast<char*>(img), acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
-    else if (form == 0) wgrad_unit_h<1>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
-    else wgrad_unit_h1(d, un, reinterpret_cast<char*>(img), acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+    if (NTp == 1 && KT <= 2) wgrad_unit_h2<2>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
+    else if (NTp == 1) wgrad_unit_h2<4>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
+    else wgrad_unit_h1(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
 
     // ---- waves that split the rows of one n-tile add their partial tiles through LDS, then the first writes the slab
     if (rsplit > 1) {

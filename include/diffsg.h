@@ -89,8 +89,10 @@ int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_ma
  *                          of the narrow run.  Cached step graphs are dropped when the value changes.
  *   DSG_OPT_TRAIN_TIME_BESIDE  1 (default): in training steps that use the side stream (>= 32 768 rows) the time-path backward
  *                          (TimeEmbedding and the per-block time_emb Linear, UNetCF.py:35-44) runs on the side stream beside the last
- *                          weight-gradient launch; 0: behind it on the caller's stream.  Same gradients bit for bit either way. */
-enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2, DSG_OPT_WGRAD_FORM = 3, DSG_OPT_WGRAD_NARROW_PART = 4 };
+ *                          weight-gradient launch; 0: behind it on the caller's stream.  Same gradients bit for bit either way.
+ *   DSG_OPT_WGRAD_NARROW_PART  0 (default) / 1: the weight gradients of the fused narrow run's blocks as one more early part on the side
+ *                          stream, behind the narrow run's backward launch (measured slower at 32 768 rows: profiles/r04_train_tail_ab.txt). */
+enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2, DSG_OPT_WGRAD_NARROW_PART = 4 };
 int dsg_set_option(dsg_handle* h, int option, int value);
 
 /* Pre-size the workspace for up to `max_rows` batch rows and `max_entries` time-table rows. */

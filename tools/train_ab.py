@@ -30,14 +30,6 @@ if os.environ.get("SPLIT_AB"):
             type(ddpm).train_split_min_rows = sp
             run(f"round {rnd}: B={B} train_split_min_rows={sp}")
     sys.exit(0)
-if os.environ.get("WGRAD_AB"):
-    # the two forms of the wide weight-gradient units (DSG_OPT_WGRAD_FORM)
-    FlatAdam.native_step = True; ddpm.device_draws = 1
-    for rnd in range(2):
-        for v in (0, 1):
-            ddpm.model.set_option("wgrad_form", v)
-            run(f"round {rnd}: B={B} wgrad_form={v}")
-    sys.exit(0)
 if os.environ.get("PART_AB"):
     # the narrow run's weight gradients as a third early part beside the end of the chain (DSG_OPT_WGRAD_NARROW_PART)
     FlatAdam.native_step = True; ddpm.device_draws = 1
