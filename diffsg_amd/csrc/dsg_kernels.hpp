@@ -608,23 +608,27 @@ __global__ __launch_bounds__(256, 4) void k_fused_narrow(const FusedOp* __restri
     for (int i = 0; i < nops; ++i) {
         const FusedOp& op = ops[i];
         if (op.kind == 0) {
+            BlockArgs b = op.b;               // every pointer of the record is global (as_global)
+            globalize_io(b); globalize_params(b);
             if (op.sclin) {
                 switch (op.N) {
-                    case 4: resblock_body<4, true>(op.b, tile, lane); break;
-                    case 8: resblock_body<8, true>(op.b, tile, lane); break;
-                    case 16: resblock_body<16, true>(op.b, tile, lane); break;
-                    default: resblock_body<32, true>(op.b, tile, lane); break;
+                    case 4: resblock_body<4, true>(b, tile, lane); break;
+                    case 8: resblock_body<8, true>(b, tile, lane); break;
+                    case 16: resblock_body<16, true>(b, tile, lane); break;
+                    default: resblock_body<32, true>(b, tile, lane); break;
                 }
             } else {
                 switch (op.N) {
-                    case 4: resblock_body<4, false>(op.b, tile, lane); break;
-                    case 8: resblock_body<8, false>(op.b, tile, lane); break;
-                    case 16: resblock_body<16, false>(op.b, tile, lane); break;
-                    default: resblock_body<32, false>(op.b, tile, lane); break;
+                    case 4: resblock_body<4, false>(b, tile, lane); break;
+                    case 8: resblock_body<8, false>(b, tile, lane); break;
+                    case 16: resblock_body<16, false>(b, tile, lane); break;
+                    default: resblock_body<32, false>(b, tile, lane); break;
                 }
             }
         } else {
-            linear_body<1, IN_FRAG, OUT_FRAG, false>(op.l, tile, lane);
+            LinArgs l = op.l;
+            globalize_io(l); globalize_params(l);
+            linear_body<1, IN_FRAG, OUT_FRAG, false>(l, tile, lane);
         }
         // the next operator of THIS wave reads what it just stored (same tile): drain the stores first
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

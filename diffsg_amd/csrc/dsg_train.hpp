@@ -942,7 +942,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradDesc* __restrict__ des
                                                float* __restrict__ slabs, size_t slab_stride, int ntiles, int nchunks) {
     __shared__ __attribute__((aligned(16))) float img[kWgLdsFloats];
     const WgradUnit un = units[blockIdx.x];
-    const WgradDesc d = descs[un.desc];
+    WgradDesc d = descs[un.desc];
+    d.G0 = as_global(d.G0); d.G1 = as_global(d.G1); globalize(d.a0); globalize(d.a1);          // dsg_kernels.hpp, as_global
+    d.rs = as_global(d.rs); d.gamma = as_global(d.gamma); d.beta = as_global(d.beta); d.ts = as_global(d.ts);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
     const int NT = (d.N + 31) / 32;

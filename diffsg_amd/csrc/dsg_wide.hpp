@@ -233,16 +233,28 @@ __device__ __forceinline__ void wide_add_private(f32x16 (&acc)[4], WideRing& r, 
     }
 }
 
+// The vector reads go out four at a time AHEAD of the arithmetic (a scheduling barrier keeps the group together): written as "read 4,
+// use 4" hipcc kept that order and reused the destination registers, i.e. sixteen LDS round trips in a row, each fully exposed, three
+// times per tile of a 128-wide block (k_panel128_h: 51 of its 63 full lgkmcnt drains).
 template <int NT>
 __device__ __forceinline__ void acc_unscale_add_lds(f32x16 (&acc)[NT], float inv, const float* vec, int h) {
+    constexpr int NB = 1;                    // out tiles per batch (two: 20-196 B of scratch in the panel kernels)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int n0 = 0; n0 < NT; n0 += NB) {
+        float4 b[4 * NB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b = ld4(vec + 32 * nt + 8 * q + 4 * h);
-            acc[nt][4 * q + 0] = fmaf(acc[nt][4 * q + 0], inv, b.x); acc[nt][4 * q + 1] = fmaf(acc[nt][4 * q + 1], inv, b.y);
-            acc[nt][4 * q + 2] = fmaf(acc[nt][4 * q + 2], inv, b.z); acc[nt][4 * q + 3] = fmaf(acc[nt][4 * q + 3], inv, b.w);
-        }
+        for (int k = 0; k < 4 * NB; ++k)
+            if (n0 + k / 4 < NT) b[k] = ld4(vec + 32 * (n0 + k / 4) + 8 * (k % 4) + 4 * h);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4 * NB; ++k)
+            if (n0 + k / 4 < NT) {
+                const int nt = n0 + k / 4, q = k % 4;
+                acc[nt][4 * q + 0] = fmaf(acc[nt][4 * q + 0], inv, b[k].x); acc[nt][4 * q + 1] = fmaf(acc[nt][4 * q + 1], inv, b[k].y);
+                acc[nt][4 * q + 2] = fmaf(acc[nt][4 * q + 2], inv, b[k].z); acc[nt][4 * q + 3] = fmaf(acc[nt][4 * q + 3], inv, b[k].w);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // EPI: 0 = block only, 1 = + raw Linear (Down/Upsample), 2 = + final (LayerNorm + SiLU + Linear, row-major out)

@@ -191,6 +191,41 @@ OTHER_HOT_KERNELS = [
 ]
 
 
+TABLE_DRIVEN_KERNELS = ["k_fused_narrow_lds", "k_fused_narrow_h", "k_fused_narrow_bwd_h", "k_wgrad_h", "k_wgrad", "k_colsum", "k_fused_narrow"]
+
+
+def test_table_driven_kernels_issue_no_flat_memory_instructions(tmp_path):
+    """Kernels that read their operands' addresses from descriptor tables in memory (the fused narrow run forward / backward, the
+    weight-gradient and column-sum launches) declare them global (csrc/dsg_kernels.hpp, as_global): a pointer loaded from memory is
+    generic to hipcc, every access through it a FLAT instruction, and every wait for an LDS read then also waits for all global loads in
+    flight.  Disassembles the gfx950 code object of the built library: no flat_load / flat_store / flat_atomic in those kernels."""
+    import re, shutil, subprocess
+    from diffsg_amd import _lib
+    _lib.build()
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    cos = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(cos) == 1, os.listdir(tmp_path)
+    dis = subprocess.run([objdump, "-d", str(tmp_path / cos[0])], check=True, capture_output=True, text=True).stdout
+    syms = [(m.start(), m.group(1)) for m in re.finditer(r"^[0-9a-f]+ <([^>]+)>:$", dis, re.M)]
+    seen, bad = set(), {}
+    for k, (pos, name) in enumerate(syms):
+        m = re.match(r"_ZN3dsg\d+([A-Za-z_0-9]+?)(?:I|E)", name)
+        if not m or m.group(1) not in TABLE_DRIVEN_KERNELS:
+            continue
+        body = dis[pos:syms[k + 1][0] if k + 1 < len(syms) else len(dis)]
+        seen.add(m.group(1))
+        n_flat = len(re.findall(r"\bflat_(?:load|store|atomic)", body))
+        assert len(re.findall(r"\bglobal_(?:load|store|atomic)", body)) > 0, name
+        if n_flat:
+            bad[name] = n_flat
+    assert seen == set(TABLE_DRIVEN_KERNELS), sorted(set(TABLE_DRIVEN_KERNELS) - seen)
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("group", ["sampling_step", "other_hot"])
 def test_hot_kernels_use_no_scratch_memory(group):
     """Compiled with -Rpass-analysis=kernel-resource-usage (diffsg_amd/_lib.build keeps hipcc's remarks beside the library): every
