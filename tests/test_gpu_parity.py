@@ -781,6 +781,29 @@ def test_train_step_vs_oracle_ragged(name, B):
     assert_grads({k: q.grad for k, q in ddpm.model.named_parameters()}, ref, ref64, f"{name}/{B}")
 
 
+@pytest.mark.parametrize("name,B,T", [("msr80", 200, 300), ("msr3", 300, 1000)])
+def test_train_step_many_timesteps_vs_oracle(name, B, T):
+    """The reference trains MSR-3c with T = 1000: the time-table gradient (dTB = one-hot(ts)^T dh1) then spans several 128-column blocks of
+    the weight-gradient units (one-hot A operand with a non-zero first group, both the wide and the one-out-tile form); loss and every
+    gradient -- the time path's included -- against the CPU oracle."""
+    plan, p = synth_params(name, 21)
+    ddpm = make_ddpm(name, p, T)
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(B + T)
+    y = torch.rand(B, cfg["input_dim"], generator=g)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g)
+    ts = torch.randint(0, T, (1, B), generator=g)
+    noise = torch.randn(B, cfg["input_dim"], generator=g)
+    mask = (torch.rand(B, 1, generator=g) < 0.9).float()
+    loss = ddpm(y.cuda(), cond.cuda(), ts=ts.cuda(), noise=noise.cuda(), cond_mask=mask.cuda())
+    loss.backward()
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    ref_loss, ref = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    _, ref64 = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask, f64=True)
+    assert_grads({k: q.grad for k, q in ddpm.model.named_parameters()}, ref, ref64, f"{name}/{B}/T={T}")
+
+
 def test_train_step_large_launch_vs_oracle():
     """BASELINE training shape (32 768 rows per GPU, + a ragged tail = 1 025 row tiles: the one-wave-per-tile forward,
     k_resblock_bwd_h, the grouped k_wgrad_h) DIRECTLY against the CPU oracle's autograd: loss and every gradient."""
