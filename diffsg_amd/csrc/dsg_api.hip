@@ -254,7 +254,7 @@ struct dsg_handle {
     std::vector<int> wg_fork_ops;      // operator index after whose backward kernel part k starts
     int wg_early_lds = 40960;
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t time_stream = nullptr; hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr};   // the tail of dsg_train_step
+    hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr};   // the tail of dsg_train_step: chain done / time path done / column sums done
     FusedBwdOpH* fbwd_dev = nullptr; int fbwd_n = 0;   // operator table of the fused narrow backward (split path), cached with the descriptors
     ColsumDesc* cs_desc_dev = nullptr; ColsumUnit* cs_unit_dev = nullptr; int cs_units = 0;
     // the descriptor tables depend only on (rows, T, precision mode) and the workspace addresses: built once, reused every step
@@ -1792,7 +1792,6 @@ void dsg_destroy(dsg_handle* h) {
     if (h->fbwd_dev) (void)hipFree(h->fbwd_dev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->time_stream && h->time_stream != h->side_stream) (void)hipStreamDestroy(h->time_stream);
     for (auto& e : h->ev_tail) if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -2360,10 +2359,9 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
         HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        // The step's tail runs on the side stream too, behind the early parts.  (A separate high-priority stream measured 2 % faster in
-        // a process of its own and 2.2x SLOWER -- 4.3 ms per step -- as soon as a second handle was alive in the process, bench.py's
-        // sampling model: profiles/r04_train_tail_ab.txt.  No stream priorities.)
-        h->time_stream = h->side_stream;
+        // (The step's tail runs on the side stream too, behind the early parts.  A separate high-priority stream for it measured 2 %
+        // faster in a process of its own and 2.2x SLOWER -- 4.3 ms per step -- as soon as a second handle was alive in the process,
+        // bench.py's sampling model: profiles/r04_train_tail_ab.txt.  No stream priorities.)
         for (auto& e : h->ev_tail) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // the G and A operands of a part are final once the backward kernel of its last block is enqueued: its weight gradients run
@@ -2422,7 +2420,7 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
     // (k_reduce_ranges: the time_emb weights are ~40 % of the parameters and nothing in the slabs belongs to them).
     mark(2);
     const bool time_beside = h->use_split && next_part > 0 && h->side_stream && h->opt_time_beside;
-    hipStream_t cs_stream = time_beside ? h->time_stream : s;
+    hipStream_t cs_stream = time_beside ? h->side_stream : s;
     unsigned* const gm_all = time_beside ? h->tr_gmax + (size_t)(1 + kMaxWgParts) * kMaxGmax : h->tr_gmax;
     auto units = [&](int lo, int hi, const unsigned* gm, hipStream_t us) {
         if (hi > lo)
@@ -2434,8 +2432,8 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
         // the blocks' slots are complete; the Linears' are not yet, and nothing reads them from this set
         hipLaunchKernelGGL(k_gmax_reduce, dim3(h->n_gmax), dim3(256), 0, s, h->tr_gmax_t, h->gmax_ld, h->tr_gmax);
         HIPCK(hipEventRecord(h->ev_tail[0], s));
-        HIPCK(hipStreamWaitEvent(h->time_stream, h->ev_tail[0], 0));
-        units(u0, h->wg_onehot_end, h->tr_gmax, h->time_stream);
+        HIPCK(hipStreamWaitEvent(h->side_stream, h->ev_tail[0], 0));
+        units(u0, h->wg_onehot_end, h->tr_gmax, h->side_stream);
     }
     hipLaunchKernelGGL(k_cs_reduce, dim3(cdiv(h->cs_slots, 256), h->tr_chunks), dim3(256), 0, cs_stream, h->tr_cs, h->cs_map_dev, h->cs_slots,
                        h->tr_slabs, h->slab_stride, tiles, h->tr_chunks);
@@ -2468,13 +2466,13 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
     };
     if (time_beside) {
         units(h->wg_onehot_end, h->wg_blocks_end, h->tr_gmax, s);
-        HIPCK(hipEventRecord(h->ev_tail[2], h->time_stream));              // column sums done: the Linears' scales
+        HIPCK(hipEventRecord(h->ev_tail[2], h->side_stream));              // column sums done: the Linears' scales
         HIPCK(hipStreamWaitEvent(s, h->ev_tail[2], 0));
         units(h->wg_blocks_end, h->wg_units, gm_all, s);
-        hipLaunchKernelGGL(k_reduce_slabs, reduce_blocks(dtb_n), dim3(256), 0, h->time_stream, h->tr_slabs + dtb0, h->slab_stride, h->tr_chunks,
+        hipLaunchKernelGGL(k_reduce_slabs, reduce_blocks(dtb_n), dim3(256), 0, h->side_stream, h->tr_slabs + dtb0, h->slab_stride, h->tr_chunks,
                            h->tr_gsum + dtb0, dtb_n);
-        time_path(grads_flat, h->time_stream);       // straight into the caller's bucket: the last reduce leaves these regions out
-        HIPCK(hipEventRecord(h->ev_tail[1], h->time_stream));
+        time_path(grads_flat, h->side_stream);       // straight into the caller's bucket: the last reduce leaves these regions out
+        HIPCK(hipEventRecord(h->ev_tail[1], h->side_stream));
         HIPCK(hipStreamWaitEvent(s, h->ev_tail[1], 0));
         mark(4);
         hipLaunchKernelGGL(k_reduce_ranges, reduce_blocks((size_t)h->r2_total), dim3(256), 0, s, h->tr_slabs, h->slab_stride, h->tr_chunks, grads_flat,
