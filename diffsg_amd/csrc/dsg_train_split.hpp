@@ -50,6 +50,7 @@ constexpr unsigned kWimgGH = 0, kWimgGL = 8192, kWimgAH = 16384, kWimgAL = 24576
 
 struct WgradRegs { float4 g0[4], av[4]; float2 ms; int oh; };   // one interval's raw operands of a wave (k_wgrad_h, TB == 1 form)
 
+template <bool HASG1>     // the descriptor has a second gradient tensor (compile time: an unconditional redundant read cost a third more L1 traffic)
 __device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUnit& un, char* __restrict__ img, f32x16 (&acc)[4], float gscale,
                                               int ntiles, int nchunks, int wave, int lane, int NTp, int KT, int g_lo, int ngr, int my_nt,
                                               int my_part, int rsplit) {
@@ -59,7 +60,6 @@ __device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUni
     const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
     const int ngg = NTp * 4, nag = KT * 4;   // groups held by the images
     const int mode = d.amode;
-    const bool hasg1 = d.G1 != nullptr;
     float* const gam = reinterpret_cast<float*>(img + kWimgVec);
     float* const bet = gam + 128;
     if (mode == A_LNSILU && threadIdx.x < 128) {
@@ -107,16 +107,15 @@ __device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUni
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) tq_a[kt] = 64u * ((unsigned)kt ^ q);
 
-    // The second gradient tensor (a skip consumer's: few descriptors) is read one interval ahead only; where there is none the loads
-    // repeat the first tensor's lines and a zero factor drops them -- every load of an interval is unconditional, so that no register
-    // has two reaching definitions (hipcc resolved those with copies behind vmcnt(0) waits).
-    float4 g1[4];
-    const float* const G1p = hasg1 ? d.G1 : d.G0;
-    const float g1s = hasg1 ? gscale : 0.f;
+    // The second gradient tensor (a skip consumer's: few descriptors) is read one interval ahead only.  Every load of an interval is
+    // unconditional, so that no register has two reaching definitions (hipcc resolved those with copies behind vmcnt(0) waits).
+    float4 g1[HASG1 ? 4 : 1];
     auto fetch_g1 = [&](int t) {
-        const float* const gb = G1p + (size_t)t * gstr;
+        if constexpr (HASG1) {
+            const float* const gb = d.G1 + (size_t)t * gstr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g1[i] = ld4(gb + goff[i] + lane4);
+            for (int i = 0; i < 4; ++i) g1[i] = ld4(gb + goff[i] + lane4);
+        }
     };
     auto fetch = [&](WgradRegs& R, int t) {
         const float* const gb = d.G0 + (size_t)t * gstr;
@@ -141,10 +140,9 @@ __device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUni
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (gok[i]) {
-                // (g0 + g1) * 2^e as g0 * 2^e + g1 * 2^e: the scale is a power of two, the same bits
-                const float4 v = R.g0[i];
-                put(kWimgGH, kWimgGL, wofs[i], make_float4(fmaf(g1[i].x, g1s, v.x * gscale), fmaf(g1[i].y, g1s, v.y * gscale),
-                                                           fmaf(g1[i].z, g1s, v.z * gscale), fmaf(g1[i].w, g1s, v.w * gscale)));
+                float4 v = R.g0[i];
+                if constexpr (HASG1) v = make_float4(v.x + g1[i].x, v.y + g1[i].y, v.z + g1[i].z, v.w + g1[i].w);
+                put(kWimgGH, kWimgGL, wofs[i], make_float4(v.x * gscale, v.y * gscale, v.z * gscale, v.w * gscale));
             }
         const bool live = t * 32 + j < d.nrows;        // forward tensors of padded rows are not zero
 #pragma unroll
@@ -200,7 +198,7 @@ __device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUni
     // unconditional -- past the chunk's end it re-reads the last tile -- so that no register of a set has two reaching definitions.
     WgradRegs R0, R1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g1[i] = R0.av[i] = R1.av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; ++i) R0.av[i] = R1.av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     R0.ms = R1.ms = make_float2(0.f, 0.f); R0.oh = R1.oh = -1;
     __syncthreads();                         // the LayerNorm vectors
     if (t_lo >= t_hi) return;
@@ -235,7 +233,7 @@ constexpr unsigned kWimg2GH = 0, kWimg2GL = 4608, kWimg2AH = 9216, kWimg2AL = 25
 template <int KTM>
 struct WgradRegs2 { float4 g0[2], av[2 * KTM]; float2 ms[2]; int oh[2]; };
 
-template <int KTM>
+template <int KTM, bool HASG1>
 __device__ __forceinline__ void wgrad_unit_h2(const WgradDesc& d, const WgradUnit& un, char* __restrict__ img, f32x16 (&acc)[4], float gscale,
                                               int ntiles, int nchunks, int wave, int lane, int KT, int g_lo, int ngr) {
     constexpr int NA = 2 * KTM;
@@ -245,7 +243,6 @@ __device__ __forceinline__ void wgrad_unit_h2(const WgradDesc& d, const WgradUni
     const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
     const int nag = KT * 4;
     const int mode = d.amode;
-    const bool hasg1 = d.G1 != nullptr;
     float* const gam = reinterpret_cast<float*>(img + kWimg2Vec);
     float* const bet = gam + 128;
     if (mode == A_LNSILU && threadIdx.x < 128) {
@@ -297,12 +294,12 @@ __device__ __forceinline__ void wgrad_unit_h2(const WgradDesc& d, const WgradUni
 
     const int t_last = t_hi - 1;
     auto clampt = [&](int t) { return t < t_last ? t : t_last; };
-    float4 g1[2];
-    const float* const G1p = hasg1 ? d.G1 : d.G0;
-    const float g1s = hasg1 ? gscale : 0.f;
+    float4 g1[HASG1 ? 2 : 1];
     auto fetch_g1 = [&](int t0) {
+        if constexpr (HASG1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) g1[i] = ld4(G1p + (size_t)clampt(t0 + i) * gstr + goff + lane4);
+            for (int i = 0; i < 2; ++i) g1[i] = ld4(d.G1 + (size_t)clampt(t0 + i) * gstr + goff + lane4);
+        }
     };
     auto fetch = [&](WgradRegs2<KTM>& R, int t0) {
 #pragma unroll
@@ -330,9 +327,10 @@ __device__ __forceinline__ void wgrad_unit_h2(const WgradDesc& d, const WgradUni
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float keep = t0 + i < t_hi ? 1.f : 0.f;        // a tile beyond the chunk: zero rows
-                const float4 v = R.g0[i];
-                put(kWimg2GH, kWimg2GL, gw[i], make_float4(keep * fmaf(g1[i].x, g1s, v.x * gscale), keep * fmaf(g1[i].y, g1s, v.y * gscale),
-                                                           keep * fmaf(g1[i].z, g1s, v.z * gscale), keep * fmaf(g1[i].w, g1s, v.w * gscale)));
+                float4 v = R.g0[i];
+                if constexpr (HASG1) v = make_float4(v.x + g1[i].x, v.y + g1[i].y, v.z + g1[i].z, v.w + g1[i].w);
+                const float ks = keep * gscale;
+                put(kWimg2GH, kWimg2GL, gw[i], make_float4(v.x * ks, v.y * ks, v.z * ks, v.w * ks));
             }
         }
 #pragma unroll
@@ -428,9 +426,17 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h(const WgradDesc* __restrict_
 
     f32x16 acc[4];
     acc_zero<4>(acc);
-    if (NTp == 1 && KT <= 2) wgrad_unit_h2<2>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
-    else if (NTp == 1) wgrad_unit_h2<4>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
-    else wgrad_unit_h1(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+    const bool g1 = d.G1 != nullptr;
+    if (NTp == 1 && KT <= 2) {
+        if (g1) wgrad_unit_h2<2, true>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
+        else wgrad_unit_h2<2, false>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
+    } else if (NTp == 1) {
+        if (g1) wgrad_unit_h2<4, true>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
+        else wgrad_unit_h2<4, false>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
+    } else {
+        if (g1) wgrad_unit_h1<true>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+        else wgrad_unit_h1<false>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+    }
 
     // ---- waves that split the rows of one n-tile add their partial tiles through LDS, then the first writes the slab
     if (rsplit > 1) {
