@@ -50,7 +50,9 @@ constexpr unsigned kWimgGH = 0, kWimgGL = 8192, kWimgAH = 16384, kWimgAL = 24576
 
 struct WgradRegs { float4 g0[4], av[4]; float2 ms; int oh; };   // one interval's raw operands of a wave (k_wgrad_h, TB == 1 form)
 
-template <bool HASG1>     // the descriptor has a second gradient tensor (compile time: an unconditional redundant read cost a third more L1 traffic)
+// HASG1: the descriptor has a second gradient tensor; ONEHOT: its A operand is the time-table one-hot (nothing to read).  Compile time:
+// as run-time cases behind unconditional redundant reads they cost a third (G1) / a half (one-hot) more L1 traffic.
+template <bool HASG1, bool ONEHOT>
 __device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUnit& un, char* __restrict__ img, f32x16 (&acc)[4], float gscale,
                                               int ntiles, int nchunks, int wave, int lane, int NTp, int KT, int g_lo, int ngr, int my_nt,
                                               int my_part, int rsplit) {
@@ -59,7 +61,7 @@ __device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUni
     const int t_lo = un.chunk * tiles_per_chunk;
     const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
     const int ngg = NTp * 4, nag = KT * 4;   // groups held by the images
-    const int mode = d.amode;
+    const int mode = ONEHOT ? (int)A_ONEHOT : d.amode;
     float* const gam = reinterpret_cast<float*>(img + kWimgVec);
     float* const bet = gam + 128;
     if (mode == A_LNSILU && threadIdx.x < 128) {
@@ -121,8 +123,10 @@ __device__ __forceinline__ void wgrad_unit_h1(const WgradDesc& d, const WgradUni
         const float* const gb = d.G0 + (size_t)t * gstr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) R.g0[i] = ld4(gb + goff[i] + lane4);
+        if constexpr (!ONEHOT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) R.av[i] = ld4(ap[i] + (size_t)t * astr[i] + lane4);
+            for (int i = 0; i < 4; ++i) R.av[i] = ld4(ap[i] + (size_t)t * astr[i] + lane4);
+        }
         if (mode == A_ONEHOT) {
             const int row = t * 32 + j;
             R.oh = d.ts[row < d.nrows ? row : d.nrows - 1];
@@ -233,7 +237,7 @@ constexpr unsigned kWimg2GH = 0, kWimg2GL = 4608, kWimg2AH = 9216, kWimg2AL = 25
 template <int KTM>
 struct WgradRegs2 { float4 g0[2], av[2 * KTM]; float2 ms[2]; int oh[2]; };
 
-template <int KTM, bool HASG1>
+template <int KTM, bool HASG1, bool ONEHOT>
 __device__ __forceinline__ void wgrad_unit_h2(const WgradDesc& d, const WgradUnit& un, char* __restrict__ img, f32x16 (&acc)[4], float gscale,
                                               int ntiles, int nchunks, int wave, int lane, int KT, int g_lo, int ngr) {
     constexpr int NA = 2 * KTM;
@@ -242,7 +246,7 @@ __device__ __forceinline__ void wgrad_unit_h2(const WgradDesc& d, const WgradUni
     const int t_lo = un.chunk * tiles_per_chunk;
     const int t_hi = (t_lo + tiles_per_chunk < ntiles) ? t_lo + tiles_per_chunk : ntiles;
     const int nag = KT * 4;
-    const int mode = d.amode;
+    const int mode = ONEHOT ? (int)A_ONEHOT : d.amode;
     float* const gam = reinterpret_cast<float*>(img + kWimg2Vec);
     float* const bet = gam + 128;
     if (mode == A_LNSILU && threadIdx.x < 128) {
@@ -304,8 +308,10 @@ __device__ __forceinline__ void wgrad_unit_h2(const WgradDesc& d, const WgradUni
     auto fetch = [&](WgradRegs2<KTM>& R, int t0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) R.g0[i] = ld4(d.G0 + (size_t)clampt(t0 + i) * gstr + goff + lane4);
+        if constexpr (!ONEHOT) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) R.av[i] = ld4(ap[i] + (size_t)clampt(t0 + i / KTM) * astr[i] + lane4);
+            for (int i = 0; i < NA; ++i) R.av[i] = ld4(ap[i] + (size_t)clampt(t0 + i / KTM) * astr[i] + lane4);
+        }
         if (mode == A_ONEHOT) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) { const int row = clampt(t0 + i) * 32 + j; R.oh[i] = d.ts[row < d.nrows ? row : d.nrows - 1]; }
@@ -426,17 +432,25 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_h(const WgradDesc* __restrict_
 
     f32x16 acc[4];
     acc_zero<4>(acc);
-    const bool g1 = d.G1 != nullptr;
+    // forms: (second gradient tensor) x (one-hot A operand: the time-table units, which have no second tensor)
+    const bool g1 = d.G1 != nullptr, oh = d.amode == A_ONEHOT;
+#define DSG_WG_ARGS2 d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr
+#define DSG_WG_ARGS1 d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit
     if (NTp == 1 && KT <= 2) {
-        if (g1) wgrad_unit_h2<2, true>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
-        else wgrad_unit_h2<2, false>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
+        if (oh) wgrad_unit_h2<2, false, true>(DSG_WG_ARGS2);
+        else if (g1) wgrad_unit_h2<2, true, false>(DSG_WG_ARGS2);
+        else wgrad_unit_h2<2, false, false>(DSG_WG_ARGS2);
     } else if (NTp == 1) {
-        if (g1) wgrad_unit_h2<4, true>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
-        else wgrad_unit_h2<4, false>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, KT, g_lo, ngr);
+        if (oh) wgrad_unit_h2<4, false, true>(DSG_WG_ARGS2);
+        else if (g1) wgrad_unit_h2<4, true, false>(DSG_WG_ARGS2);
+        else wgrad_unit_h2<4, false, false>(DSG_WG_ARGS2);
     } else {
-        if (g1) wgrad_unit_h1<true>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
-        else wgrad_unit_h1<false>(d, un, img, acc, gscale, ntiles, nchunks, wave, lane, NTp, KT, g_lo, ngr, my_nt, my_part, rsplit);
+        if (oh) wgrad_unit_h1<false, true>(DSG_WG_ARGS1);
+        else if (g1) wgrad_unit_h1<true, false>(DSG_WG_ARGS1);
+        else wgrad_unit_h1<false, false>(DSG_WG_ARGS1);
     }
+#undef DSG_WG_ARGS1
+#undef DSG_WG_ARGS2
 
     // ---- waves that split the rows of one n-tile add their partial tiles through LDS, then the first writes the slab
     if (rsplit > 1) {
