@@ -2337,8 +2337,18 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
     auto mark = [&](int i) { if (h->train_prof) (void)hipEventRecord(h->tev[i], s); };
     mark(0);
     if (ts != h->tr_ts) HIPCK(hipMemcpyAsync(h->tr_ts, ts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_linspace_t, dim3(cdiv(T, 256)), dim3(256), 0, s, h->tvals, T);
-    run_time_path(h, T, s, true);
+    // The time path forward (TimeEmbedding + the blocks' time_emb Linears over the T table rows: five short dependent launches) needs
+    // nothing of the batch: once the side stream exists (large batches, from the second step on) it runs there, beside the draws'
+    // consumers (condition fragments, q-sample, condition embeddings), and joins in front of the first block.
+    const bool time_fwd_beside = h->side_stream && h->opt_time_beside && h->use_split;
+    hipStream_t tstream = time_fwd_beside ? h->side_stream : s;
+    if (time_fwd_beside) {
+        HIPCK(hipEventRecord(h->ev_tail[0], s));                           // the weights of this step (optimizer step, re-pack) are in place
+        HIPCK(hipStreamWaitEvent(h->side_stream, h->ev_tail[0], 0));
+    }
+    hipLaunchKernelGGL(k_linspace_t, dim3(cdiv(T, 256)), dim3(256), 0, tstream, h->tvals, T);
+    run_time_path(h, T, tstream, true);
+    if (time_fwd_beside) HIPCK(hipEventRecord(h->ev_tail[2], h->side_stream));
     hipLaunchKernelGGL(k_cond_frag, dim3(cdiv(tiles * CG * 256, 256)), dim3(256), 0, s, cond, cond_mask, B, C, CG, h->condfrag, tiles);
     hipLaunchKernelGGL(k_qsample, dim3(cdiv(tiles * DG * 256, 256)), dim3(256), 0, s, y, noise, h->tr_ts, sqrt_acp, sqrt_1m_acp, B, D,
                        h->tr_yt_rm, trp(h, h->tr_yt_frag), tiles);
@@ -2346,6 +2356,7 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
     if (h->use_split) run_cond_embed(h, B, s);
     RunCtx c{B, 1, 0, h->tr_yt_rm, h->eps, nullptr, h->tr_ts, true, h->use_split};
     if (prepare_fused(h, c, s)) return 1;
+    if (time_fwd_beside) HIPCK(hipStreamWaitEvent(s, h->ev_tail[2], 0));   // the time table
     run_unet(h, c, s);
     hipLaunchKernelGGL(k_loss_grad, dim3(kRedBlocks), dim3(256), 0, s, h->eps, noise, B, D, trp(h, h->tr_deps), tiles, h->red);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, s, h->red, kRedBlocks, (double)B * (double)D, loss_out);
