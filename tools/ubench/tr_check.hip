@@ -11,15 +11,17 @@ __device__ __forceinline__ unsigned wimg_off(unsigned row, unsigned ch) { return
 __global__ void k(int* bad, float* dump) {
     __shared__ __attribute__((aligned(16))) char img[8192];
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    // store: value(row, feature) = row * 128 + feature  (exact in f16 up to 2048: rows 0..15 checked exactly, the rest modulo)
+    // two passes (f16 holds integers up to 2048 exactly): mode 0: value(row, feature) = (row & 15) * 128 + feature; mode 1: value = row
+    const int li = lane & 15, q = li >> 2, p = li & 3, sub = (lane >> 4) & 1;
+    int nbad = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+    __syncthreads();
     for (int g = 0; g < 16; ++g) {
         _Float16 v[4];
-        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(float)((j & 15) * 128 + 8 * g + 4 * h + e);
+        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(float)(mode ? j : (j & 15) * 128 + 8 * g + 4 * h + e);
         *reinterpret_cast<uint2*>(img + wimg_off(j, g) + 8 * h) = *reinterpret_cast<uint2*>(v);
     }
     __syncthreads();
-    const int li = lane & 15, q = li >> 2, p = li & 3, sub = (lane >> 4) & 1;
-    int nbad = 0;
     for (int s = 0; s < 2; ++s)
         for (int T = 0; T < 4; ++T) {
             _Float16 got[8];
@@ -31,18 +33,19 @@ __global__ void k(int* bad, float* dump) {
             }
             for (int e = 0; e < 8; ++e) {
                 const int row = 16 * s + 8 * h + e, feat = 32 * T + (lane & 31);
-                const float want = (float)((row & 15) * 128 + feat);
+                const float want = (float)(mode ? row : (row & 15) * 128 + feat);
                 if ((float)got[e] != want) ++nbad;
-                if (s == 0 && T == 1) dump[lane * 8 + e] = (float)got[e];
+                if (mode == 0 && s == 0 && T == 1) dump[lane * 8 + e] = (float)got[e];
             }
         }
+    }
     atomicAdd(bad, nbad);
 }
 int main() {
     int* bad; float* dump; hipMalloc(&bad, 4); hipMalloc(&dump, 64 * 8 * 4); hipMemset(bad, 0, 4);
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, bad, dump);
     int hb = -1; float hd[512]; hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost); hipMemcpy(hd, dump, sizeof hd, hipMemcpyDeviceToHost);
-    printf("wrong elements: %d of 4096\n", hb);
+    printf("wrong elements: %d of 8192\n", hb);
     if (hb) for (int l = 0; l < 64; l += 9) { printf("lane %2d:", l); for (int e = 0; e < 8; ++e) printf(" %6.0f", hd[l * 8 + e]); printf("\n"); }
     return hb != 0;
 }
