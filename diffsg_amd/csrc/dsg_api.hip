@@ -249,6 +249,7 @@ struct dsg_handle {
     std::vector<int> wg_forks = {3, 6};
     std::vector<int> wg_part_end;      // units [wg_part_end[k-1], wg_part_end[k]) = part k; the rest runs on the caller's stream
     long long* r2_dev = nullptr; int r2_n = 0; long long r2_total = 0;   // [starts | prefix]: the parameter ranges the last reduce covers
+    bool r2_vec4 = false;              // ... in float4 units (k_reduce_ranges4)
     int wg_onehot_end = 0;             // ... and opens with the final part's time-table units: [wg_part_end.back(), wg_onehot_end),
     int wg_blocks_end = 0;             // then its residual blocks' other units [wg_onehot_end, wg_blocks_end), then the plain Linears'
     std::vector<int> wg_fork_ops;      // operator index after whose backward kernel part k starts
@@ -1584,8 +1585,20 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
             at = std::max(at, sk.first + sk.second);
         }
         if (h->total_params > at) { starts.push_back(at); prefix.push_back(acc); acc += h->total_params - at; }
+        // every range on a multiple of four elements (all shipped configurations: layer widths are multiples of 4) and the slab stride
+        // too: the reduce then moves 16 bytes per access, the table counts float4 units
+        bool vec4 = h->slab_stride % 4 == 0;
+        for (size_t i = 0; i < starts.size(); ++i) {
+            const long long len = (i + 1 < starts.size() ? prefix[i + 1] : acc) - prefix[i];
+            if (starts[i] % 4 || len % 4) vec4 = false;
+        }
+        h->r2_vec4 = vec4;
         h->r2_n = (int)starts.size(); h->r2_total = acc;
         tab = starts; tab.insert(tab.end(), prefix.begin(), prefix.end());
+        if (vec4) {                                        // the same table in float4 units behind the scalar one
+            for (long long v : starts) tab.push_back(v / 4);
+            for (long long v : prefix) tab.push_back(v / 4);
+        }
         if (h->r2_dev) (void)hipFree(h->r2_dev);
         HIPCK(hipMalloc(&h->r2_dev, tab.size() * sizeof(long long)));
         HIPCK(hipMemcpy(h->r2_dev, tab.data(), tab.size() * sizeof(long long), hipMemcpyHostToDevice));
@@ -2486,8 +2499,13 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
         HIPCK(hipEventRecord(h->ev_tail[1], h->side_stream));
         HIPCK(hipStreamWaitEvent(s, h->ev_tail[1], 0));
         mark(4);
-        hipLaunchKernelGGL(k_reduce_ranges, reduce_blocks((size_t)h->r2_total), dim3(256), 0, s, h->tr_slabs, h->slab_stride, h->tr_chunks, grads_flat,
-                           (const long long*)h->r2_dev, (const long long*)(h->r2_dev + h->r2_n), h->r2_n, h->r2_total);
+        if (h->r2_vec4 && (reinterpret_cast<unsigned long long>(grads_flat) & 15ull) == 0)
+            hipLaunchKernelGGL(k_reduce_ranges4, reduce_blocks((size_t)h->r2_total / 4), dim3(256), 0, s, h->tr_slabs, h->slab_stride, h->tr_chunks,
+                               grads_flat, (const long long*)(h->r2_dev + 2 * h->r2_n), (const long long*)(h->r2_dev + 3 * h->r2_n), h->r2_n,
+                               h->r2_total / 4);
+        else
+            hipLaunchKernelGGL(k_reduce_ranges, reduce_blocks((size_t)h->r2_total), dim3(256), 0, s, h->tr_slabs, h->slab_stride, h->tr_chunks,
+                               grads_flat, (const long long*)h->r2_dev, (const long long*)(h->r2_dev + h->r2_n), h->r2_n, h->r2_total);
     } else {
         if (h->use_split) {
             if (next_part) HIPCK(hipEventRecord(h->ev_join, h->side_stream));

@@ -1181,6 +1181,26 @@ __global__ void k_reduce_ranges(const float* __restrict__ slabs, size_t slab_str
     }
 }
 
+// ... four elements per thread (16-byte accesses) where every range starts and ends on a multiple of four elements; `starts` /
+// `prefix` / `total` then count float4 units
+__global__ void k_reduce_ranges4(const float* __restrict__ slabs, size_t slab_stride, int nchunks, float* __restrict__ out,
+                                 const long long* __restrict__ starts, const long long* __restrict__ prefix, int nranges, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nranges - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (prefix[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const size_t e = (size_t)(starts[lo] + (i - prefix[lo])) * 4;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < nchunks; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)c * slab_stride + e);
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + e) = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Time-path backward on the [entries x .] tables: tiny dense products, one thread per output.
 //   C[i][j] (+)= sum_l A[i*ai + l*al] * B[l*bl + j*bj]      (optional elementwise factor on A: swish'(Apre))
