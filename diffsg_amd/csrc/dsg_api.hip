@@ -108,7 +108,7 @@ struct Op {
 };
 
 // launches with fewer row tiles than this leave SIMDs idle with one wave per tile (dsg_set_launch_policy)
-constexpr int kCoopMaxTilesDefault = 512, kNarrowSmallMaxTilesDefault = 1024;
+constexpr int kCoopMaxTilesDefault = 512, kNarrowSmallMaxTilesDefault = 1024, kCoopMaxTilesTrain = 1024;
 constexpr int kPanelMinTilesDefault = 2048;    // 256 CUs x 8 tiles: below this the persistent panel kernels leave CUs idle
 
 }  // namespace
@@ -702,7 +702,10 @@ void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStr
     fill_block_args_h(h, r, b, a);
     const int ks1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2;
     const bool coop_fits = ks1 * 128 <= kCoopLdsU4 / (4 / (r.N / 32 > 0 ? r.N / 32 : 1)) / 2 && ks1 <= (r.sclin ? r.N / 8 : r.N / 16);   // LDS images, register bound
-    if ((r.N == 64 || r.N == 128) && coop_fits && a.b.ntiles <= h->coop_max_tiles) {
+    // the training forward (it stores h1 / h2) takes the cooperative form up to 1 024 tiles -- 32 768 rows: 1.939 -> 1.923 ms per step
+    // (profiles/r04_train_tail_ab.txt); a sampling launch of that size has two passes' worth of tiles per row and stays as measured
+    const int coop_max = (a.b.save_h1 && h->coop_max_tiles > 0 && h->coop_max_tiles < kCoopMaxTilesTrain) ? kCoopMaxTilesTrain : h->coop_max_tiles;
+    if ((r.N == 64 || r.N == 128) && coop_fits && a.b.ntiles <= coop_max) {
         const int tpw = 4 / (r.N / 32);
         const dim3 grid(cdiv(a.b.ntiles, tpw)), block(256);
         if (r.N == 128) {

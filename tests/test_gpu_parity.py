@@ -856,11 +856,12 @@ def test_training_reduces_loss_and_matches_cpu_adam():
         assert rel(v, cpu[k].detach()) <= 1e-3, k
 
 
-def test_train_step_large_launch_split_vs_exact_f32():
-    """BASELINE training shape (32 768 rows + a ragged tail: 1 025 row tiles, above the cooperative threshold): loss and
-    every gradient of the split path (one-wave-per-tile forward, k_resblock_bwd_h, k_wgrad_h) against the exact-f32 path
-    (k_resblock / k_resblock_bwd / k_wgrad) on the same draws."""
-    name, B, T = "msr80", 32768 + 17, 20
+@pytest.mark.parametrize("B", [32768 + 17, 32768])
+def test_train_step_large_launch_split_vs_exact_f32(B):
+    """BASELINE training shape (32 768 rows + a ragged tail: 1 025 row tiles, above every cooperative threshold; and exactly 32 768 rows =
+    1 024 tiles, where the training forward takes the cooperative form of the wide blocks): loss and every gradient of the split path
+    against the exact-f32 path (k_resblock / k_resblock_bwd / k_wgrad) on the same draws."""
+    name, T = "msr80", 20
     plan, p = synth_params(name, 13)
     ddpm = make_ddpm(name, p, T)
     cfg = CONFIGS[name]
