@@ -1575,7 +1575,8 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
     HIPCK(hipMemcpyAsync(h->cs_unit_dev, cu.data(), cu.size() * sizeof(ColsumUnit), hipMemcpyHostToDevice, s));
     HIPCK(hipStreamSynchronize(s));  // host vectors go out of scope
     memcpy(h->td_key, key, sizeof key);
-    {   // the ranges of the flat gradient that the slabs hold: everything but what the time path produces (dsg_train_step)
+    if (!h->r2_dev) {   // the ranges of the flat gradient that the slabs hold: everything but what the time path produces (dsg_train_step);
+                        // a function of the parameter layout only (the slab stride is a multiple of 64 whatever T): built once per handle
         std::vector<std::pair<long long, long long>> skip;
         for (const ResP& r : h->res) skip.push_back({P[r.te.w].off, P[r.te.w].numel});
         for (int pi : {h->temb_l1w, h->temb_l1b, h->temb_l2w, h->temb_l2b}) skip.push_back({P[pi].off, P[pi].numel});
@@ -1602,7 +1603,6 @@ int build_train_descs(dsg_handle* h, int B, int T, hipStream_t s) {
             for (long long v : starts) tab.push_back(v / 4);
             for (long long v : prefix) tab.push_back(v / 4);
         }
-        if (h->r2_dev) (void)hipFree(h->r2_dev);
         HIPCK(hipMalloc(&h->r2_dev, tab.size() * sizeof(long long)));
         HIPCK(hipMemcpy(h->r2_dev, tab.data(), tab.size() * sizeof(long long), hipMemcpyHostToDevice));
     }
