@@ -213,7 +213,10 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
                 "avg_launch_ms": wg, "share_of_step": wg / (dt / steps * 1e3),
                 "algorithmic_tflops": f_wg * B / (wg * 1e-3) / 1e12,
                 "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "phase_ms": {"forward": fwd, "activation_backward": bwd, "column_sums": cs, "weight_gradients": wg, "reduce_and_time_path": tail}}
+                "phase_ms": {"forward": fwd, "activation_backward": bwd, "column_sums": cs, "weight_gradients": wg, "reduce_and_time_path": tail},
+                "phase_note": "event marks on the caller's stream; from 32 768 rows on the column sums and the time-path backward run on the side "
+                              "stream beside the weight gradients, so `column_sums` is only the max|G| reduce and `reduce_and_time_path` only "
+                              "the closing reduce (DESIGN.md 5)"}
         # algorithmic bytes of the launch: every saved activation (A operand: x, h1, h2 per block + Linear inputs) and every
         # gradient tensor (G operand) read once, float32
         blocks = [(128, 128, 0)] * 2 + [(64, 64, 0)] * 2 + [(32, 32, 0)] * 2 + [(16, 16, 0)] * 2 + [(8, 8, 0)] * 4 + \
