@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Static look at the gfx950 code object of the built library for the patterns that cost time without showing up as scratch or registers
+(DESIGN.md 9):  python tools/isa_lint.py [substring of kernel names ...]
+per kernel: instructions, FLAT accesses (a pointer read from memory: as_global it), global loads that are followed within four
+instructions by `s_waitcnt vmcnt(0)` (a load inside a wave-uniform branch, or a load-use pair the scheduler could not separate), full
+LDS drains (`lgkmcnt(0)`), register moves, branches.  Runs on the CPU (llvm-objdump from the ROCm tree)."""
+import os, re, shutil, subprocess, sys, tempfile
+from collections import Counter
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+FILT = next((f for f in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "/usr/bin/c++filt") if os.path.exists(f)), "")
+
+
+def disassemble(so):
+    tmp = tempfile.mkdtemp()
+    try:
+        shutil.copy(so, os.path.join(tmp, "lib.so"))
+        subprocess.run([OBJDUMP, "--offloading", "lib.so"], check=True, capture_output=True, cwd=tmp)
+        co = [f for f in os.listdir(tmp) if "gfx950" in f][0]
+        return subprocess.run([OBJDUMP, "-d", os.path.join(tmp, co)], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def kernels(dis):
+    syms = [(m.start(), m.group(1)) for m in re.finditer(r"^[0-9a-f]+ <([^>]+)>:$", dis, re.M)]
+    for k, (pos, name) in enumerate(syms):
+        body = dis[pos:syms[k + 1][0] if k + 1 < len(syms) else len(dis)]
+        ins = [l.split("\t")[1].split("//")[0].strip() for l in body.split("\n") if "\t" in l]
+        yield name, [i for i in ins if i]
+
+
+def demangle(names):
+    if not FILT:
+        return {n: n for n in names}
+    out = subprocess.run([FILT], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    return dict(zip(names, out))
+
+
+def main():
+    want = sys.argv[1:]
+    dis = disassemble(os.path.join(ROOT, "diffsg_amd", "libdiffsg_hip.so"))
+    rows = []
+    for name, ins in kernels(dis):
+        if not name.startswith("_ZN3dsg"):
+            continue
+        ops = Counter(i.split()[0] for i in ins)
+        waits = [k for k, i in enumerate(ins) if i.startswith("s_waitcnt")]
+        vm0 = [k for k in waits if "vmcnt(0)" in ins[k]]
+        load_then_wait = sum(1 for k in vm0 if any(x.startswith("global_load") or x.startswith("flat_load") for x in ins[max(0, k - 4):k]))
+        rows.append((name, len(ins), sum(v for o, v in ops.items() if o.startswith("flat_")), load_then_wait, len(vm0),
+                     sum(1 for k in waits if "lgkmcnt(0)" in ins[k]), ops.get("v_mov_b32_e32", 0) + ops.get("v_mov_b64_e32", 0),
+                     sum(v for o, v in ops.items() if o.startswith("s_cbranch")), sum(v for o, v in ops.items() if o.startswith("v_mfma"))))
+    names = demangle([r[0] for r in rows])
+    print(f"{'kernel':72s} {'instr':>6s} {'flat':>5s} {'ld->vm0':>7s} {'vm0':>4s} {'lgkm0':>5s} {'v_mov':>5s} {'br':>4s} {'mfma':>5s}")
+    for r in sorted(rows, key=lambda r: -r[1]):
+        dn = re.sub(r"\(.*", "", names[r[0]]).replace("void ", "").replace("dsg::", "")
+        if want and not any(w in dn for w in want):
+            continue
+        print(f"{dn[:72]:72s} {r[1]:6d} {r[2]:5d} {r[3]:7d} {r[4]:4d} {r[5]:5d} {r[6]:5d} {r[7]:4d} {r[8]:5d}")
+
+
+if __name__ == "__main__":
+    main()
