@@ -87,6 +87,19 @@ def self_launch(a):
     raise SystemExit(rc)
 
 
+BOX_REF_MIX_GSLOTS = 50.0      # nominal rate of the MFMA + 6-vector-instruction probe: `value_at_ref_box` = value x this / box.mix_gslots
+
+
+def box_calibrate():
+    """dsg_box_calibrate on the current device: {mfma_tflops, mix_gslots, copy_gbs} of three fixed probes (how to compare
+    two lines measured on different boxes)."""
+    import ctypes
+    from diffsg_amd import _lib
+    o = (ctypes.c_float * 3)()
+    _lib.check(_lib.lib().dsg_box_calibrate(o, _lib.stream_ptr()))
+    return {"mfma_tflops": round(o[0], 1), "mix_gslots": round(o[1], 2), "copy_gbs": round(o[2], 1)}
+
+
 def cpu_baseline(sample_rows=4096, steps=2, B_ref=65536):
     """Oracle timed on the host: `steps` reverse steps of a `sample_rows`-row batch.  The thread count is the best
     of {32, 16, 8} on a one-step probe (hundreds of small ATen ops oversubscribe a 128-core host: all cores is slower)."""
@@ -239,6 +252,16 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
         roof["algorithmic_bytes_per_launch"] = per_row * B
         roof["achieved"] = per_row * B / (wg * 1e-3) / 1e9
         roof["frac"] = roof["achieved"] / PEAK_HBM_GBS
+        # counter traffic, imported like the sampling leg's (labelled; separate --pmc passes of tools/pmc_train.sh at 32 768 rows)
+        ttp = os.path.join(ROOT, "profiles", "traffic_train.json")
+        if os.path.exists(ttp) and B == 32768:
+            tt = json.load(open(ttp))
+            kw = tt["kernels"].get("k_wgrad_h", {})
+            roof["traffic"] = kw.get("bytes_per_launch")
+            roof["traffic_per_step_all_k_wgrad_h_launches"] = kw.get("bytes_per_step")
+            roof["step_traffic_bytes_listed_kernels"] = tt.get("bytes_per_step_listed_kernels")
+            roof["traffic_source"] = "imported, not measured in this run: profiles/traffic_train.json <- " + tt.get("summary", "") + \
+                                     " (mean k_wgrad_h launch, five per step; 2 x FETCH_SIZE + WRITE_SIZE, fabric side)"
     return {"roofline": roof, "samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": B, "global_batch": world * B,
             "steps": steps, "T": 20, "final_loss": float(loss.detach()), "draws": "device Philox per rank (dsg_train_step_seeded, seed 1000 + rank)", "achieved_tflops": sps / world * f_train / 1e12,
             "frac_f32_mfma": sps / world * f_train / 1e12 / PEAK_F32_TFLOPS, "grad_bucket_bytes": int(ddpm.grad_bucket.numel()) * 4,
@@ -265,6 +288,7 @@ def main():
     ap.add_argument("--no-f32-exact", action="store_true", help="skip the exact-float32 re-run of the same K steps")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE config-2 sub-record (MSR-3c, 8192 rows, T = 1000)")
     ap.add_argument("--warm-seconds", type=float, default=0.3, help="untimed clock warm-up before the timed steps")
+    ap.add_argument("--repeats", type=int, default=7, help="consecutive timed K-step sample() calls; `value` is the median (each is exactly K steps)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -315,15 +339,23 @@ def main():
     # the K-step schedule's coefficient table (4 floats per step, a function of the registered schedule buffers only) is built
     # on an object's first call and cached on it; the timed object is fresh only because the warm-up uses its own W-step schedule
     ddpm_k._coef_table()
-    barrier()
-    t0 = time.perf_counter()
-    y0 = ddpm_k.sample(cond, a.omega, seed=2)   # exactly K timed steps
-    barrier()
-    dt = time.perf_counter() - t0
+    box = box_calibrate()                 # fixed MFMA / copy probes on this box, right before the timed region (also keeps the clock up)
     from diffsg_amd import parallel as par
-    ev = par.run_evidence(dev, dt, K)
+    # R consecutive timed calls of exactly K steps each, every one between barrier + synchronize; `value` is the MEDIAN call (the
+    # first call of a process and a box's clock excursions fall out of it), min / max ride along in `repeats`
+    evs = []
+    for _ in range(max(a.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        y0 = ddpm_k.sample(cond, a.omega, seed=2)   # exactly K timed steps
+        barrier()
+        evs.append(par.run_evidence(dev, time.perf_counter() - t0, K))    # max over ranks of this call
+    evs_sorted = sorted(evs, key=lambda e: e["max_seconds"])
+    ev = evs_sorted[len(evs_sorted) // 2]
     dt = ev["max_seconds"]
+    rep_ms = [e["max_seconds"] / K * 1e3 for e in evs]
     assert torch.isfinite(y0).all()
+    box_after = box_calibrate()
 
     # the same K steps on the exact-float32 kernels (v_mfma_f32_32x32x2_f32), so that a strict-fp32 figure always sits beside the
     # split-f16 one.  Untimed warm-up first: the precision switch drops the captured step graphs.
@@ -399,6 +431,15 @@ def main():
                                    f"(64,32,16,8), n_blocks 2), omega={a.omega:g}, device Philox noise; rows sharded, no collective",
                        "batch_per_gpu": B, "solution_dim": 80, "parallelism": f"rows x{world}"},
             "row_steps_per_s": world * K * B / dt,
+            # `value` = K / the median of R consecutive timed K-step calls; the spread of the calls and this box's rates on two fixed
+            # probes ride along, and `value_at_ref_box` rescales the median by the box's matrix-core probe
+            "repeats": {"n": len(rep_ms), "ms_per_step_min": min(rep_ms), "ms_per_step_median": step_ms, "ms_per_step_max": max(rep_ms),
+                        "ms_per_step_all": [round(v, 4) for v in rep_ms]},
+            "box": {"before": box, "after": box_after, "ref_mix_gslots": BOX_REF_MIX_GSLOTS,
+                    "probe": "dsg_box_calibrate, median of five ~5-ms launches each: mfma_tflops = dependent v_mfma_f32_32x32x16_f16 on every SIMD; "
+                             "mix_gslots = the same with 6 vector instructions behind every MFMA (1e9 slots/s); copy_gbs = 256 MiB float4 device "
+                             "copy, read + written bytes"},
+            "value_at_ref_box": world * K / dt * BOX_REF_MIX_GSLOTS / max(0.5 * (box["mix_gslots"] + box_after["mix_gslots"]), 1e-3),
             "roofline": {"bound": "mfma", "kernel": f"{kname} ({len(dom)} launches/step: {', '.join(r[0] for r in dom)})",
                          "achieved": mfma_x * ach, "peak": unit_peak, "unit": "TFLOP/s", "frac": mfma_x * ach / unit_peak,
                          "mfma_unit": "v_mfma_f32_32x32x16_f16, 3 per float32 product (hi*hi + hi*lo + lo*hi)" if split else "v_mfma_f32_32x32x2_f32",

@@ -226,14 +226,15 @@ class UNet1D(nn.Module):
             if not hd:
                 raise RuntimeError("libdiffsg_hip: " + L.dsg_last_error().decode())
             nat.handle = hd
-            if twin:                       # a twin starts with the settings the primary handle was given
-                st = self.__dict__.get("_settings", {})
-                if "precision" in st:
-                    _lib.check(L.dsg_set_precision(hd, st["precision"]))
-                if "policy" in st:
-                    _lib.check(L.dsg_set_launch_policy(hd, *st["policy"]))
-                for code, val in st.get("options", {}).items():
-                    _lib.check(L.dsg_set_option(hd, code, val))
+            # every new handle starts with the module's settings: a twin, and also the primary handle of a deep-copied module, which
+            # keeps `_settings` but gets a fresh _Native (its twin would otherwise run f32 beside a split_f16 primary)
+            st = self.__dict__.get("_settings", {})
+            if "precision" in st:
+                _lib.check(L.dsg_set_precision(hd, st["precision"]))
+            if "policy" in st:
+                _lib.check(L.dsg_set_launch_policy(hd, *st["policy"]))
+            for code, val in st.get("options", {}).items():
+                _lib.check(L.dsg_set_option(hd, code, val))
             n = L.dsg_param_count(hd)
             names = [L.dsg_param_name(hd, i).decode() for i in range(n)]
             if names != [k for k, _ in params]:
@@ -289,20 +290,27 @@ class UNet1D(nn.Module):
         code = {"split_f16": 0, "f32": 1}[mode]
         for hd in self._all_handles():
             _lib.check(_lib.lib().dsg_set_precision(hd, code))
-        self._native.precision = mode
         self.__dict__.setdefault("_settings", {})["precision"] = code
 
     @property
     def precision(self):
         """The handle's current arithmetic mode ("split_f16" unless `set_precision` changed it)."""
-        return getattr(self._native, "precision", "split_f16")
+        return {0: "split_f16", 1: "f32"}[self.__dict__.get("_settings", {}).get("precision", 0)]
 
     def range_exceeded(self):
         """True if, since the last query, a raw operand of the split-f16 path left fp16's range (dsg_range_status;
         synchronises the device and clears the flag).  Outputs computed meanwhile are then wrong."""
-        flag = ctypes.c_int(0)
-        _lib.check(_lib.lib().dsg_range_status(self.native_handle(), ctypes.byref(flag)))
-        return bool(flag.value)
+        hit = False
+        # every handle that EXISTS (a module that has not launched anything has no flag to read; the twin handle of a split training
+        # step has a flag word of its own)
+        for nat in [self._native] + list(self.__dict__.get("_twins", {}).values()):
+            hd = nat.handle
+            if hd is None:
+                continue
+            flag = ctypes.c_int(0)
+            _lib.check(_lib.lib().dsg_range_status(hd, ctypes.byref(flag)))
+            hit = hit or bool(flag.value)
+        return hit
 
     def check_range(self):
         """Raise if `range_exceeded()`: the caller should switch to `set_precision("f32")` and repeat the call."""
@@ -322,8 +330,9 @@ class UNet1D(nn.Module):
         """Per-handle kernel-form switches (dsg_set_option): "narrow_valu8" -- the 8-wide bottom of the net on the vector
         unit in float32 inside large sampling launches (default on); "train_time_beside" -- the time-path backward of large
         training steps on the side stream beside the last weight-gradient launch (default on); "wgrad_narrow_part" -- the narrow
-        run's weight gradients as a third early part (default off)."""
-        code = {"narrow_valu8": 1, "train_time_beside": 2, "wgrad_narrow_part": 4}[name]
+        run's weight gradients as a third early part (default off); "tile_step" -- small launches run a denoiser pass as feature_proj + one
+        launch that walks every operator per row tile (default on; csrc/dsg_tile.hpp)."""
+        code = {"narrow_valu8": 1, "train_time_beside": 2, "wgrad_narrow_part": 4, "tile_step": 8}[name]
         for hd in self._all_handles():
             _lib.check(_lib.lib().dsg_set_option(hd, code, int(value)))
         self.__dict__.setdefault("_settings", {}).setdefault("options", {})[code] = int(value)

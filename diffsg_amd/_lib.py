@@ -205,6 +205,7 @@ _SIGS = {
                                    ctypes.POINTER(ctypes.c_double)]),
     "dsg_op_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_int)]),
+    "dsg_box_calibrate": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]),
     "dsg_time_op": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                    ctypes.c_void_p]),
 }

@@ -7,6 +7,7 @@
 #include "dsg_wide.hpp"
 #include "dsg_panel.hpp"
 #include "dsg_res64.hpp"
+#include "dsg_tile.hpp"
 #include "dsg_train_split.hpp"
 #include "dsg_eval.hpp"
 #include "dsg_labelgen.hpp"
@@ -174,6 +175,7 @@ struct dsg_handle {
     int* step_dev = nullptr;
     double* renorm_stats = nullptr;              // dsg_set_renorm_hook: caller's 3 doubles (device), reduced across ranks by `renorm_fn`
     void (*renorm_fn)(void*) = nullptr; void* renorm_user = nullptr;
+    int device = 0;              // the device that was current in dsg_create: the settings / status entry points select it themselves
     int* range_flag = nullptr;   // device word: a raw split-path operand left fp16's range since the last dsg_range_status
     CallParams* call_dev = nullptr;
     hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream)
@@ -188,6 +190,11 @@ struct dsg_handle {
     FusedOp* fused_dev = nullptr;
     std::vector<FusedOp> fused_host;
     FusedOpH* fusedh_dev = nullptr;
+    // operator table of the WHOLE net for k_unet_tile (dsg_tile.hpp: one launch per pass for small batches), rebuilt with the fused
+    // narrow run's table; tile_valid: the net has the shapes the kernel covers; opt_tile: dsg_set_option(DSG_OPT_TILE_STEP)
+    FusedOpH* tileops_dev = nullptr;
+    std::vector<FusedOpH> tileops_host;
+    bool tile_valid = false, opt_tile = true;
     FusedOpH* fusedh_train_dev = nullptr;   // the same run for the training forward (every output stored, h1/h2 saved)
     const void* fusedh_train_key[4] = {nullptr, nullptr, nullptr, nullptr}; int fusedh_train_rows = 0;
     // inference tables (dsg_sample / dsg_unet_forward / dsg_time_op share them): what the device copy was built for
@@ -920,6 +927,42 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
     }
     if (sp) HIPCK(hipMemcpyAsync(c.train ? h->fusedh_train_dev : h->fusedh_dev, h->fusedh_host.data(), h->fusedh_host.size() * sizeof(FusedOpH), hipMemcpyHostToDevice, s));
     else HIPCK(hipMemcpyAsync(h->fused_dev, h->fused_host.data(), n * sizeof(FusedOp), hipMemcpyHostToDevice, s));
+    if (sp && !c.train) {
+        // the whole net's table for k_unet_tile: the run's entries as above, every other operator stored (its consumer reads memory)
+        const int nops = (int)h->ops.size();
+        h->tileops_host.assign(nops, FusedOpH{});
+        bool ok = nops >= 2 && h->ops[0].kind == OP_PROJ && h->fuse_lo >= 1;
+        int wide = 0;
+        for (int i = 0; i < nops && ok; ++i) {
+            const Op& op = h->ops[i];
+            FusedOpH& f = h->tileops_host[i];
+            memset(&f, 0, sizeof f);
+            if (i >= h->fuse_lo && i < h->fuse_hi) { f = h->fusedh_host[i - h->fuse_lo]; continue; }
+            f.store_out = 1;
+            if (op.kind == OP_RES) {
+                const ResP& r = h->res[op.p];
+                BlockArgs b;
+                fill_block_args(h, op, c, b);
+                f.kind = 0; f.N = r.N; f.sclin = r.sclin ? 1 : 0;
+                fill_block_args_h(h, r, b, f.b);
+                // the cooperative body's shapes: inputs exactly N wide, images within the LDS slot (launch_res_h, coop_fits)
+                const int ks1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2;
+                if (!((r.N == 64 || r.N == 128) && r.in0 == r.N && (r.in1 == 0 || r.in1 == r.N) && ks1 <= (r.sclin ? r.N / 8 : r.N / 16) && b.cond_pre)) ok = false;
+                ++wide;
+            } else {
+                const LinOpP& l = h->lin[op.p];
+                LinArgs la;
+                fill_lin_args(h, op, c, la);
+                f.kind = op.kind == OP_FINAL ? 3 : 1; f.N = l.l.N;
+                fill_lin_args_h(h, l, la, f.l);
+                if (op.kind == OP_PROJ) f.kind = 1;            // never executed by the kernel (its range starts behind feature_proj)
+                else if (l.l.N > 128 || (op.kind == OP_FINAL) != l.lnact) ok = false;
+            }
+        }
+        h->tile_valid = ok && wide > 0;
+        if (h->tile_valid)
+            HIPCK(hipMemcpyAsync(h->tileops_dev, h->tileops_host.data(), (size_t)nops * sizeof(FusedOpH), hipMemcpyHostToDevice, s));
+    }
     // the training forward has its own table and leaves the inference plan (and fused_sig) alone: resetting the LDS plan here
     // would drop the eager sampling path to the non-LDS kernels for good while cached graphs keep replaying the LDS form
     if (!c.train) { h->nlds_valid = false; h->nlds_tail = false; }
@@ -1150,7 +1193,25 @@ bool try_dual64(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
     return true;
 }
 
+// Small launches: feature_proj, then ONE launch that carries every row tile through the rest of the net (dsg_tile.hpp)
+bool tile_step_ok(const dsg_handle* h, const RunCtx& c) {
+    return h->opt_tile && h->tile_valid && split_ctx(h, c) && !c.train && h->fuse_hi - h->fuse_lo >= 2 &&
+           cdiv(c.nrows, 32) * c.npass <= h->coop_max_tiles;
+}
+void launch_tile_step(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
+    launch_op(h, h->ops[0], c, s);            // feature_proj: moves the device step counter on (reverse loop), one pass when shared
+    const int ntiles = cdiv(c.nrows, 32) * c.npass, nops = (int)h->ops.size();
+    const bool v8 = h->opt_v8 && h->v8_lo >= 0 && h->v8_ncopies > 0 && c.cond_pre;
+    const int v8nb = v8 ? h->d.n_blocks : 0, v8_at = v8 ? h->v8_lo - h->fuse_lo : -1, v8_n = v8 ? h->v8_hi - h->v8_lo : 0;
+    const dim3 grid(ntiles), block(256);
+#define DSG_TILE(NB_) hipLaunchKernelGGL((k_unet_tile<NB_>), grid, block, 0, s, (const FusedOpH*)h->tileops_dev, 1, nops, ntiles, h->fuse_lo, h->fuse_hi, \
+                                         v8_at, v8_n, (const float*)h->v8_image)
+    if (v8nb == 2) DSG_TILE(2); else if (v8nb == 3) DSG_TILE(3); else DSG_TILE(0);
+#undef DSG_TILE
+}
+
 void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
+    if (tile_step_ok(h, c)) { launch_tile_step(h, c, s); return; }
     const bool fuse = (!c.train || split_ctx(h, c)) && h->fuse_hi - h->fuse_lo >= 2;
     for (int i = 0; i < (int)h->ops.size(); ++i) {
         if (fuse && i == h->fuse_lo) {
@@ -1651,6 +1712,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
     dsg_handle* h = new dsg_handle();
     h->d = d;
     h->td = 4 * d.proj_dim;
+    (void)hipGetDevice(&h->device);
     // ---- parameter table + plan, in the registration order of UNet1D.__init__ (UNetCF.py:272-316)
     LinOpP proj;
     proj.l = add_linear(h, "feature_proj", d.input_dim, d.proj_dim);
@@ -1753,6 +1815,7 @@ dsg_handle* dsg_create(const dsg_unet_desc* desc) {
     }
     bool ok = hipMalloc(&h->ce_dev, (h->res.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
               hipMalloc(&h->fusedh_dev, (h->ops.size() + 1) * sizeof(FusedOpH)) == hipSuccess &&
+              hipMalloc(&h->tileops_dev, (h->ops.size() + 1) * sizeof(FusedOpH)) == hipSuccess &&
               hipMalloc(&h->maxabs, (h->params.size() + 1) * sizeof(float)) == hipSuccess &&
               hipMalloc(&h->fused_dev, (h->ops.size() + 1) * sizeof(FusedOp)) == hipSuccess &&
               hipMalloc(&h->arena, h->arena_floats * sizeof(float)) == hipSuccess &&
@@ -1800,7 +1863,7 @@ void dsg_destroy(dsg_handle* h) {
     (void)hipDeviceSynchronize();
     free_workspace(h);
     void* ptrs[] = {h->arena, h->tdesc_dev, h->pack_dev, h->freq, h->red, h->step_dev, h->call_dev, h->fused_dev, h->maxabs,
-                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->opc_desc_dev, h->opc_dev, h->fusedh_dev, h->fusedh_train_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->r2_dev, h->ce_dev, h->ctile_dev};
+                    (void*)h->mx_ptrs_dev, h->mx_numel_dev, h->mx_idx_dev, h->packh_dev, h->opc_desc_dev, h->opc_dev, h->fusedh_dev, h->tileops_dev, h->fusedh_train_dev, h->tw_dst_dev, (void*)h->tw_src_dev, h->r2_dev, h->ce_dev, h->ctile_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -2015,8 +2078,21 @@ int dsg_bind_weights(dsg_handle* h, const float* const* ptrs, int n, void* strea
     return 0;
 }
 
+// The settings / status entry points synchronise and free graphs on the HANDLE's device, whatever device is current in the calling
+// thread (a model on cuda:1 queried while cuda:0 was current synchronised the wrong device and could read the range
+// flag before the sampling kernels had finished).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const dsg_handle* h) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != h->device) (void)hipSetDevice(h->device); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 int dsg_set_precision(dsg_handle* h, int mode) {
     if (!h) return fail("null handle");
+    DeviceGuard dg(h);
     if (mode != DSG_PRECISION_SPLIT_F16 && mode != DSG_PRECISION_F32_MFMA) return fail("unknown precision mode %d", mode);
     const bool split = mode == DSG_PRECISION_SPLIT_F16;
     if (split != h->use_split) { (void)hipDeviceSynchronize(); free_graphs(h); h->use_split = split; }
@@ -2034,6 +2110,7 @@ int dsg_set_renorm_hook(dsg_handle* h, double* stats3, void (*reduce)(void*), vo
 
 int dsg_set_option(dsg_handle* h, int option, int value) {
     if (!h) return fail("null handle");
+    DeviceGuard dg(h);
     switch (option) {
         case DSG_OPT_NARROW_VALU8:
             if ((value != 0) != h->opt_v8) {
@@ -2044,6 +2121,9 @@ int dsg_set_option(dsg_handle* h, int option, int value) {
             }
             return 0;
         case DSG_OPT_TRAIN_TIME_BESIDE: h->opt_time_beside = value != 0; return 0;
+        case DSG_OPT_TILE_STEP:
+            if ((value != 0) != h->opt_tile) { (void)hipDeviceSynchronize(); free_graphs(h); h->opt_tile = value != 0; }
+            return 0;
         case DSG_OPT_WGRAD_NARROW_PART:
             if ((value != 0) != h->opt_wg_narrow_part) { (void)hipDeviceSynchronize(); h->opt_wg_narrow_part = value != 0; h->td_valid = false; }
             return 0;
@@ -2053,6 +2133,7 @@ int dsg_set_option(dsg_handle* h, int option, int value) {
 
 int dsg_range_status(dsg_handle* h, int* exceeded) {
     if (!h || !exceeded) return fail("dsg_range_status: null argument");
+    DeviceGuard dg(h);
     HIPCK(hipDeviceSynchronize());
     HIPCK(hipMemcpy(exceeded, h->range_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (*exceeded) HIPCK(hipMemset(h->range_flag, 0, sizeof(int)));
@@ -2061,6 +2142,7 @@ int dsg_range_status(dsg_handle* h, int* exceeded) {
 
 int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_max_tiles) {
     if (!h) return fail("null handle");
+    DeviceGuard dg(h);
     const int c = coop_max_tiles < 0 ? kCoopMaxTilesDefault : coop_max_tiles;
     const int n = narrow_small_max_tiles < 0 ? kNarrowSmallMaxTilesDefault : narrow_small_max_tiles;
     if (c != h->coop_max_tiles || n != h->narrow_small_max_tiles) {
@@ -2760,6 +2842,61 @@ int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* st
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms_avg = ms / iters;
+    return 0;
+}
+
+// ---- box calibration (bench.py `box`): the pool's MI355X boxes differ by up to 15 % on the same binary (clock under load), so a
+// headline alone cannot tell a slow box from a slow tree.  Three fixed probes, timed with HIP events on `stream`, median of 5 launches
+// of ~5 ms each (a 1-ms probe read 1 816 and 1 564 TFLOP/s on one box a second apart: the clock had not settled):
+//   out[0] mfma_tflops  every SIMD issues dependent v_mfma_f32_32x32x16_f16 back to back on non-trivial operands (two waves per SIMD):
+//                       the bare matrix pipe at the clock the box holds under it;
+//   out[1] mix_gslots   the same loop with six vector instructions (one of them transcendental) behind every MFMA -- the instruction mix
+//                       of the block kernels -- in 1e9 (MFMA + 6 vector) slots per second over the chip;
+//   out[2] copy_gbs     a 256 MiB float4 copy inside a buffer allocated for the call (read + written bytes per second).
+int dsg_box_calibrate(float* out3, void* stream) {
+    if (!out3) return fail("dsg_box_calibrate: null output");
+    hipStream_t s = (hipStream_t)stream;
+    hipDeviceProp_t prop;
+    int devid = 0;
+    HIPCK(hipGetDevice(&devid));
+    HIPCK(hipGetDeviceProperties(&prop, devid));
+    const int cus = prop.multiProcessorCount;
+    hipEvent_t e0, e1;
+    HIPCK(hipEventCreate(&e0));
+    HIPCK(hipEventCreate(&e1));
+    float* sink = nullptr;
+    const size_t copy_bytes = (size_t)256 << 20;
+    char* buf = nullptr;
+    HIPCK(hipMalloc(&sink, (size_t)cus * 2 * 256 * sizeof(float)));
+    HIPCK(hipMalloc(&buf, 2 * copy_bytes));
+    HIPCK(hipMemsetAsync(buf, 1, 2 * copy_bytes, s));
+    auto median5 = [&](auto&& launch, float& ms_out) -> int {
+        float t[6];
+        for (int rep = 0; rep < 6; ++rep) {      // the first launch is a warm-up
+            HIPCK(hipEventRecord(e0, s));
+            launch();
+            HIPCK(hipEventRecord(e1, s));
+            HIPCK(hipEventSynchronize(e1));
+            HIPCK(hipEventElapsedTime(&t[rep], e0, e1));
+        }
+        std::sort(t + 1, t + 6);
+        ms_out = t[3];
+        return 0;
+    };
+    // two workgroups of four waves per CU = two waves per SIMD, as the block kernels run
+    const int it0 = 3072, it6 = 1536;             // x 48 MFMAs: ~5 ms each at two waves per SIMD
+    float ms0 = 0.f, ms6 = 0.f, msc = 0.f;
+    if (median5([&] { hipLaunchKernelGGL(dsg::k_calib_mfma<0>, dim3(2 * cus), dim3(256), 0, s, it0, sink); }, ms0)) return 1;
+    if (median5([&] { hipLaunchKernelGGL(dsg::k_calib_mfma<6>, dim3(2 * cus), dim3(256), 0, s, it6, sink); }, ms6)) return 1;
+    if (median5([&] { hipLaunchKernelGGL(dsg::k_calib_copy, dim3(cus * 8), dim3(256), 0, s, reinterpret_cast<const uint4*>(buf),
+                                         reinterpret_cast<uint4*>(buf + copy_bytes), copy_bytes / 16); }, msc)) return 1;
+    out3[0] = (float)((double)cus * 8 * it0 * 48 * 32768.0 / (ms0 * 1e-3) / 1e12);
+    out3[1] = (float)((double)cus * 8 * it6 * 48 / (ms6 * 1e-3) / 1e9);
+    out3[2] = (float)(2.0 * copy_bytes / (msc * 1e-3) / 1e9);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    (void)hipFree(buf);
     return 0;
 }
 

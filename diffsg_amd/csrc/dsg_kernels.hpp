@@ -458,7 +458,8 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
 }
 
 template <int N, bool SCLIN>
-__global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {
+__global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {   // (bounded to 2 waves per SIMD hipcc keeps the accumulators in
+                                                                         // plain registers: measured 7 % slower at N = 128, round 5)
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.ntiles) return;
@@ -523,14 +524,27 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, const int tile, co
         chain_from_mem<NT, LNACT>(acc, a.in.data + (size_t)tile * KG * 256 + lane * 4, KG, a.W + lane * 4, nt_stride,
                                   LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
     } else {
+        // rows of a multiple of 4 floats (MSR-80c: 80): one 16-byte load per lane and group instead of four 4-byte ones (a wave's
+        // load touches 32 rows = 32 cache lines either way; round 5: feature_proj 53 us at 65 536 rows on the exact path)
+        const bool vec4 = (a.in_width & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in_rm) & 15) == 0;
+        const bool rowok = row < a.nrows;
+        const float* rp = a.in_rm + (size_t)(rowok ? row : 0) * a.in_width;
+        float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec4 && rowok && 4 * h < a.in_width) xn = ld4(rp + 4 * h);
         for (int g = 0; g < KG; ++g) {
             float4 wc[NT];
             load_wfrag<NT>(wc, a.W + (size_t)g * 256 + lane * 4, nt_stride);
             float v[4];
+            if (vec4) {
+                v[0] = xn.x; v[1] = xn.y; v[2] = xn.z; v[3] = xn.w;
+                xn = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowok && 8 * (g + 1) + 4 * h < a.in_width && g + 1 < KG) xn = ld4(rp + 8 * (g + 1) + 4 * h);
+            } else {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int f = 8 * g + 4 * h + p;
-                v[p] = (row < a.nrows && f < a.in_width) ? a.in_rm[(size_t)row * a.in_width + f] : 0.f;
+                for (int p = 0; p < 4; ++p) {
+                    const int f = 8 * g + 4 * h + p;
+                    v[p] = (rowok && f < a.in_width) ? rp[f] : 0.f;
+                }
             }
             mfma_group<NT>(acc, wc, v[0], v[1], v[2], v[3]);
         }
@@ -566,19 +580,30 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, const int tile, co
     } else {
         if (row < a.nrows) {
             float* o = a.out_rm + ((size_t)pass * a.nrows + row) * a.out_width;
+            if ((a.out_width & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out_rm) & 15) == 0) {       // 16-byte stores (as the split path's epilogue): a quarter of the store instructions
 #pragma unroll
-            for (int G = 0; G < NT * 4; ++G)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int f = 8 * G + 4 * h + p;
-                    if (f < a.out_width) o[f] = acc[G >> 2][4 * (G & 3) + p];
+                for (int G = 0; G < NT * 4; ++G) {
+                    const int f = 8 * G + 4 * h;
+                    if (f < a.out_width)
+                        st4(o + f, make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
                 }
+            } else {
+#pragma unroll
+                for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int f = 8 * G + 4 * h + p;
+                        if (f < a.out_width) o[f] = acc[G >> 2][4 * (G & 3) + p];
+                    }
+            }
         }
     }
 }
 
+// (Without a waves-per-SIMD bound hipcc gave these kernels 174-302 registers -- up to 128 of them accumulator registers for 64
+// accumulator values -- and one or two waves per SIMD: a handful of MFMAs per memory round trip then runs at 1 TB/s.  Round 5.)
 template <int NT, int INMODE, int OUTMODE, bool LNACT>
-__global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
+__global__ __launch_bounds__(256, NT >= 4 ? 3 : 4) void k_linear(const LinArgs a) {
     if (INMODE == IN_ROWMAJOR && a.advance_step && blockIdx.x == 0 && threadIdx.x == 0) *a.advance_step -= 1;
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
@@ -1125,6 +1150,50 @@ __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
         adam_one(p, a.g[i], m, v, a, bias_correction1, bias_correction2_sqrt);
         a.p[i] = p; a.m[i] = m; a.v[i] = v;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Box calibration probes (dsg_box_calibrate, bench.py `box`): a dependent-MFMA loop on every SIMD and a float4 copy.
+// ---------------------------------------------------------------------------------------------
+// NV = vector instructions (every sixth a transcendental) behind each MFMA: 0 = the bare matrix pipe, 6 = the instruction mix of this
+// library's block kernels (6.5 vector instructions per MFMA), whose clock under load is not the bare pipe's.
+template <int NV>
+__global__ __launch_bounds__(256) void k_calib_mfma(int iters, float* __restrict__ sink) {
+    typedef _Float16 h8c __attribute__((ext_vector_type(8)));
+    h8c a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {             // non-trivial operands: the clock a box holds depends on the data (all-zero operands run faster)
+        a[i] = (_Float16)(0.37f + 0.013f * (float)((threadIdx.x * 7 + i * 3) & 63));
+        b[i] = (_Float16)(-0.81f + 0.021f * (float)((threadIdx.x * 5 + i) & 31));
+    }
+    f32x16 c[4] = {{0}, {0}, {0}, {0}};
+    float v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = 1.0f + 0.001f * (float)(threadIdx.x + i);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 48; ++r) {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[r & 3]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int q = (r * NV + i) % 12;
+                if (i == 5) asm volatile("v_exp_f32 %0, %0" : "+v"(v[q]));
+                else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[q]) : "v"(0.999f), "v"(0.001f));
+            }
+        }
+        // keep the sums finite over thousands of iterations without leaving the matrix pipe idle for long
+        if ((it & 63) == 63) { c[0] *= 1e-6f; c[1] *= 1e-6f; c[2] *= 1e-6f; c[3] *= 1e-6f; }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMA's results are read below
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc += c[0][i] + c[1][i] + c[2][i] + c[3][i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) sacc += v[i];
+    sink[blockIdx.x * 256 + threadIdx.x] = sacc;
+}
+__global__ __launch_bounds__(256) void k_calib_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 }  // namespace dsg

@@ -328,7 +328,7 @@ __device__ __forceinline__ void panel_pipe_s(f32x16 (&acc)[4], const uint4* pn /
             } else { v0 = u0; v1 = u1; }
         } else {
             unsigned a, er;
-            split_pair(v0, v1, a, er);
+            split_pair_nowait(v0, v1, a, er);     // the next statement is an MFMA that only pins these registers; first read a step later
             hq[m] = __builtin_bit_cast(float, a); lq[m] = __builtin_bit_cast(float, er);
         }
     }

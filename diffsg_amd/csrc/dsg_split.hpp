@@ -79,6 +79,17 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
         : "=&v"(l) : "v"(v0), "v"(v1), "v"(hi));
     lo = l;
 }
+// The same split WITHOUT the closing wait state, for call sites whose next instruction is known not to read `lo`: the pieces of
+// panel_pipe_s sit between two MFMA statements and their results are first read a k16-step later (round 5: the wait state is an issue
+// slot like any other -- 192 per tile of a 128-wide up block -- in a kernel that the round's microbenchmark shows to be issue-bound).
+__device__ __forceinline__ void split_pair_nowait(float v0, float v1, unsigned& hi, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(l) : "v"(v0), "v"(v1), "v"(hi));
+    lo = l;
+}
 // 8 float32 values (already multiplied by the activation scale) -> hi / lo half vectors; hi + lo carries 22 bits
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
     unsigned hh[4], ll[4];
@@ -637,17 +648,19 @@ __device__ __forceinline__ void coop_merge_stats(const float2* __restrict__ st /
     m2 = q;
 }
 
+// workgroup barriers inside resblock_coop_body: a wave that sits a block out (k_unet_tile: the upper waves of a 64-wide block) meets
+// exactly these and nothing else
+constexpr int kCoopBarriers = 7;
+
+// The body: `tile_raw` = the tile of this wave's slot (>= ntiles: an idle slot that only meets the barriers and stores nothing),
+// `slot` / `w` = the wave's tile slot and 32-feature slice, `img` / `stats` = the workgroup's LDS (kCoopLdsU4 uint4, 4 x 32 float2).
 template <int N, bool SCLIN>
-__global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
+__device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const int tile_raw, const int slot, const int w, uint4* __restrict__ img,
+                                                   float2* __restrict__ stats) {
     constexpr int NG = N / 8, NT = N / 32, TPW = 4 / NT, KS = NG / 2;
     constexpr int kSlotU4 = kCoopLdsU4 / TPW;
-    __shared__ uint4 img[kCoopLdsU4];
-    __shared__ float2 stats[4 * 32];
     const BlockArgs& a = ah.b;
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = wave / NT, w = wave % NT;
-    const int tile_raw = blockIdx.x * TPW + slot;
     const bool live = tile_raw < a.ntiles;            // idle slots of the last workgroup still meet the barriers
     const int tile = live ? tile_raw : a.ntiles - 1;
     const int ptile = tile % a.tiles_per_pass;
@@ -862,6 +875,16 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
             st4(a.out + ((size_t)tile * NG + 4 * w + q) * 256 + lane * 4,
                 make_float4(acc3[0][4 * q], acc3[0][4 * q + 1], acc3[0][4 * q + 2], acc3[0][4 * q + 3]));
     }
+}
+
+template <int N, bool SCLIN>
+__global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
+    constexpr int NT = N / 32, TPW = 4 / NT;
+    __shared__ uint4 img[kCoopLdsU4];
+    __shared__ float2 stats[4 * 32];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = wave / NT, w = wave % NT;
+    resblock_coop_body<N, SCLIN>(ah, blockIdx.x * TPW + slot, slot, w, img, stats);
 }
 
 // A wide block followed by the Linear that consumes it (Down/Upsample: raw; final: LayerNorm + SiLU, row-major out),
@@ -1183,12 +1206,10 @@ struct V8TableSave {
 
 // V8NB > 0: operators [v8_at, v8_at + v8_nops) of the run are the 8-wide bottom of the net (n_blocks = V8NB) and run on the vector unit in
 // float32 from the global image `v8_img` (dsg_narrow8.hpp); v8_store: the training forward (every tensor of the section is stored).
+// The run for ONE wave and its tile (k_fused_narrow_h below; k_unet_tile runs it on the first wave of a tile's workgroup).
 template <bool PRE, int V8NB>
-__global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles, int v8_at, int v8_nops,
-                                                                     const float* __restrict__ v8_img, int v8_store) {
-    const int lane = threadIdx.x & 63;
-    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (tile >= ntiles) return;
+__device__ __forceinline__ void narrow_run_body(const FusedOpH* __restrict__ ops, const int nops, const int tile, const int lane, const int v8_at,
+                                                const int v8_nops, const float* __restrict__ v8_img, const int v8_store) {
     f32x16 x[1];
     float xmean = 0.f, xm2 = 0.f;
     bool have_x = false;
@@ -1318,6 +1339,15 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
         }
     }
     }
+}
+
+template <bool PRE, int V8NB>
+__global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const FusedOpH* __restrict__ ops, int nops, int ntiles, int v8_at, int v8_nops,
+                                                                     const float* __restrict__ v8_img, int v8_store) {
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (tile >= ntiles) return;
+    narrow_run_body<PRE, V8NB>(ops, nops, tile, lane, v8_at, v8_nops, v8_img, v8_store);
 }
 
 // ---------------------------------------------------------------------------------------------

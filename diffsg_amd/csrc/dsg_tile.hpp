@@ -1,0 +1,80 @@
+// One launch per denoiser pass for SMALL batches: a 4-wave workgroup carries ONE 32-row tile through every operator of the U-Net.
+//
+// Why (round 5, profiles/r05_small_batch_kernel_stats_*.csv): BASELINE config 2 (MSR-3c, 8 192 rows, T = 1000) and the reference's own
+// evaluation shape (512-row sample() calls, classifier_free_MSR.py:257, 273-279) are far below one wave per SIMD.  A reverse step
+// there is 17 dependent launches, 250 us of kernel time with 8 us of gaps: the time is INSIDE the kernels, each of which is one tile's
+// latency through one operator -- and begins with a dispatch, its kernel arguments and a cold round trip for statistics, inputs and
+// weights (~2-3 us, seventeen times a step).  Rows are independent (UNetCF.py:318-356 has no cross-row operation), so nothing forces a
+// launch boundary between operators: here the operator table of the whole net is walked inside the kernel.
+//   * 64- and 128-wide blocks run the cooperative N-split body of k_resblock_c (resblock_coop_body: each wave a 32-feature slice of
+//     every stage, operand images published once in LDS); a 64-wide block occupies two of the four waves, the others meet its barriers;
+//   * the run of <= 32-wide operators is narrow_run_body (k_fused_narrow_h's) on the first wave, running tensor in registers, the 8-wide
+//     bottom in float32 on the vector unit;
+//   * the Linears outside the run (Down/Upsample at 64 / 128, final) are linear_body_h on the first wave: a handful of MFMAs each, not
+//     worth a launch (they were 6-8 us apiece).
+// Tensors cross operators through their fragment buffers exactly as between launches (written and re-read by the same workgroup: one
+// CU, one L1; a workgroup barrier orders them), so every other kernel form reads and writes the same buffers and the per-operator
+// arithmetic is bit for bit that of the separate launches.  feature_proj stays a launch of its own in front: it moves the device step
+// counter on, which no workgroup of THIS kernel may do while another still reads it.
+#pragma once
+#include "dsg_split.hpp"
+
+namespace dsg {
+
+// kind of a table entry (FusedOpH::kind): 0 residual block, 1 Linear fragment -> fragment, 3 final (LayerNorm + SiLU + Linear, row-major out)
+template <int NT>
+__device__ __forceinline__ void tile_linear(const FusedOpH& op, const int tile, const int lane) {
+    LinArgsH l = op.l;
+    globalize<false>(l);
+    if (op.kind == 3) linear_body_h<NT, IN_FRAG, OUT_ROWMAJOR, true>(l, tile, lane);
+    else linear_body_h<NT, IN_FRAG, OUT_FRAG, false>(l, tile, lane);
+}
+
+template <int V8NB>
+__global__ __launch_bounds__(256, 2) void k_unet_tile(const FusedOpH* __restrict__ ops, const int op_lo, const int nops, const int ntiles, const int run_lo,
+                                                   const int run_hi, const int v8_at, const int v8_nops, const float* __restrict__ v8_img) {
+    __shared__ uint4 img[kCoopLdsU4];
+    __shared__ float2 stats[4 * 32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x;              // grid = ntiles
+#pragma unroll 1
+    for (int i = op_lo; i < nops;) {
+        if (i == run_lo && run_hi > run_lo) {
+            if (wave == 0) narrow_run_body<true, V8NB>(ops + run_lo, run_hi - run_lo, tile, lane, v8_at, v8_nops, v8_img, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                  // the run's stored tensors (skips, its last output) are visible to the whole workgroup
+            i = run_hi;
+            continue;
+        }
+        const FusedOpH& op = ops[i];
+        if (op.kind == 0) {
+            // a wide block: all four waves (128) or the first two (64); its last barrier sits in front of the stores, the one below
+            // behind them.  The record's pointers are declared global (as_global: the table is read from memory).
+            BlockArgsH b = op.b;
+            globalize<false>(b);
+            if (op.N == 128) {
+                if (op.sclin) resblock_coop_body<128, true>(b, tile, 0, wave, img, stats);
+                else resblock_coop_body<128, false>(b, tile, 0, wave, img, stats);
+            } else if (wave < 2) {
+                if (op.sclin) resblock_coop_body<64, true>(b, tile, 0, wave, img, stats);
+                else resblock_coop_body<64, false>(b, tile, 0, wave, img, stats);
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < kCoopBarriers; ++nb) __syncthreads();
+            }
+        } else if (wave == 0) {
+            switch ((op.N + 31) >> 5) {
+                case 1: tile_linear<1>(op, tile, lane); break;
+                case 2: tile_linear<2>(op, tile, lane); break;
+                case 3: tile_linear<3>(op, tile, lane); break;
+                default: tile_linear<4>(op, tile, lane); break;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                      // stores of this operator -> loads of the next (same workgroup: one CU, one L1)
+        ++i;
+    }
+}
+
+}  // namespace dsg

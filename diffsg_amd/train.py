@@ -170,6 +170,13 @@ def run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, w
                     and ema_step_cnt % diffusion_model.ema_update_rate == 0):
                 diffusion_model.ema.update_parameters(diffusion_model.model)
             epoch_loss += loss.item()
+            # loss.item() has just synchronised: reading the fp16 range flag of the split-f16 path costs nothing more.  A step whose
+            # raw operands left fp16's range saturated silently where the reference would print inf / NaN: the
+            # update it made is wrong, so stop here and say what to do.
+            if hasattr(diffusion_model.model, "range_exceeded") and diffusion_model.model.range_exceeded():
+                raise FloatingPointError(
+                    f"epoch {epoch}: an activation of the training step left the fp16 range of the split-f16 path (|x| > 6e4); the "
+                    "gradients of this step are invalid.  Scale the targets, or train with model.set_precision('f32')")
             epoch_rows += x.shape[0]
             ema_step_cnt += 1
         # the reference prints (sum of batch-mean losses) / (row count), MSR.py:233 -- reproduced as is

@@ -91,8 +91,12 @@ int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_ma
  *                          (TimeEmbedding and the per-block time_emb Linear, UNetCF.py:35-44) runs on the side stream beside the last
  *                          weight-gradient launch; 0: behind it on the caller's stream.  Same gradients bit for bit either way.
  *   DSG_OPT_WGRAD_NARROW_PART  0 (default) / 1: the weight gradients of the fused narrow run's blocks as one more early part on the side
- *                          stream, behind the narrow run's backward launch (measured slower at 32 768 rows: profiles/r04_train_tail_ab.txt). */
-enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2, DSG_OPT_WGRAD_NARROW_PART = 4 };
+ *                          stream, behind the narrow run's backward launch (measured slower at 32 768 rows: profiles/r04_train_tail_ab.txt).
+ *   DSG_OPT_TILE_STEP      1 (default): launches of at most `coop_max_tiles` row tiles (dsg_set_launch_policy) run one denoiser pass as
+ *                          feature_proj + ONE launch that carries every row tile through all the other operators (csrc/dsg_tile.hpp;
+ *                          UNetCF.py:318-356 has no cross-row operation); 0: one launch per operator / fused run, as larger launches.
+ *                          Same arithmetic per operator, bit-identical results.  Cached step graphs are dropped when the value changes. */
+enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2, DSG_OPT_WGRAD_NARROW_PART = 4, DSG_OPT_TILE_STEP = 8 };
 int dsg_set_option(dsg_handle* h, int option, int value);
 
 /* Pre-size the workspace for up to `max_rows` batch rows and `max_entries` time-table rows. */
@@ -220,6 +224,12 @@ int dsg_op_info(const dsg_handle* h, int op, char* name, double* flops_per_row, 
 int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* stream);
 /* Summed HIP-event time (ms) and launch count of operator `op` over the last DSG_SAMPLE_PROFILE call. */
 int dsg_op_profile(const dsg_handle* h, int op, double* ms_total, int* calls);
+
+/* Box calibration for bench.py (`box`): three fixed probes on the current device, median of five ~5-ms launches each, timed with
+ * HIP events on `stream` (synchronises): out3[0] = rate of a dependent v_mfma_f32_32x32x16_f16 loop on every SIMD (TFLOP/s, dense f16),
+ * out3[1] = the same loop with six vector instructions behind every MFMA (1e9 slots/s), out3[2] = a 256 MiB device copy (GB/s, read +
+ * written).  Not part of the reference's seam (the reference has no benchmark): it lets a reader separate a slow box from a slow tree. */
+int dsg_box_calibrate(float* out3, void* stream);
 
 #ifdef __cplusplus
 }

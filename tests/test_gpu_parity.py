@@ -804,10 +804,16 @@ def test_train_step_many_timesteps_vs_oracle(name, B, T):
     assert_grads({k: q.grad for k, q in ddpm.model.named_parameters()}, ref, ref64, f"{name}/{B}/T={T}")
 
 
-def test_train_step_large_launch_vs_oracle():
-    """BASELINE training shape (32 768 rows per GPU, + a ragged tail = 1 025 row tiles: the one-wave-per-tile forward,
-    k_resblock_bwd_h, the grouped k_wgrad_h) DIRECTLY against the CPU oracle's autograd: loss and every gradient."""
-    name, B, T = "msr80", 32768 + 17, 20
+@pytest.mark.parametrize("B", [32768 + 17, 32768, 65536])
+def test_train_step_large_launch_vs_oracle(B):
+    """BASELINE training shapes DIRECTLY against the CPU oracle's autograd, loss and every gradient:
+    32 785 rows (a ragged tail = 1 025 row tiles: the one-wave-per-tile forward, the grouped k_wgrad_h);
+    32 768 rows = exactly 1 024 tiles, bench.py's training shape -- the one size where the cooperative forward (<= 1 024 tiles) and
+    the side-stream weight-gradient parts (>= 1 024 tiles) coexist (it was only compared with the library's own
+    exact path);
+    65 536 rows = DDPM.train_split_min_rows: the step runs as two 32 768-row halves on two handles and four streams (that
+    shipped configuration was only checked at 213 rows with the threshold lowered)."""
+    name, T = "msr80", 20
     plan, p = synth_params(name, 13)
     ddpm = make_ddpm(name, p, T)
     cfg = CONFIGS[name]
@@ -823,7 +829,9 @@ def test_train_step_large_launch_vs_oracle():
     ref_loss, ref = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask)
     assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
     _, ref64 = O.ddpm_loss_and_grads(p, plan, bufs, T, y, cond, ts, noise, mask, f64=True)
-    assert_grads({k: q.grad for k, q in ddpm.model.named_parameters()}, ref, ref64, "train 32785 rows")
+    assert_grads({k: q.grad for k, q in ddpm.model.named_parameters()}, ref, ref64, f"train {B} rows")
+    assert ddpm._splits(B) == (B >= 65536)
+    assert not ddpm.model.range_exceeded()
 
 
 def test_training_reduces_loss_and_matches_cpu_adam():
@@ -1457,3 +1465,31 @@ def test_co_minlp_gen_vs_oracle(n, samples):
         return
     Xo, Yo, _ = C.conv_co_minlp_gen(n, samples)
     assert np.array_equal(X, Xo) and np.array_equal(Y, Yo)
+
+
+@pytest.mark.parametrize("name,B,T", [("msr3", 1000, 6), ("msr80", 513, 5), ("co3", 300, 6), ("msr80", 33, 20)])
+def test_tile_step_kernel_is_the_per_operator_launches_bit_for_bit(name, B, T):
+    """k_unet_tile (csrc/dsg_tile.hpp: feature_proj + ONE launch that walks every operator per row tile, the default for launches of at
+    most coop_max_tiles tiles) against the same call with `tile_step` off (one launch per operator / fused run): the operators' bodies,
+    buffers and arithmetic are the same, so every output bit is -- sampling (graph and eager, ragged batch: a partial last tile) and
+    UNet1D.forward with per-row t.  The goldens themselves run through the tile kernel (default policy) and through the large-launch
+    forms (policy "large") in the tests above."""
+    plan, p = synth_params(name, 17)
+    cfg = CONFIGS[name]
+    d = make_ddpm(name, p, T)
+    g = torch.Generator().manual_seed(5)
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+    a = d.sample(cond, 1.5, seed=11)
+    a_eager = d.sample(cond, 1.5, seed=11, use_graph=False)
+    x = torch.randn(B, cfg["input_dim"], generator=g).cuda()
+    t = (torch.randint(0, T, (1, B), generator=g).float() / T).cuda()
+    mask = (torch.rand(B, 1, generator=g) < 0.8).float().cuda()
+    fa = d.model(x, t, cond, mask)
+    d.model.set_option("tile_step", 0)
+    b = d.sample(cond, 1.5, seed=11)
+    fb = d.model(x, t, cond, mask)
+    d.model.set_option("tile_step", 1)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a_eager, b)
+    assert torch.equal(fa, fb)
+    assert torch.equal(d.sample(cond, 1.5, seed=11), a)        # and back on

@@ -13,6 +13,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = torch.device("cuda:0")
 ddpm = bench.build_model(dev, 6)
+if os.environ.get("PRECISION"):      # e.g. PRECISION=f32: the exact-float32 kernels
+    ddpm.model.set_precision(os.environ["PRECISION"])
 cond = torch.rand(B, 80, device=dev)
 ddpm.sample(cond, 1.0, seed=1)          # fills the workspace with real activations
 L, hd = _lib.lib(), ddpm.model.native_handle()

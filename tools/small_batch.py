@@ -18,6 +18,8 @@ D = cfg["input_dim"]
 d = DDPM(T, m, D, 10.0, 1.0 - generate_cosine_schedule(T), dev, (1, D), None)
 d.apply(init_weights); d.to(dev)
 cond = torch.rand(B, cfg["cond_dim"], device=dev)
+if os.environ.get("TILE") is not None:      # 0: one launch per operator (tile_step off); 1: k_unet_tile (default)
+    d.model.set_option("tile_step", int(os.environ["TILE"]))
 for _ in range(3):
     d.sample(cond, 500.0, seed=1)
 torch.cuda.synchronize()
@@ -25,4 +27,4 @@ t0 = time.perf_counter()
 for _ in range(10):
     d.sample(cond, 500.0, seed=2)
 torch.cuda.synchronize()
-print(f"{name} B={B} T={T}: {(time.perf_counter()-t0)/10*1e3:.3f} ms per sample() call")
+print(f"{name} B={B} T={T} tile_step={os.environ.get('TILE', 'default')}: {(time.perf_counter()-t0)/10*1e3:.3f} ms per sample() call")

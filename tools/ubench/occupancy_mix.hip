@@ -35,11 +35,12 @@ __global__ __launch_bounds__(1024) void k_mix(int iters, float* out, long long* 
         for (int s = 0; s < 12; ++s) {
             if (MODE == 0 || MODE == 3) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[s & 1]) : "v"(a), "v"(b));
             else if (MODE == 2 || MODE == 4) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c[s & 1]) : "v"(a), "v"(b));
+            else if (MODE == 5) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c[s & 1]) : "v"(v[11]), "v"(v[10]));
             else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d[s & 3]) : "v"(a), "v"(b));
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int r = (s * NV + i) % 12;
-                if (i % 6 == 5 && MODE < 3) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
+                const int r = (s * NV + i) % 10;
+                if (i % 6 == 5 && (MODE < 3 || MODE == 5)) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
                 else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(0.999f), "v"(0.001f));
             }
 #pragma unroll
@@ -107,7 +108,7 @@ template <int MODE, int NV, int NL>
 void run_mix() {
     const int blocks = 256, iters = 200;
     (void)hipFuncSetAttribute((const void*)k_mix<MODE, NV, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    const char* mn[] = {"32x32x16", "16x16x32", "32x32x16 acc in AGPRs", "32x32x16 fma only", "32x32x16 AGPR acc, fma only"};
+    const char* mn[] = {"32x32x16", "16x16x32", "32x32x16 acc in AGPRs", "32x32x16 fma only", "32x32x16 AGPR acc, fma only", "32x32x2 f32 (AGPR acc)"};
     printf("%s  %d vector + %d ds_read_b128 per MFMA slot:", mn[MODE], NV, NL);
     for (int W = 1; W <= 4; ++W) {
         (void)hipMemset(g_cyc, 0, blocks * 32 * sizeof(long long));
@@ -151,6 +152,7 @@ void run_roles() {
 
 int main() {
     (void)hipMalloc(&g_out, 256 * 1024 * sizeof(float)); (void)hipMalloc(&g_cyc, 256 * 32 * sizeof(long long));
+    run_mix<5, 0, 0>(); run_mix<5, 3, 0>(); run_mix<5, 5, 0>(); run_mix<5, 6, 0>(); run_mix<5, 12, 0>(); run_mix<5, 24, 0>();
     run_mix<0, 0, 0>(); run_mix<0, 3, 0>(); run_mix<0, 6, 0>(); run_mix<0, 6, 1>(); run_mix<0, 6, 2>(); run_mix<0, 8, 1>(); run_mix<0, 10, 1>();
     run_mix<0, 12, 0>(); run_mix<0, 24, 0>();
     run_mix<3, 6, 0>(); run_mix<3, 12, 0>(); run_mix<3, 24, 0>();
