@@ -634,6 +634,27 @@ __device__ __forceinline__ void coop_mma(f32x16 (&acc)[1], const uint4* __restri
             mfma_step_h<1>(acc, wf[S], bhi, blo);
         }
 }
+// A chain of up to 2 * KSM steps out of KSM plane registers: behind the MFMAs of step S the planes of step S + KSM are requested into the
+// registers step S has just released, so the second batch arrives while the first is still being multiplied (the plain form asked for
+// it behind the LAST step of the first batch: an exposed L2 round trip of 8 KiB per wave in the middle of every 2N-wide chain).
+template <int KSM>
+__device__ __forceinline__ void coop_mma_refill(f32x16 (&acc)[1], const uint4* __restrict__ img, HFrag<1> (&wf)[KSM], const uint4* __restrict__ wp,
+                                                int KS, int lane) {
+#pragma unroll
+    for (int S = 0; S < KSM; ++S)
+        if (S < KS) {
+            const h8 bhi = __builtin_bit_cast(h8, img[(size_t)(2 * S) * 64 + lane]), blo = __builtin_bit_cast(h8, img[(size_t)(2 * S + 1) * 64 + lane]);
+            mfma_step_h<1>(acc, wf[S], bhi, blo);
+            if (S + KSM < KS) load_hfrag<1>(wf[S], wp + (size_t)(S + KSM) * 128, 0);
+        }
+#pragma unroll
+    for (int S = 0; S < KSM; ++S)
+        if (S + KSM < KS) {
+            const h8 bhi = __builtin_bit_cast(h8, img[(size_t)(2 * (S + KSM)) * 64 + lane]), blo = __builtin_bit_cast(h8, img[(size_t)(2 * (S + KSM) + 1) * 64 + lane]);
+            mfma_step_h<1>(acc, wf[S], bhi, blo);
+        }
+}
+
 // (mean, M2) of a row over N = 32 * NT features from the per-slice (mean, M2) in `st` (Chan, equal counts)
 template <int NT>
 __device__ __forceinline__ void coop_merge_stats(const float2* __restrict__ st /* [NT][32] of this tile slot */, int j, float& mean, float& m2) {
@@ -654,9 +675,14 @@ constexpr int kCoopBarriers = 7;
 
 // The body: `tile_raw` = the tile of this wave's slot (>= ntiles: an idle slot that only meets the barriers and stores nothing),
 // `slot` / `w` = the wave's tile slot and 32-feature slice, `img` / `stats` = the workgroup's LDS (kCoopLdsU4 uint4, 4 x 32 float2).
+// `vlds` (7 * N floats of LDS, or null): the per-feature vectors every stage reads -- gamma2 | beta2 | gamma3 | beta3 | c2 | c3 | this step's
+// time-bias row -- staged by the workgroup at the top and read from LDS behind the first barrier.  Round 5 (tools/tile_stamps.py): read
+// from global memory right where they are used, each was an exposed L2 round trip on the tile's critical path (the transforms of stages
+// 2 and 3 took 5x their arithmetic); likewise the condition embedding is requested a stage early and the second batch of the planes
+// of a 2N-wide input refills the registers of the first behind each step's MFMAs.
 template <int N, bool SCLIN>
 __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const int tile_raw, const int slot, const int w, uint4* __restrict__ img,
-                                                   float2* __restrict__ stats) {
+                                                   float2* __restrict__ stats, float* __restrict__ vlds = nullptr) {
     constexpr int NG = N / 8, NT = N / 32, TPW = 4 / NT, KS = NG / 2;
     constexpr int kSlotU4 = kCoopLdsU4 / TPW;
     const BlockArgs& a = ah.b;
@@ -668,6 +694,19 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
     uint4* const Rimg = Bimg + kSlotU4 / 2;
     float2* const st = stats + slot * NT * 32;
     const int ks0 = (a.in0.groups + 1) >> 1, ks1 = (a.in1.groups + 1) >> 1, KS1 = ks0 + ks1;
+    const bool tb_lds = vlds && !a.ts;                  // one time-bias row for the whole launch (sampling); per-row entries stay in memory
+    if (vlds) {
+        // thread t stages one float4: 7 vectors x N / 4 quads (N = 128: 224 threads; N = 64: 112, the two waves that run a 64-wide block)
+        constexpr int per = N / 4;
+        const int t = threadIdx.x, v = t / per, o = (t % per) * 4;
+        if (t < 7 * per && (v < 6 || tb_lds)) {
+            const float* src = v == 0 ? a.gamma2 : v == 1 ? a.beta2 : v == 2 ? a.gamma3 : v == 3 ? a.beta3 : v == 4 ? a.c2 : v == 5 ? a.c3
+                                      : a.tbias + (size_t)(a.step_ptr ? *a.step_ptr : 0) * a.tb_stride;
+            *reinterpret_cast<float4*>(vlds + v * N + o) = ld4(src + o);
+        }
+    }
+    const float* const g2p = vlds ? vlds : a.gamma2, * const b2p = vlds ? vlds + N : a.beta2, * const g3p = vlds ? vlds + 2 * N : a.gamma3,
+               * const b3p = vlds ? vlds + 3 * N : a.beta3, * const c2p = vlds ? vlds + 4 * N : a.c2, * const c3p = vlds ? vlds + 5 * N : a.c3;
 
     // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as k_resblock_h
     float mean1, rstd1;
@@ -688,10 +727,11 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- stage 1 operands: this wave transforms k16-steps w, w + NT, ... of the (concatenated) input
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x2001);
     constexpr int KS1M = SCLIN ? NG : NG / 2;           // concat input of an up block: 2N wide
     constexpr int KSB = KS1M < 8 ? KS1M : 8;            // planes in flight per batch (8 steps = 64 VGPRs)
     HFrag<1> wf1[KSB];
-    coop_load_w<KSB>(wf1, ah.W1h + (size_t)w * KS1 * 128 + lane, KS1);
+    float4 cvp[4] = {z4, z4, z4, z4};                   // condition embedding of this wave's slice (conditional tiles), added behind stage 2
     {
         const float c = rstd1, d = -mean1 * rstd1;
         constexpr int MY = KS1M / NT;                   // k16-steps per wave (upper bound)
@@ -711,6 +751,13 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
                 g0[i] = ld4(a.gamma1 + gbase); b0[i] = ld4(a.beta1 + gbase); g1[i] = ld4(a.gamma1 + gbase + 8); b1[i] = ld4(a.beta1 + gbase + 8);
             }
         }
+        // the stage's planes BEHIND the tile's own inputs (loads return in order: the transform below needs only the inputs)
+        coop_load_w<KSB>(wf1, ah.W1h + (size_t)w * KS1 * 128 + lane, KS1);
+        if (tile >= a.uncond_tiles) {
+            const float* cp = a.cond_pre + ((size_t)ptile * NG + 4 * w) * 256 + lane * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cvp[q] = ld4(cp + (size_t)q * 256);
+        }
 #pragma unroll
         for (int i = 0; i < MY; ++i) {
             const int S = w + i * NT;
@@ -729,19 +776,19 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
             }
         }
     }
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x2002);
     __syncthreads();
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x2003);
 
     // ---- stage 1: this wave's 32 output features
     f32x16 acc1[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-    coop_mma<KSB>(acc1, Bimg, wf1, KS1, lane);
-    if (KS1M > KSB) {                                   // second batch of a 2N-wide input
-        coop_load_w<KSB>(wf1, ah.W1h + (size_t)w * KS1 * 128 + lane, KS1, KSB);
-        coop_mma<KSB>(acc1, Bimg, wf1, KS1, lane, KSB);
-    }
+    if (KS1M > KSB) coop_mma_refill<KSB>(acc1, Bimg, wf1, ah.W1h + (size_t)w * KS1 * 128 + lane, KS1, lane);   // 2N-wide input: two batches
+    else coop_mma<KSB>(acc1, Bimg, wf1, KS1, lane);
     HFrag<1> wf2[KS];                                   // next stage's planes: requested now, used after two barriers
     coop_load_w<KS>(wf2, ah.W2h + (size_t)w * KS * 128 + lane, KS);
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x2004);
     {
         int entry = 0;
         if (a.ts) {
@@ -751,7 +798,8 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
         } else if (a.step_ptr) {
             entry = *a.step_ptr;
         }
-        acc_unscale_add<1>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride + 32 * w, h);
+        if (tb_lds) acc_unscale_add<1>(acc1, inv1, vlds + 6 * N + 32 * w, h);
+        else acc_unscale_add<1>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride + 32 * w, h);
     }
     if (a.save_h1 && live) {
 #pragma unroll
@@ -765,6 +813,7 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
         if (h == 0) st[w * 32 + j] = make_float2(m, q);
     }
     __syncthreads();                 // statistics published; every wave is also done reading the stage-1 image
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x2005);
 
     // ---- stage 2
     f32x16 acc2[1];
@@ -778,8 +827,8 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int S = 2 * w + half, r0 = 8 * half;
-            const float4 g0 = ld4(a.gamma2 + 16 * S + 4 * h), b0 = ld4(a.beta2 + 16 * S + 4 * h);
-            const float4 g1 = ld4(a.gamma2 + 16 * S + 8 + 4 * h), b1 = ld4(a.beta2 + 16 * S + 8 + 4 * h);
+            const float4 g0 = ld4(g2p + 16 * S + 4 * h), b0 = ld4(b2p + 16 * S + 4 * h);
+            const float4 g1 = ld4(g2p + 16 * S + 8 + 4 * h), b1 = ld4(b2p + 16 * S + 8 + 4 * h);
             float v[8];
             act8(v, make_float4(acc1[0][r0], acc1[0][r0 + 1], acc1[0][r0 + 2], acc1[0][r0 + 3]),
                  make_float4(acc1[0][r0 + 4], acc1[0][r0 + 5], acc1[0][r0 + 6], acc1[0][r0 + 7]), c, d, g0, b0, g1, b1);
@@ -788,18 +837,20 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
             coop_publish(Bimg, S, lane, hi, lo);
         }
     }
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x2006);
     __syncthreads();
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x2007);
     coop_mma<KS>(acc2, Bimg, wf2, KS, lane);
     HFrag<1> wf3[KS];
     coop_load_w<KS>(wf3, ah.W3h + (size_t)w * KS * 128 + lane, KS);
     HFrag<1> wfs[SCLIN ? KSB : 1];
     if (SCLIN) coop_load_w<(SCLIN ? KSB : 1)>(wfs, ah.Wsch + (size_t)w * KS1 * 128 + lane, KS1);
-    acc_unscale_add<1>(acc2, inv2, a.c2 + 32 * w, h);
+    acc_unscale_add<1>(acc2, inv2, c2p + 32 * w, h);
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x2008);
     if (tile >= a.uncond_tiles) {
-        const float* cp = a.cond_pre + ((size_t)ptile * NG + 4 * w) * 256 + lane * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 cv = ld4(cp + (size_t)q * 256);
+            const float4 cv = cvp[q];
             acc2[0][4 * q + 0] += cv.x; acc2[0][4 * q + 1] += cv.y; acc2[0][4 * q + 2] += cv.z; acc2[0][4 * q + 3] += cv.w;
         }
     }
@@ -815,6 +866,7 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
         if (h == 0) st[w * 32 + j] = make_float2(m, q);
     }
     __syncthreads();
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x2009);
 
     // ---- stage 3 (+ shortcut in the same scaled accumulator)
     f32x16 (&acc3)[1] = acc1;
@@ -828,8 +880,8 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int S = 2 * w + half, r0 = 8 * half;
-            const float4 g0 = ld4(a.gamma3 + 16 * S + 4 * h), b0 = ld4(a.beta3 + 16 * S + 4 * h);
-            const float4 g1 = ld4(a.gamma3 + 16 * S + 8 + 4 * h), b1 = ld4(a.beta3 + 16 * S + 8 + 4 * h);
+            const float4 g0 = ld4(g3p + 16 * S + 4 * h), b0 = ld4(b3p + 16 * S + 4 * h);
+            const float4 g1 = ld4(g3p + 16 * S + 8 + 4 * h), b1 = ld4(b3p + 16 * S + 8 + 4 * h);
             float v[8];
             act8(v, make_float4(acc2[0][r0], acc2[0][r0 + 1], acc2[0][r0 + 2], acc2[0][r0 + 3]),
                  make_float4(acc2[0][r0 + 4], acc2[0][r0 + 5], acc2[0][r0 + 6], acc2[0][r0 + 7]), c, d, g0, b0, g1, b1);
@@ -838,17 +890,16 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
             coop_publish(Bimg, S, lane, hi, lo);
         }
     }
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x200a);
     __syncthreads();
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x200b);
     coop_mma<KS>(acc3, Bimg, wf3, KS, lane);
     if (SCLIN) {
-        coop_mma<(SCLIN ? KSB : 1)>(acc3, Rimg, wfs, KS1, lane);
-        if (KS1M > KSB) {
-            coop_load_w<(SCLIN ? KSB : 1)>(wfs, ah.Wsch + (size_t)w * KS1 * 128 + lane, KS1, KSB);
-            coop_mma<(SCLIN ? KSB : 1)>(acc3, Rimg, wfs, KS1, lane, KSB);
-        }
-        acc_unscale_add<1>(acc3, inv3, a.c3 + 32 * w, h);
+        if (KS1M > KSB) coop_mma_refill<(SCLIN ? KSB : 1)>(acc3, Rimg, wfs, ah.Wsch + (size_t)w * KS1 * 128 + lane, KS1, lane);
+        else coop_mma<(SCLIN ? KSB : 1)>(acc3, Rimg, wfs, KS1, lane);
+        acc_unscale_add<1>(acc3, inv3, c3p + 32 * w, h);
     } else {
-        acc_unscale_add<1>(acc3, inv3, a.c3 + 32 * w, h);
+        acc_unscale_add<1>(acc3, inv3, c3p + 32 * w, h);
         const float* xp = a.in0.data + ((size_t)seg_tile(a.in0, tile) * NG + 4 * w) * 256 + lane * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -857,6 +908,7 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
         }
     }
     // ---- output statistics (merged by the first wave of the tile) + store
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x200c);
     {
         float m, q;
         acc_stats<32, 1>(acc3, h, m, q);
@@ -864,6 +916,7 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
         if (h == 0) st[w * 32 + j] = make_float2(m, q);
     }
     __syncthreads();
+    DSG_STAMP(tile_raw == 0 && w == 0, 0x200d);
     if (live) {
         if (w == 0 && h == 0) {
             float mean, m2;
@@ -882,9 +935,10 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
     constexpr int NT = N / 32, TPW = 4 / NT;
     __shared__ uint4 img[kCoopLdsU4];
     __shared__ float2 stats[4 * 32];
+    __shared__ float4 vecs[7 * N / 4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = wave / NT, w = wave % NT;
-    resblock_coop_body<N, SCLIN>(ah, blockIdx.x * TPW + slot, slot, w, img, stats);
+    resblock_coop_body<N, SCLIN>(ah, blockIdx.x * TPW + slot, slot, w, img, stats, reinterpret_cast<float*>(vecs));
 }
 
 // A wide block followed by the Linear that consumes it (Down/Upsample: raw; final: LayerNorm + SiLU, row-major out),
@@ -1017,6 +1071,33 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
         chain_from_mem_h<NT, LNACT>(acc, a.in.data + (size_t)seg_tile(a.in, tile) * KG * 256 + lane * 4, KG, ah.Wh + lane, nt_stride,
                                     LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
     } else {
+        // rows of 16-byte quads up to 128 wide (MSR-80c: 80): EVERY quad of the row is requested before the first step (round 5: with
+        // one step's two loads issued per step, feature_proj was five dependent HBM round trips long -- 26 us at 65 536 rows for 55 MB)
+        constexpr int kPreS = 8;
+        if ((a.in_width & 3) == 0 && KS <= kPreS) {
+            float4 xq[2 * kPreS];
+#pragma unroll
+            for (int q = 0; q < 2 * kPreS; ++q) {
+                const int f = 8 * q + 4 * h;
+                xq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < 2 * KS && row < a.nrows && f < a.in_width) xq[q] = ld4(a.in_rm + (size_t)row * a.in_width + f);
+            }
+#pragma unroll
+            for (int S = 0; S < kPreS; ++S) {
+                if (S < KS) {
+                    HFrag<NT> wc;
+                    load_hfrag<NT>(wc, ah.Wh + (size_t)S * 128 + lane, nt_stride);
+                    const float4 x0 = xq[2 * S], x1 = xq[2 * S + 1];
+                    const float v[8] = {kRawScale * x0.x, kRawScale * x0.y, kRawScale * x0.z, kRawScale * x0.w,
+                                        kRawScale * x1.x, kRawScale * x1.y, kRawScale * x1.z, kRawScale * x1.w};
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) vmax = fmaxf(vmax, fabsf(v[jj]));
+                    h8 bhi, blo;
+                    split8(v, bhi, blo);
+                    mfma_step_h<NT>(acc, wc, bhi, blo);
+                }
+            }
+        } else
         for (int S = 0; S < KS; ++S) {
             HFrag<NT> wc;
             load_hfrag<NT>(wc, ah.Wh + (size_t)S * 128 + lane, nt_stride);

@@ -30,23 +30,12 @@ __device__ __forceinline__ void tile_linear(const FusedOpH& op, const int tile, 
     else linear_body_h<NT, IN_FRAG, OUT_FRAG, false>(l, tile, lane);
 }
 
-template <int V8NB>
-__global__ __launch_bounds__(256, 2) void k_unet_tile(const FusedOpH* __restrict__ ops, const int op_lo, const int nops, const int ntiles, const int run_lo,
-                                                   const int run_hi, const int v8_at, const int v8_nops, const float* __restrict__ v8_img) {
-    __shared__ uint4 img[kCoopLdsU4];
-    __shared__ float2 stats[4 * 32];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x;              // grid = ntiles
+// operators [lo, hi) outside the narrow run, one after the other
+__device__ __forceinline__ void tile_wide_ops(const FusedOpH* __restrict__ ops, const int lo, const int hi, const int tile, const int wave, const int lane,
+                                              uint4* __restrict__ img, float2* __restrict__ stats, float* __restrict__ vecs) {
 #pragma unroll 1
-    for (int i = op_lo; i < nops;) {
-        if (i == run_lo && run_hi > run_lo) {
-            if (wave == 0) narrow_run_body<true, V8NB>(ops + run_lo, run_hi - run_lo, tile, lane, v8_at, v8_nops, v8_img, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                  // the run's stored tensors (skips, its last output) are visible to the whole workgroup
-            i = run_hi;
-            continue;
-        }
+    for (int i = lo; i < hi; ++i) {
+        DSG_STAMP(blockIdx.x == 0 && wave == 0, 0x1000 + i);      // measurement builds only (tools/tile_stamps.py)
         const FusedOpH& op = ops[i];
         if (op.kind == 0) {
             // a wide block: all four waves (128) or the first two (64); its last barrier sits in front of the stores, the one below
@@ -54,11 +43,11 @@ __global__ __launch_bounds__(256, 2) void k_unet_tile(const FusedOpH* __restrict
             BlockArgsH b = op.b;
             globalize<false>(b);
             if (op.N == 128) {
-                if (op.sclin) resblock_coop_body<128, true>(b, tile, 0, wave, img, stats);
-                else resblock_coop_body<128, false>(b, tile, 0, wave, img, stats);
+                if (op.sclin) resblock_coop_body<128, true>(b, tile, 0, wave, img, stats, vecs);
+                else resblock_coop_body<128, false>(b, tile, 0, wave, img, stats, vecs);
             } else if (wave < 2) {
-                if (op.sclin) resblock_coop_body<64, true>(b, tile, 0, wave, img, stats);
-                else resblock_coop_body<64, false>(b, tile, 0, wave, img, stats);
+                if (op.sclin) resblock_coop_body<64, true>(b, tile, 0, wave, img, stats, vecs);
+                else resblock_coop_body<64, false>(b, tile, 0, wave, img, stats, vecs);
             } else {
 #pragma unroll
                 for (int nb = 0; nb < kCoopBarriers; ++nb) __syncthreads();
@@ -73,8 +62,30 @@ __global__ __launch_bounds__(256, 2) void k_unet_tile(const FusedOpH* __restrict
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                      // stores of this operator -> loads of the next (same workgroup: one CU, one L1)
-        ++i;
     }
+}
+
+template <int V8NB>
+__global__ __launch_bounds__(256, 2) void k_unet_tile(const FusedOpH* __restrict__ ops, const int op_lo, const int nops, const int ntiles, const int run_lo,
+                                                      const int run_hi, const int v8_at, const int v8_nops, const float* __restrict__ v8_img) {
+    __shared__ uint4 img[kCoopLdsU4];
+    __shared__ float2 stats[4 * 32];
+    __shared__ float4 vecs4[7 * 128 / 4];
+    float* const vecs = reinterpret_cast<float*>(vecs4);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x;              // grid = ntiles
+    const bool has_run = run_hi > run_lo;
+    // the wide operators in front of the narrow run, the run (first wave), the wide operators behind it
+    tile_wide_ops(ops, op_lo, has_run ? run_lo : nops, tile, wave, lane, img, stats, vecs);
+    if (has_run) {
+        DSG_STAMP(blockIdx.x == 0 && wave == 0, 0x1000 + run_lo);
+        if (wave == 0) narrow_run_body<true, V8NB>(ops + run_lo, run_hi - run_lo, tile, lane, v8_at, v8_nops, v8_img, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                      // the run's stored tensors (skips, its last output) are visible to the whole workgroup
+        tile_wide_ops(ops, run_hi, nops, tile, wave, lane, img, stats, vecs);
+    }
+    DSG_STAMP(blockIdx.x == 0 && wave == 0, 0x1fff);
 }
 
 }  // namespace dsg

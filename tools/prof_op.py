@@ -15,6 +15,8 @@ dev = torch.device("cuda:0")
 ddpm = bench.build_model(dev, 6)
 if os.environ.get("PRECISION"):      # e.g. PRECISION=f32: the exact-float32 kernels
     ddpm.model.set_precision(os.environ["PRECISION"])
+if os.environ.get("POLICY"):         # "coop_max_tiles,narrow_small_max_tiles" (dsg_set_launch_policy), e.g. POLICY=1048576,-1: the cooperative
+    ddpm.model.set_launch_policy(*[int(v) for v in os.environ["POLICY"].split(",")])   # N-split form at every size
 cond = torch.rand(B, 80, device=dev)
 ddpm.sample(cond, 1.0, seed=1)          # fills the workspace with real activations
 L, hd = _lib.lib(), ddpm.model.native_handle()
