@@ -87,17 +87,14 @@ def self_launch(a):
     raise SystemExit(rc)
 
 
-BOX_REF_MIX_GSLOTS = 50.0      # nominal rate of the MFMA + 6-vector-instruction probe: `value_at_ref_box` = value x this / box.mix_gslots
-
-
 def box_calibrate():
     """dsg_box_calibrate on the current device: {mfma_tflops, mix_gslots, copy_gbs} of three fixed probes (how to compare
     two lines measured on different boxes)."""
     import ctypes
     from diffsg_amd import _lib
-    o = (ctypes.c_float * 3)()
+    o = (ctypes.c_float * 4)()
     _lib.check(_lib.lib().dsg_box_calibrate(o, _lib.stream_ptr()))
-    return {"mfma_tflops": round(o[0], 1), "mix_gslots": round(o[1], 2), "copy_gbs": round(o[2], 1)}
+    return {"mfma_tflops": round(o[0], 1), "mix_gslots": round(o[1], 2), "copy_gbs": round(o[2], 1), "panel_gslots": round(o[3], 2)}
 
 
 def cpu_baseline(sample_rows=4096, steps=2, B_ref=65536):
@@ -431,15 +428,20 @@ def main():
                                    f"(64,32,16,8), n_blocks 2), omega={a.omega:g}, device Philox noise; rows sharded, no collective",
                        "batch_per_gpu": B, "solution_dim": 80, "parallelism": f"rows x{world}"},
             "row_steps_per_s": world * K * B / dt,
-            # `value` = K / the median of R consecutive timed K-step calls; the spread of the calls and this box's rates on two fixed
-            # probes ride along, and `value_at_ref_box` rescales the median by the box's matrix-core probe
+            # `value` = K / the median of R consecutive timed K-step calls; the spread of the calls and this box's rates on four fixed
+            # probes ride along
             "repeats": {"n": len(rep_ms), "ms_per_step_min": min(rep_ms), "ms_per_step_median": step_ms, "ms_per_step_max": max(rep_ms),
                         "ms_per_step_all": [round(v, 4) for v in rep_ms]},
-            "box": {"before": box, "after": box_after, "ref_mix_gslots": BOX_REF_MIX_GSLOTS,
-                    "probe": "dsg_box_calibrate, median of five ~5-ms launches each: mfma_tflops = dependent v_mfma_f32_32x32x16_f16 on every SIMD; "
-                             "mix_gslots = the same with 6 vector instructions behind every MFMA (1e9 slots/s); copy_gbs = 256 MiB float4 device "
-                             "copy, read + written bytes"},
-            "value_at_ref_box": world * K / dt * BOX_REF_MIX_GSLOTS / max(0.5 * (box["mix_gslots"] + box_after["mix_gslots"]), 1e-3),
+            "box": {"before": box, "after": box_after,
+                    "probe": "dsg_box_calibrate, median of five 3-10 ms launches each, run right before and right after the timed calls: mfma_tflops = "
+                             "dependent v_mfma_f32_32x32x16_f16 on every SIMD; mix_gslots = the same with 6 vector instructions behind every MFMA "
+                             "(1e9 slots/s); copy_gbs = 256 MiB float4 device copy, read + written bytes; panel_gslots = a frozen miniature of the "
+                             "128-wide panel kernels' load profile (LDS-DMA weight stream + activation stream + LDS reads + MFMA + vector "
+                             "instructions), 1e9 MFMA slots/s",
+                    "note": "round 5, five boxes: the four probes agree within 2 % (panel_gslots 5 %) between boxes whose `value` differs by 8 % "
+                            "-- the spread of the pool is NOT the matrix-pipe clock, the vector rate or the copy bandwidth, and no probe normalises "
+                            "it; compare lines through `repeats` (within-box spread ~1 %) and `roofline.avg_launch_ms`, and trees through same-box "
+                            "A-B runs (tools/tree_ab.sh; DESIGN.md 8)"},
             "roofline": {"bound": "mfma", "kernel": f"{kname} ({len(dom)} launches/step: {', '.join(r[0] for r in dom)})",
                          "achieved": mfma_x * ach, "peak": unit_peak, "unit": "TFLOP/s", "frac": mfma_x * ach / unit_peak,
                          "mfma_unit": "v_mfma_f32_32x32x16_f16, 3 per float32 product (hi*hi + hi*lo + lo*hi)" if split else "v_mfma_f32_32x32x2_f32",

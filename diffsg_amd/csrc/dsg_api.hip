@@ -508,7 +508,11 @@ bool bwd_coop_ok(int N, bool sclin, const BlockBwdArgsH& a) {
 }
 // `coop`: the cooperative form where the shapes allow it (faster at every batch size measured: 512 rows 72 -> 20 us per up-128 block,
 // 32 768 rows 105 -> 65 us); the fused narrow backward's table keeps the one-wave-per-tile bodies
-void launch_res_bwd_h(int N, bool sclin, const BlockBwdArgsH& a, hipStream_t s, bool coop = false) {
+// Returns false for a shape no kernel is instantiated for: a 64- / 128-wide block whose inputs are not exactly N wide.  UNet1D builds
+// none (DownBlock w -> w, UpBlock 2w -> w, UNetCF.py:278-311); the one-wave-per-tile form that covered them kept 72-108 bytes of scratch
+// per lane at N = 128 and was never launched: removed rather than shipped unmeasured.
+bool launch_res_bwd_h(int N, bool sclin, const BlockBwdArgsH& a, hipStream_t s, bool coop = false) {
+    if ((N == 64 || N == 128) && !(coop && bwd_coop_ok(N, sclin, a))) return false;
     if (coop && bwd_coop_ok(N, sclin, a)) {
         const dim3 block(256);
         if (N == 128) {
@@ -520,16 +524,16 @@ void launch_res_bwd_h(int N, bool sclin, const BlockBwdArgsH& a, hipStream_t s, 
             if (sclin) hipLaunchKernelGGL((k_resblock_bwd_c<64, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_resblock_bwd_c<64, false>), grid, block, 0, s, a);
         }
-        return;
+        return true;
     }
     switch (N) {
         case 4: launch_res_bwd_h_n<4>(sclin, a, s); break;
         case 8: launch_res_bwd_h_n<8>(sclin, a, s); break;
         case 16: launch_res_bwd_h_n<16>(sclin, a, s); break;
         case 32: launch_res_bwd_h_n<32>(sclin, a, s); break;
-        case 64: launch_res_bwd_h_n<64>(sclin, a, s); break;
-        case 128: launch_res_bwd_h_n<128>(sclin, a, s); break;
+        default: return false;
     }
+    return true;
 }
 void launch_res_bwd(int N, bool sclin, const BlockBwdArgs& a, hipStream_t s) {
     switch (N) {
@@ -2506,7 +2510,8 @@ int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int*
             BlockBwdArgsH ah;
             fill_res_bwd_args(h, op, tiles, a, ah);
             if (h->use_split) {
-                launch_res_bwd_h(r.N, r.sclin, ah, s, true);
+                if (!launch_res_bwd_h(r.N, r.sclin, ah, s, true))
+                    return fail("dsg_train_step: no backward kernel for a %d-wide block with inputs %d + %d wide", r.N, r.in0, r.in1);
                 if (fork_parts(oi)) return 1;
             } else {
                 launch_res_bwd(r.N, r.sclin, a, s);
@@ -2852,7 +2857,8 @@ int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* st
 //                       the bare matrix pipe at the clock the box holds under it;
 //   out[1] mix_gslots   the same loop with six vector instructions (one of them transcendental) behind every MFMA -- the instruction mix
 //                       of the block kernels -- in 1e9 (MFMA + 6 vector) slots per second over the chip;
-//   out[2] copy_gbs     a 256 MiB float4 copy inside a buffer allocated for the call (read + written bytes per second).
+//   out[2] copy_gbs     a 256 MiB float4 copy inside a buffer allocated for the call (read + written bytes per second);
+//   out[3] panel_gslots the frozen miniature of the panel kernels' load profile (k_calib_panel), 1e9 MFMA slots per second.
 int dsg_box_calibrate(float* out3, void* stream) {
     if (!out3) return fail("dsg_box_calibrate: null output");
     hipStream_t s = (hipStream_t)stream;
@@ -2867,9 +2873,9 @@ int dsg_box_calibrate(float* out3, void* stream) {
     float* sink = nullptr;
     const size_t copy_bytes = (size_t)256 << 20;
     char* buf = nullptr;
-    HIPCK(hipMalloc(&sink, (size_t)cus * 2 * 256 * sizeof(float)));
+    HIPCK(hipMalloc(&sink, (size_t)cus * 2 * 512 * sizeof(float)));
     HIPCK(hipMalloc(&buf, 2 * copy_bytes));
-    HIPCK(hipMemsetAsync(buf, 1, 2 * copy_bytes, s));
+    hipLaunchKernelGGL(dsg::k_calib_fill, dim3(cus * 8), dim3(256), 0, s, reinterpret_cast<uint4*>(buf), 2 * copy_bytes / 16);
     auto median5 = [&](auto&& launch, float& ms_out) -> int {
         float t[6];
         for (int rep = 0; rep < 6; ++rep) {      // the first launch is a warm-up
@@ -2893,6 +2899,15 @@ int dsg_box_calibrate(float* out3, void* stream) {
     out3[0] = (float)((double)cus * 8 * it0 * 48 * 32768.0 / (ms0 * 1e-3) / 1e12);
     out3[1] = (float)((double)cus * 8 * it6 * 48 / (ms6 * 1e-3) / 1e9);
     out3[2] = (float)(2.0 * copy_bytes / (msc * 1e-3) / 1e9);
+    // out3[3]: the frozen miniature of the panel kernels' load profile (dsg_panel.hpp, k_calib_panel): one workgroup per CU, ~10 ms per
+    // launch -- long enough for the clock to settle under it -- 1e9 MFMA slots per second over the chip
+    {
+        const int panels = 1536;
+        float msp = 0.f;
+        if (median5([&] { hipLaunchKernelGGL(dsg::k_calib_panel, dim3(cus), dim3(512), 0, s, reinterpret_cast<const uint4*>(buf),
+                                             reinterpret_cast<const uint4*>(buf + copy_bytes), copy_bytes / 16 - 1, panels, sink); }, msp)) return 1;
+        out3[3] = (float)((double)cus * 8 * panels * 48 / (msp * 1e-3) / 1e9);
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(sink);

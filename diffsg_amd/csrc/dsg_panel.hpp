@@ -765,4 +765,77 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Box calibration probe with the panel kernel's load profile (dsg_box_calibrate, out[3]).  The pool's boxes run k_panel128_h 8-10 %
+// apart while a bare MFMA loop, an MFMA + vector loop out of registers and a device copy differ by 1-2 % between the same boxes (round
+// 5): what differs is the clock a box holds under THIS mix of matrix, vector, LDS and memory work.  The probe is a FROZEN miniature of
+// that mix -- it must not follow the product kernels when they change -- : one 8-wave workgroup per CU; per "panel" every wave moves 4 KiB
+// of an L2-resident buffer into LDS by LDS-DMA (the weight stream) and 2 KiB of a large buffer into registers (the activation stream),
+// meets one barrier, then issues 48 x { one 1-KiB LDS read, one v_mfma_f32_32x32x16_f16, six vector instructions (one transcendental) }.
+// ---------------------------------------------------------------------------------------------
+// non-trivial half-precision patterns (values in [0.5, 1)): the clock a box holds depends on the data
+__global__ void k_calib_fill(uint4* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned hsh = (unsigned)i * 2654435761u;
+        uint4 v;
+        v.x = 0x38003800u | (hsh & 0x03ff03ffu); hsh = hsh * 1664525u + 1013904223u;
+        v.y = 0x38003800u | (hsh & 0x03ff03ffu); hsh = hsh * 1664525u + 1013904223u;
+        v.z = 0x38003800u | (hsh & 0x03ff03ffu); hsh = hsh * 1664525u + 1013904223u;
+        v.w = 0x38003800u | (hsh & 0x03ff03ffu);
+        p[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void k_calib_panel(const uint4* __restrict__ wbuf /* 64 KiB, L2-resident */, const uint4* __restrict__ abuf,
+                                                        size_t abuf_mask /* uint4 count - 1, a power of two */, int panels, float* __restrict__ sink) {
+    __shared__ uint4 lds[2 * kPanelU4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds;
+    const unsigned my = lds0 + (unsigned)wave * 4096u;
+    typedef _Float16 h8c __attribute__((ext_vector_type(8)));
+    h8c b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = (_Float16)(-0.81f + 0.021f * (float)((threadIdx.x * 5 + i) & 31));
+    f32x16 c[4] = {{0}, {0}, {0}, {0}};
+    float v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = 1.0f + 0.001f * (float)(threadIdx.x + i);
+    for (int i = threadIdx.x; i < 2 * kPanelU4; i += 512) lds[i] = make_uint4(0x3c003c00u, 0x38003800u, 0x3a003a00u, 0x34003400u);
+    __syncthreads();
+    size_t apos = ((size_t)blockIdx.x * 8 + wave) * 128 + lane;       // this wave's cursor in the activation stream
+    const size_t astride = (size_t)gridDim.x * 8 * 128;
+    uint4 a0 = abuf[apos & abuf_mask], a1 = abuf[(apos + 64) & abuf_mask];
+    for (int p = 0; p < panels; ++p) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        glds_quad_s((unsigned)lane * 16u, wbuf + (size_t)((p & 1) * 8 + wave) * 256, my + (unsigned)((p + 1) & 1) * (kPanelU4 * 16u));
+        apos += astride;
+        const uint4 n0 = abuf[apos & abuf_mask], n1 = abuf[(apos + 64) & abuf_mask];
+        const uint4* rd = lds + (p & 1) * kPanelU4 + lane;
+        v[0] += __uint_as_float(a0.x & 0x007fffffu | 0x3f800000u) * 1e-3f;    // the stream's data enters the arithmetic
+        v[1] += __uint_as_float(a1.y & 0x007fffffu | 0x3f800000u) * 1e-3f;
+#pragma unroll
+        for (int r = 0; r < 48; ++r) {
+            const uint4 wv = rd[(r % 32) * 64];
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[r & 3]) : "v"(__builtin_bit_cast(h8c, wv)), "v"(b));
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int q = (r * 6 + k) % 12;
+                if (k == 5) asm volatile("v_exp_f32 %0, %0" : "+v"(v[q]));
+                else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[q]) : "v"(0.999f), "v"(0.001f));
+            }
+        }
+        if ((p & 15) == 15) { c[0] *= 1e-6f; c[1] *= 1e-6f; c[2] *= 1e-6f; c[3] *= 1e-6f; }
+        a0 = n0; a1 = n1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc += c[0][i] + c[1][i] + c[2][i] + c[3][i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) sacc += v[i];
+    sink[blockIdx.x * 512 + threadIdx.x] = sacc;
+}
+
 }  // namespace dsg

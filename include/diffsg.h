@@ -225,11 +225,12 @@ int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* st
 /* Summed HIP-event time (ms) and launch count of operator `op` over the last DSG_SAMPLE_PROFILE call. */
 int dsg_op_profile(const dsg_handle* h, int op, double* ms_total, int* calls);
 
-/* Box calibration for bench.py (`box`): three fixed probes on the current device, median of five ~5-ms launches each, timed with
- * HIP events on `stream` (synchronises): out3[0] = rate of a dependent v_mfma_f32_32x32x16_f16 loop on every SIMD (TFLOP/s, dense f16),
- * out3[1] = the same loop with six vector instructions behind every MFMA (1e9 slots/s), out3[2] = a 256 MiB device copy (GB/s, read +
- * written).  Not part of the reference's seam (the reference has no benchmark): it lets a reader separate a slow box from a slow tree. */
-int dsg_box_calibrate(float* out3, void* stream);
+/* Box calibration for bench.py (`box`): four fixed probes on the current device, median of five 3-10 ms launches each, timed with
+ * HIP events on `stream` (synchronises): out[0] = rate of a dependent v_mfma_f32_32x32x16_f16 loop on every SIMD (TFLOP/s, dense f16),
+ * out[1] = the same loop with six vector instructions behind every MFMA (1e9 slots/s), out[2] = a 256 MiB device copy (GB/s, read +
+ * written), out[3] = a frozen miniature of the 128-wide panel kernels' load profile (LDS-DMA weight stream, activation stream, LDS
+ * reads, MFMAs and vector instructions interleaved; 1e9 MFMA slots/s) -- `out` has FOUR floats.  Not part of the reference's seam (the reference has no benchmark): it lets a reader separate a slow box from a slow tree. */
+int dsg_box_calibrate(float* out, void* stream);
 
 #ifdef __cplusplus
 }

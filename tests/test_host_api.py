@@ -188,7 +188,14 @@ OTHER_HOT_KERNELS = [
     "dsg::k_wgrad_h", "dsg::k_fused_narrow_bwd_h", "dsg::k_resblock_bwd_c<128, true>", "dsg::k_resblock_bwd_c<128, false>",
     "dsg::k_resblock_bwd_c<64, true>", "dsg::k_resblock_bwd_c<64, false>", "dsg::k_wide128_h<true, 0, 1>", "dsg::k_wide128_h<false, 0, 1>",
     "dsg::k_resblock_h<64, true>", "dsg::k_resblock_h<64, false>", "dsg::k_cond_embed_h", "dsg::k_colsum",
+    # every other instantiated >= 64-wide kernel of the training step and of the small-launch forms
+    "dsg::k_resblock_c<128, true>", "dsg::k_resblock_c<128, false>", "dsg::k_resblock_c<64, true>", "dsg::k_resblock_c<64, false>",
+    "dsg::k_resblock_h<128, true>", "dsg::k_resblock_h<128, false>", "dsg::k_wide128_h<false, 1, 2>", "dsg::k_wide128_h<true, 2, 3>",
+    "dsg::k_linear_h<4, 0, 0, false>", "dsg::k_linear_h<2, 0, 0, false>", "dsg::k_linear_h<3, 0, 1, true>",
 ]
+# kernels that MAY keep a few bytes of scratch (stated, bounded): the whole-net tile kernel is the union of every small-launch body under
+# one 256-register budget (two workgroups per CU); what it spills is reloaded once per operator, not inside a loop
+BOUNDED_SCRATCH_KERNELS = {"dsg::k_unet_tile<2>": 32, "dsg::k_unet_tile<3>": 32, "dsg::k_unet_tile<0>": 32}
 
 
 TABLE_DRIVEN_KERNELS = ["k_fused_narrow_lds", "k_fused_narrow_h", "k_fused_narrow_bwd_h", "k_wgrad_h", "k_wgrad", "k_colsum", "k_fused_narrow"]
@@ -239,3 +246,7 @@ def test_hot_kernels_use_no_scratch_memory(group):
     assert not missing, f"kernels not in the build record (renamed?): {missing}"
     spilled = {n: res[n]["scratch"] for n in names if res[n]["scratch"] != 0}
     assert not spilled, f"scratch bytes per lane: {spilled}"
+    if group == "other_hot":
+        assert not [n for n in res if "k_resblock_bwd_h<128" in n or "k_resblock_bwd_h<64" in n], "the one-wave-per-tile wide backward is gone"
+        over = {n: res[n]["scratch"] for n, cap in BOUNDED_SCRATCH_KERNELS.items() if res[n]["scratch"] > cap}
+        assert not over, f"scratch above the stated bound: {over}"

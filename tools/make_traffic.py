@@ -19,8 +19,11 @@ fetch, write = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 d = {"kernel": pat, "summary": cite,
      "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_bench.sh), mean per dispatch; FETCH_SIZE "
                "doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); counters are in KiB",
-     "note": "FETCH_SIZE counts the L2's fabric-side read requests, Infinity-Cache hits included: the second read of a tensor the same "
-             "launch has just read (shortcut pass over the concat input) is served on-die and is NOT HBM traffic; see DESIGN.md 3.2",
+     "note": "FETCH_SIZE counts the L2's fabric-side read requests (Infinity-Cache hits included): an upper bound of HBM bytes.  The up "
+             "block reads its concat input twice (stage 1, then the Linear shortcut): both reads are in the figure.  Round 5 sweep "
+             "(profiles/r05_concat_read_sweep.txt): at 65 536 / 131 072 / 262 144 rows -- the last past the 256 MB Infinity Cache -- FETCH per row "
+             "stays flat and the time per row falls, so the second read costs no time at any size (the kernel is not bound by these "
+             "bytes); whether it is served on-die is neither shown nor needed; DESIGN.md 3.4",
      "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
      "valu_per_mfma": vals["SQ_INSTS_VALU"] / vals["SQ_INSTS_MFMA"] if "SQ_INSTS_MFMA" in vals else None,
      "vmem_rd_per_wave": vals.get("SQ_INSTS_VMEM_RD", 0) / vals["SQ_WAVES"] if "SQ_WAVES" in vals else None,
