@@ -298,8 +298,9 @@ class UNet1D(nn.Module):
         return {0: "split_f16", 1: "f32"}[self.__dict__.get("_settings", {}).get("precision", 0)]
 
     def range_exceeded(self):
-        """True if, since the last query, a raw operand of the split-f16 path left fp16's range (dsg_range_status;
-        synchronises the device and clears the flag).  Outputs computed meanwhile are then wrong."""
+        """True if, since the last query, a raw operand of the split-f16 path left fp16's range (dsg_range_status_stream:
+        synchronises torch's CURRENT stream of the model's device -- the stream the launches went to -- and clears the flag; other
+        streams keep running).  Outputs computed meanwhile are then wrong."""
         hit = False
         # every handle that EXISTS (a module that has not launched anything has no flag to read; the twin handle of a split training
         # step has a flag word of its own)
@@ -308,7 +309,8 @@ class UNet1D(nn.Module):
             if hd is None:
                 continue
             flag = ctypes.c_int(0)
-            _lib.check(_lib.lib().dsg_range_status(hd, ctypes.byref(flag)))
+            with torch.cuda.device(self._named_param_list()[0][1].device):
+                _lib.check(_lib.lib().dsg_range_status_stream(hd, ctypes.byref(flag), _lib.stream_ptr()))
             hit = hit or bool(flag.value)
         return hit
 

@@ -168,6 +168,7 @@ _SIGS = {
     "dsg_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "dsg_set_renorm_hook": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dsg_range_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
+    "dsg_range_status_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "dsg_build_id": (ctypes.c_char_p, []),
     "dsg_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "dsg_train_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

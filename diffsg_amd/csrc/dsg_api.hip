@@ -2144,6 +2144,20 @@ int dsg_range_status(dsg_handle* h, int* exceeded) {
     return 0;
 }
 
+int dsg_range_status_stream(dsg_handle* h, int* exceeded, void* stream) {
+    if (!h || !exceeded) return fail("dsg_range_status_stream: null argument");
+    DeviceGuard dg(h);
+    hipStream_t s = (hipStream_t)stream;
+    // the flag travels through a pinned word so that the copy is truly asynchronous and only `s` is waited for
+    static thread_local int* pinned = nullptr;
+    if (!pinned) HIPCK(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int), hipHostMallocDefault));
+    HIPCK(hipMemcpyAsync(pinned, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    *exceeded = *pinned;
+    if (*exceeded) { HIPCK(hipMemsetAsync(h->range_flag, 0, sizeof(int), s)); HIPCK(hipStreamSynchronize(s)); }
+    return 0;
+}
+
 int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_max_tiles) {
     if (!h) return fail("null handle");
     DeviceGuard dg(h);

@@ -1069,7 +1069,8 @@ __global__ void k_renorm_moments_final(const double* __restrict__ part, const do
 __global__ __launch_bounds__(256) void k_renorm_apply_stats(float* __restrict__ y, size_t n, const double* __restrict__ stats3) {
     const double N = stats3[2], m = stats3[0] / N;
     const float mean = (float)m;
-    const float sd = sqrtf((float)((stats3[1] - N * m * m) / (N - 1.0)));
+    const double var = (stats3[1] - N * m * m) / (N - 1.0);     // one-pass form: a (near-)constant y can round a hair below zero -> clamp
+    const float sd = sqrtf((float)(var > 0.0 ? var : 0.0));         // (the two-pass form of MSR.py:136-137 gives exactly 0 there)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         y[i] = (y[i] - mean) / sd;
 }
@@ -1085,7 +1086,8 @@ __global__ __launch_bounds__(256) void k_renorm_apply(float* y, size_t n, const 
     for (int i = 0; i < kRedBlocks; ++i) { tot += part[i]; tot2 += part2[i]; }
     const double mean_d = tot / (double)n;
     const float mean = (float)mean_d;
-    const float sd = sqrtf((float)((tot2 - tot * mean_d) / (double)(n - 1)));      // unbiased, as torch.var (MSR.py:137)
+    const double var = (tot2 - tot * mean_d) / (double)(n - 1);                     // unbiased, as torch.var (MSR.py:137)
+    const float sd = sqrtf((float)(var > 0.0 ? var : 0.0));                        // clamp: see k_renorm_apply_stats
     const size_t n4 = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(rec)) & 15) ? 0 : n / 4;
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
     for (size_t i4 = t; i4 < n4; i4 += st) {

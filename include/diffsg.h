@@ -72,6 +72,9 @@ int dsg_set_renorm_hook(dsg_handle* h, double* stats3, void (*reduce)(void* user
  * 65504: the result would be silently wrong, not inf).  dsg_range_status synchronises the device, returns the flag in
  * *exceeded and clears it; on 1 the outputs since the last query are not to be trusted: rerun with DSG_PRECISION_F32_MFMA. */
 int dsg_range_status(dsg_handle* h, int* exceeded);
+/* The same query behind the work already enqueued on ONE stream: synchronises `stream` only (other streams of the device keep running;
+ * the default DDPM.sample() stalled every stream of the device once per call) and reads / clears the flag stream-ordered. */
+int dsg_range_status_stream(dsg_handle* h, int* exceeded, void* stream);
 
 /* Which FORM of the kernels a launch uses (same arithmetic per element, different work decomposition):
  *   coop_max_tiles          launches of at most this many 32-row tiles (both CFG passes counted) run the 64/128-wide
@@ -172,8 +175,10 @@ int dsg_train_profile_enable(dsg_handle* h, int on);
 int dsg_train_profile(dsg_handle* h, float* ms5);
 
 /* One Adam step (torch.optim.Adam, no amsgrad) over a flat float32 range: p, exp_avg, exp_avg_sq updated in place from g.  Element for
- * element the arithmetic of torch's fused kernel (ATen/native/cuda/fused_adam_utils.cuh), so the trajectory of the reference's optimizer
- * (classifier_free_MSR.py:209) is reproduced bit for bit; `step` is the update's number (1 for the first).  Replaces torch's
+ * element the arithmetic of torch's FUSED kernel (ATen/native/cuda/fused_adam_utils.cuh: moment updates in double), i.e. bit-identical to
+ * torch.optim.Adam(fused=True).  The reference constructs Adam with torch's default (foreach: float32 lerp / addcmul,
+ * classifier_free_MSR.py:213), which can differ from the fused form in the last bit of an update; the parity tests follow the reference's
+ * trajectory with a tolerance (three steps against CPU Adam).  `step` is the update's number (1 for the first).  Replaces torch's
  * multi_tensor_apply launch, which gives the 1.6 M-element flat parameter vector to 26 workgroups. */
 int dsg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
                   double weight_decay, int maximize, long long step, void* stream);

@@ -896,7 +896,8 @@ def test_train_step_large_launch_split_vs_exact_f32(B):
 
 def test_time_path_beside_the_last_weight_gradient_launch_gives_the_same_bits():
     """dsg_set_option(DSG_OPT_TRAIN_TIME_BESIDE): at the BASELINE training shape the time-path backward runs on the side stream beside
-    the last weight-gradient launch and delivers its results through slab 0 of the fixed-order reduce; loss and every gradient --
+    the last weight-gradient launch and writes its five results straight into the caller's bucket (the closing range-list reduce skips
+    those ranges); loss and every gradient --
     the TimeEmbedding's and the per-block time_emb Linears' included -- are bit-identical to the serial order, step after step."""
     name, B, T = "msr80", 32768 + 17, 20
     plan, p = synth_params(name, 13)
@@ -1493,3 +1494,30 @@ def test_tile_step_kernel_is_the_per_operator_launches_bit_for_bit(name, B, T):
     assert torch.equal(a, b) and torch.equal(a_eager, b)
     assert torch.equal(fa, fb)
     assert torch.equal(d.sample(cond, 1.5, seed=11), a)        # and back on
+
+
+def test_early_step_renorm_with_a_large_mean_to_std_ratio():
+    """the early-step renorm forms the variance in ONE float64 pass, (sum y^2 - n mean^2) / (n - 1), where the reference
+    subtracts the mean first (MSR.py:136-137).  A start state of mean 1e4 and unit spread (mean^2 / var = 1e8, where a float32 one-pass
+    form would return garbage) must standardise like the reference's two-pass form: finite, and equal to the oracle up to what float32
+    inputs of that size allow (their spacing is 1e-3 of the spread)."""
+    name, B, T = "msr3", 257, 5
+    plan, p = synth_params(name, 3)
+    cfg = CONFIGS[name]
+    d = make_ddpm(name, p, T)
+    g = torch.Generator().manual_seed(2)
+    D = cfg["input_dim"]
+    cond = torch.rand(B, cfg["cond_dim"], generator=g)
+    y_T = torch.randn(B, D, generator=g) + 1.0e4
+    z = torch.randn(max(T - 2, 0), B, D, generator=g)
+    got = d.sample(cond.cuda(), 1.0, y_T=y_T.cuda(), noise=z.cuda())
+    assert torch.isfinite(got).all()
+    bufs = O.schedule_buffers(1.0 - O.cosine_betas(T))
+    zd = {i: z[j] for j, i in enumerate(range(T - 1, 1, -1))}
+    with torch.no_grad():
+        ref = O.ddpm_sample(p, plan, bufs, T, cond, 1.0, y_T, zd)
+        ref64 = O.ddpm_sample({k: v.double() for k, v in p.items()}, plan, {k: v.double() for k, v in bufs.items()}, T, cond.double(), 1.0,
+                              y_T.double(), {i: v.double() for i, v in zd.items()})
+    e, budget = rel(got, ref64), rel(ref, ref64)
+    print(f"renorm at mean 1e4: rel err vs float64 {e:.2e} (the reference's own float32: {budget:.2e})")
+    assert e <= TOL + 3.0 * budget, (e, budget)
