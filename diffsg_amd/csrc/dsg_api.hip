@@ -109,7 +109,9 @@ struct Op {
 };
 
 // launches with fewer row tiles than this leave SIMDs idle with one wave per tile (dsg_set_launch_policy)
-constexpr int kCoopMaxTilesDefault = 512, kNarrowSmallMaxTilesDefault = 1024, kCoopMaxTilesTrain = 1024;
+// (narrow run: round 5 sweep, tools/policy_rows_ab.py -- at 1 536 / 2 048 tiles the small-launch form is 3-5 % of the step faster than the
+// large-launch form without the LDS image: 0.489 -> 0.477 and 0.503 -> 0.479 ms per step at 24 576 / 32 768 rows; the LDS-resident form takes over above)
+constexpr int kCoopMaxTilesDefault = 512, kNarrowSmallMaxTilesDefault = 2048, kCoopMaxTilesTrain = 1024;
 constexpr int kPanelMinTilesDefault = 2048;    // 256 CUs x 8 tiles: below this the persistent panel kernels leave CUs idle
 
 }  // namespace

@@ -81,7 +81,7 @@ int dsg_range_status_stream(dsg_handle* h, int* exceeded, void* stream);
  *                           blocks cooperatively (one tile per workgroup, N/32 waves) and never as block+Linear pair
  *                           kernels; larger launches run one wave per tile (weight planes shared through LDS) and pairs;
  *   narrow_small_max_tiles  launches of at most this many tiles use the small-launch form of the fused narrow run.
- * Defaults 512 / 1024; a negative value restores the default, 0 forces the large-launch forms at every size (the
+ * Defaults 512 / 2048; a negative value restores the default, 0 forces the large-launch forms at every size (the
  * parity tests run every golden both ways).  Cached step graphs are dropped when the policy changes. */
 int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_max_tiles);
 
