@@ -911,6 +911,8 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
             FusedOp& f = h->fused_host[i];
             memset(&f, 0, sizeof f);
             f.kind = kind; f.N = N; f.sclin = sclin; f.b = b; f.l = l;
+            // a link of the chain (bit 1): input handed over in registers; stored (bit 0) if something else reads it from memory
+            f.pad = 2 | ((h->tensors[op.out].is_skip || i == n - 1) ? 1 : 0);
         }
     }
     // the Linear behind the run (Upsample 32 -> 64 of the shipped nets): the LDS form of the run computes it from the registers of

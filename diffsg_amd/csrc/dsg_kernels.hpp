@@ -220,6 +220,29 @@ __device__ __forceinline__ void chain_from_acc(f32x16 (&out)[NT], const f32x16 (
     }
 }
 
+// Register-fed segment of a chain whose weights have tile stride `nt_stride` (stage 1 / shortcut of a block whose in0 is the narrow
+// run's running tensor, <= 32 wide: one accumulator tile): every load of the segment first, then LayerNorm + SiLU (LNACT) or the raw
+// values, group by group in the order chain_from_mem walks them -- same products, same order, same bits.
+template <int NT, bool LNACT>
+__device__ __forceinline__ void chain_from_reg(f32x16 (&out)[NT], const f32x16& in, int groups, const float* __restrict__ wp /* + lane*4 */,
+                                               size_t nt_stride, const float* __restrict__ gamma /* + 4h */, const float* __restrict__ beta,
+                                               float mean, float rstd) {
+    float4 w[4][NT], gm[4], bt[4];
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+        if (G < groups) {
+            load_wfrag<NT>(w[G], wp + (size_t)G * 256, nt_stride);
+            if (LNACT) { gm[G] = ld4(gamma + 8 * G); bt[G] = ld4(beta + 8 * G); }
+        }
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+        if (G < groups) {
+            float4 b = make_float4(in[4 * G], in[4 * G + 1], in[4 * G + 2], in[4 * G + 3]);
+            if (LNACT) b = ln_silu4(b, mean, rstd, gm[G], bt[G]);
+            mfma_group<NT>(out, w[G], b.x, b.y, b.z, b.w);
+        }
+}
+
 // A fragment-layout tensor in HBM.
 // Cycle stamps for measurement builds (-DDSG_CYCLE_STAMPS, tools/cycle_stamps.sh): (cycle counter << 16 | tag) appended to a device array by
 // lane 0 of the selected wave; dsg_stamps_fetch (dsg_api.hip) reads and clears it.  Compiled out otherwise.
@@ -325,9 +348,13 @@ __device__ __forceinline__ void globalize_params(BlockArgs& a) {
     a.W3 = as_global(a.W3); a.gamma3 = as_global(a.gamma3); a.beta3 = as_global(a.beta3); a.c3 = as_global(a.c3); a.Wsc = as_global(a.Wsc);
 }
 
-template <int N, bool SCLIN>
-__device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile, const int lane) {
+// XIN / XOUT (round 5, the exact path's narrow run): in0 is handed over in registers `xr` with its row statistics instead of read from
+// memory / the output is handed on the same way and stored only if `store_out` (a skip tensor, the run's last tensor).  N <= 32.
+template <int N, bool SCLIN, bool XIN = false, bool XOUT = false>
+__device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile, const int lane, f32x16* xr = nullptr, float* xr_mean = nullptr,
+                                              float* xr_m2 = nullptr, const bool store_out = true) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
+    static_assert(!(XIN || XOUT) || NT == 1, "register hand-over: one accumulator tile");
     const int h = lane >> 5, j = lane & 31;
     const int ptile = tile % a.tiles_per_pass;
     const int KG = a.in0.groups + a.in1.groups;
@@ -335,7 +362,9 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
     // ---- LN1 statistics from the producers' per-row (mean, M2), combined over the concat (Chan)
     float mean1, rstd1;
     {
-        const float2 s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
+        float2 s0;
+        if constexpr (XIN) s0 = make_float2(*xr_mean, *xr_m2);
+        else s0 = reinterpret_cast<const float2*>(a.in0.stats)[(size_t)tile * 32 + j];
         float mean = s0.x, m2 = s0.y, n = (float)a.in0.width;
         if (a.in1.groups) {
             const float2 s1 = reinterpret_cast<const float2*>(a.in1.stats)[(size_t)tile * 32 + j];
@@ -372,6 +401,8 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
     }
     {
         const size_t nt_stride = (size_t)KG * 256;
+        if constexpr (XIN) chain_from_reg<NT, true>(acc1, (*xr), a.in0.groups, a.W1 + lane * 4, nt_stride, a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
+        else
         chain_from_mem<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, a.W1 + lane * 4, nt_stride,
                                  a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
         if (a.in1.groups)
@@ -429,11 +460,19 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
     }
     if (SCLIN) {
         const size_t nt_stride = (size_t)KG * 256;
+        if constexpr (XIN) chain_from_reg<NT, false>(acc3, (*xr), a.in0.groups, a.Wsc + lane * 4, nt_stride, nullptr, nullptr, 0.f, 1.f);
+        else
         chain_from_mem<NT, false>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, a.Wsc + lane * 4, nt_stride,
                                   nullptr, nullptr, 0.f, 1.f);
         if (a.in1.groups)
             chain_from_mem<NT, false>(acc3, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                       a.Wsc + (size_t)a.in0.groups * 256 + lane * 4, nt_stride, nullptr, nullptr, 0.f, 1.f);
+    } else if constexpr (XIN) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G) {
+            acc3[0][4 * G + 0] += (*xr)[4 * G + 0]; acc3[0][4 * G + 1] += (*xr)[4 * G + 1];
+            acc3[0][4 * G + 2] += (*xr)[4 * G + 2]; acc3[0][4 * G + 3] += (*xr)[4 * G + 3];
+        }
     } else {
         const float* xp = a.in0.data + (size_t)tile * NG * 256 + lane * 4;
 #pragma unroll
@@ -448,12 +487,15 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
     {
         float mean, m2;
         acc_stats<N, NT>(acc3, h, mean, m2);
-        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
+        if constexpr (XOUT) { *xr = acc3[0]; *xr_mean = mean; *xr_m2 = m2; }
+        if (!XOUT || store_out) {
+            if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
 #pragma unroll
-        for (int G = 0; G < NG; ++G)
-            st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
-                make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2],
-                            acc3[G >> 2][4 * (G & 3) + 3]));
+            for (int G = 0; G < NG; ++G)
+                st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4,
+                    make_float4(acc3[G >> 2][4 * (G & 3)], acc3[G >> 2][4 * (G & 3) + 1], acc3[G >> 2][4 * (G & 3) + 2],
+                                acc3[G >> 2][4 * (G & 3) + 3]));
+        }
     }
 }
 
@@ -626,15 +668,85 @@ struct FusedOp {
     LinArgs l;
 };
 
+// Linear with register input (in width <= 32) and register output (out width <= 32): the exact path's in-run Down/Upsample
+__device__ __forceinline__ void linear_reg(const LinArgs& a, const int tile, const int lane, f32x16& x, float& xmean, float& xm2, const bool store_out) {
+    const int h = lane >> 5, j = lane & 31;
+    f32x16 acc[1];
+    acc_init<1>(acc, a.bias, h);
+    chain_from_reg<1, false>(acc, x, a.in_groups, a.W + lane * 4, (size_t)a.in_groups * 256, nullptr, nullptr, 0.f, 1.f);
+    const int NG = (a.out_width + 7) / 8;
+    float s = 0.f;
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (8 * G + 4 * h + p < a.out_width) s += acc[0][4 * G + p];
+    const float m = xhalf_sum(s) / (float)a.out_width;
+    float q = 0.f;
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (8 * G + 4 * h + p < a.out_width) { const float d = acc[0][4 * G + p] - m; q = fmaf(d, d, q); }
+    q = xhalf_sum(q);
+    x = acc[0]; xmean = m; xm2 = q;
+    if (store_out) {
+        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
+#pragma unroll
+        for (int G = 0; G < 4; ++G)
+            if (G < NG) st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4, make_float4(acc[0][4 * G], acc[0][4 * G + 1], acc[0][4 * G + 2], acc[0][4 * G + 3]));
+    }
+}
+
+// `pad` of an entry: bit 1 = the entry is a link of a CHAIN (the narrow run: its input is the previous entry's output, handed over in
+// registers; round 5 -- the round-1 form stored every tensor, drained its stores and re-read them: ~27 exposed round trips per tile),
+// bit 0 = store the output anyway (a skip tensor, the run's last tensor).  pad = 0: an independent operator, memory in, memory out
+// (the condition-embedding Linears of run_cond_embed share this kernel).
 __global__ __launch_bounds__(256, 4) void k_fused_narrow(const FusedOp* __restrict__ ops, int nops, int ntiles) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= ntiles) return;
+    f32x16 x;
+    float xmean = 0.f, xm2 = 0.f;
+    bool have_x = false;
+#pragma unroll 1
     for (int i = 0; i < nops; ++i) {
         const FusedOp& op = ops[i];
+        const bool chain = (op.pad & 2) != 0, st = (op.pad & 1) != 0;
         if (op.kind == 0) {
             BlockArgs b = op.b;               // every pointer of the record is global (as_global)
             globalize_io(b); globalize_params(b);
+            if (chain) {
+                if (!have_x) {                // first link: bring its (<= 32 wide) input into registers once
+                    const float2 s0 = reinterpret_cast<const float2*>(b.in0.stats)[(size_t)tile * 32 + j];
+                    xmean = s0.x; xm2 = s0.y;
+#pragma unroll
+                    for (int G = 0; G < 4; ++G) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (G < b.in0.groups) v = ld4(b.in0.data + ((size_t)tile * b.in0.groups + G) * 256 + lane * 4);
+                        x[4 * G] = v.x; x[4 * G + 1] = v.y; x[4 * G + 2] = v.z; x[4 * G + 3] = v.w;
+                    }
+                    have_x = true;
+                }
+                // skip tensors were stored by this wave earlier in the run: make sure those stores have landed
+                if (b.in1.groups) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (op.sclin) {
+                    switch (op.N) {
+                        case 4: resblock_body<4, true, true, true>(b, tile, lane, &x, &xmean, &xm2, st); break;
+                        case 8: resblock_body<8, true, true, true>(b, tile, lane, &x, &xmean, &xm2, st); break;
+                        case 16: resblock_body<16, true, true, true>(b, tile, lane, &x, &xmean, &xm2, st); break;
+                        default: resblock_body<32, true, true, true>(b, tile, lane, &x, &xmean, &xm2, st); break;
+                    }
+                } else {
+                    switch (op.N) {
+                        case 4: resblock_body<4, false, true, true>(b, tile, lane, &x, &xmean, &xm2, st); break;
+                        case 8: resblock_body<8, false, true, true>(b, tile, lane, &x, &xmean, &xm2, st); break;
+                        case 16: resblock_body<16, false, true, true>(b, tile, lane, &x, &xmean, &xm2, st); break;
+                        default: resblock_body<32, false, true, true>(b, tile, lane, &x, &xmean, &xm2, st); break;
+                    }
+                }
+                continue;
+            }
             if (op.sclin) {
                 switch (op.N) {
                     case 4: resblock_body<4, true>(b, tile, lane); break;
@@ -653,9 +765,25 @@ __global__ __launch_bounds__(256, 4) void k_fused_narrow(const FusedOp* __restri
         } else {
             LinArgs l = op.l;
             globalize_io(l); globalize_params(l);
+            if (chain && have_x && l.in_groups <= 4) { linear_reg(l, tile, lane, x, xmean, xm2, st); continue; }
             linear_body<1, IN_FRAG, OUT_FRAG, false>(l, tile, lane);
+            if (chain) {
+                // the Linear that enters the run (its input is wider than one tile): memory in, memory out, then reload
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int NG = (l.out_width + 7) / 8;
+                const float2 s0 = reinterpret_cast<const float2*>(l.out_stats)[(size_t)tile * 32 + j];
+                xmean = s0.x; xm2 = s0.y;
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (G < NG) v = ld4(l.out + ((size_t)tile * NG + G) * 256 + lane * 4);
+                    x[4 * G] = v.x; x[4 * G + 1] = v.y; x[4 * G + 2] = v.z; x[4 * G + 3] = v.w;
+                }
+                have_x = true;
+                continue;
+            }
         }
-        // the next operator of THIS wave reads what it just stored (same tile): drain the stores first
+        // the next operator of THIS wave may read what it just stored (same tile): drain the stores first
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }

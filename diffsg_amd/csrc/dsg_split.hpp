@@ -1692,8 +1692,14 @@ __global__ __launch_bounds__(256) void k_cond_embed_h(const float* __restrict__ 
             if (S < KS) { wh[S] = W[ot * ot_stride + (size_t)S * 128 + lane]; wl[S] = W[ot * ot_stride + (size_t)S * 128 + 64 + lane]; }
     };
     if (part < nout) loadw(part);
+    // the tile's record and the weight maximum behind its pointer are requested one output tile ahead as well (round 5: record ->
+    // pointer -> max|W| -> un-scale was a dependent chain of two round trips in front of every tile's stores)
+    CondTile ctn = tiles_tab[part < nout ? part : 0];
+    float mn = *as_global(ctn.m);
     for (int ot = part; ot < nout; ot += nparts) {
-        const CondTile ct = tiles_tab[ot];
+        const CondTile ct = ctn;
+        const float mcur = mn;
+        if (ot + nparts < nout) { ctn = tiles_tab[ot + nparts]; mn = *as_global(ctn.m); }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1706,8 +1712,8 @@ __global__ __launch_bounds__(256) void k_cond_embed_h(const float* __restrict__ 
                 DSG_MFMA_H(acc, wlo, bhi[S]);
             }
         if (ot + nparts < nout) loadw(ot + nparts);     // next tile's planes land under this tile's MFMAs and stores
-        const float inv = ldexpf(1.0f / kActScale, -scale_exp(*ct.m));
-        float* o = ct.out + (size_t)tile * ct.ng_block * 256 + lane * 4;
+        const float inv = ldexpf(1.0f / kActScale, -scale_exp(mcur));
+        float* o = as_global(ct.out) + (size_t)tile * ct.ng_block * 256 + lane * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (q < ct.groups) st4(o + (size_t)q * 256, make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv));
