@@ -365,6 +365,10 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int stride = gridDim.x;
+#ifdef DSG_CYCLE_STAMPS
+    // the clock the chip holds under THIS kernel: shader cycles (s_memtime) against the constant 100 MHz counter (s_memrealtime)
+    const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // Waves w and w + 4 share a SIMD.  Both run the same program (every panel's MFMA stream carries the operand preparation of
     // the next step between its MFMAs, panel_pipe_s); the younger half gets a static priority: at equal priority the older wave
     // of a SIMD wins every arbitration, finishes a panel ~1 400 cycles before its partner and idles at the barrier while the
@@ -760,7 +764,11 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     if (STAMPED && blockIdx.x == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int k = lane; k < 128; k += 64) dsg_stamp_buf[wave * 128 + k] = k < stamp_k ? stamp_lds[wave * 128 + k] : 0ull;
-        if (threadIdx.x == 0) dsg_stamp_n = kPW * 128;
+        if (threadIdx.x == 0) {
+            dsg_stamp_buf[kPW * 128 + 0] = clk_t0; dsg_stamp_buf[kPW * 128 + 1] = clk_r0;
+            dsg_stamp_buf[kPW * 128 + 2] = __builtin_readcyclecounter(); dsg_stamp_buf[kPW * 128 + 3] = __builtin_amdgcn_s_memrealtime();
+            dsg_stamp_n = kPW * 128 + 4;
+        }
     }
 #endif
 }

@@ -29,6 +29,10 @@ _lib.check(L.dsg_time_op(hd, names.index(op_name), B, 5, ctypes.byref(ms), _lib.
 torch.cuda.synchronize()
 n = L2.dsg_stamps_fetch(buf, 8192)
 print(f"{op_name}: {ms.value*1e3:.1f} us per launch; {n} stamp slots")
+if n >= 8 * 128 + 4:
+    t0, r0, t1, r1 = (buf[8 * 128 + k] for k in range(4))
+    if r1 > r0:
+        print(f"clock under this kernel (workgroup 0, whole launch): {t1 - t0} shader cycles in {(r1 - r0) * 10} ns = {(t1 - t0) / ((r1 - r0) * 10.0):.3f} GHz")
 for w in range(8):
     st = [(buf[w * 128 + k] >> 16, buf[w * 128 + k] & 0xffff) for k in range(128) if buf[w * 128 + k]]
     if not st:
