@@ -197,6 +197,7 @@ struct dsg_handle {
     FusedOpH* tileops_dev = nullptr;
     std::vector<FusedOpH> tileops_host;
     bool tile_valid = false, opt_tile = true;
+    bool opt_panel_half = false;      // dsg_set_option(DSG_OPT_PANEL_HALF): the 128-wide panel kernels with 16 KiB panels, two workgroups per CU
     FusedOpH* fusedh_train_dev = nullptr;   // the same run for the training forward (every output stored, h1/h2 saved)
     const void* fusedh_train_key[4] = {nullptr, nullptr, nullptr, nullptr}; int fusedh_train_rows = 0;
     // inference tables (dsg_sample / dsg_unet_forward / dsg_time_op share them): what the device copy was built for
@@ -699,6 +700,13 @@ bool panel128_ok(const dsg_handle* h, const ResP& r, const BlockArgs& b) {
 }
 template <bool SC, int EPI, int NTO>
 void launch_panel128(const dsg_handle* h, const BlockLinArgsH& w, hipStream_t s) {
+    if (h->opt_panel_half) {
+        // half-size panels, 4 waves per workgroup, two workgroups per CU (dsg_panel.hpp, STEPS = 2)
+        const int ngroups = cdiv(w.b.b.ntiles, 4);
+        const dim3 grid(ngroups < 2 * h->num_cus ? ngroups : 2 * h->num_cus), block(256);
+        hipLaunchKernelGGL((k_panel128_h<SC, EPI, NTO, 2>), grid, block, 0, s, w, ngroups);
+        return;
+    }
     const int ngroups = cdiv(w.b.b.ntiles, kPW);
     const dim3 grid(ngroups < h->num_cus ? ngroups : h->num_cus), block(kPW * 64);
     hipLaunchKernelGGL((k_panel128_h<SC, EPI, NTO>), grid, block, 0, s, w, ngroups);
@@ -2129,6 +2137,9 @@ int dsg_set_option(dsg_handle* h, int option, int value) {
             }
             return 0;
         case DSG_OPT_TRAIN_TIME_BESIDE: h->opt_time_beside = value != 0; return 0;
+        case DSG_OPT_PANEL_HALF:
+            if ((value != 0) != h->opt_panel_half) { (void)hipDeviceSynchronize(); free_graphs(h); h->opt_panel_half = value != 0; }
+            return 0;
         case DSG_OPT_TILE_STEP:
             if ((value != 0) != h->opt_tile) { (void)hipDeviceSynchronize(); free_graphs(h); h->opt_tile = value != 0; }
             return 0;

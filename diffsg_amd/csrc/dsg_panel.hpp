@@ -29,6 +29,13 @@ constexpr int kPrivSlots = 5;          // per wave
 constexpr int kPrivDist = 4;           // items in flight ahead of the consumer (four k16-steps: their items are requested during
                                        // the previous one); the slot refilled is the one read a step earlier
 constexpr int kPanelLdsU4 = 2 * kPanelU4 + kPW * kPrivSlots * kPrivU4 + kWideVec / 4;
+// Round 5: the same kernel with HALF-size panels (STEPS = 2 k16-steps x 4 out tiles x hi/lo = 16 KiB) and 4 waves per workgroup, TWO
+// workgroups per CU (79 KiB of LDS each).  Each workgroup streams its own panels (the L2 -> LDS weight traffic doubles) and has its own
+// barrier: the two waves that share a SIMD no longer run the block program in lock-step, so one workgroup's vector-only pieces (row
+// statistics, step 0 of a stage, un-scale, store: 15 - 40 % of a tile's life) can sit beside the other's MFMA panels.
+constexpr int panel_pw(int steps) { return 2 * steps; }                 // waves per workgroup
+constexpr int panel_u4(int steps) { return 512 * steps; }               // uint4 per weight panel
+constexpr int panel_lds_u4(int steps) { return 2 * panel_u4(steps) + panel_pw(steps) * kPrivSlots * kPrivU4 + kWideVec / 4; }
 
 // Measurement build (-DDSG_CYCLE_STAMPS): every wave of workgroup 0 keeps up to 128 (cycle, tag) stamps in LDS and dumps them at
 // the end of the launch (no global traffic inside the pipelined loop); tools/panel_stamps.py reads them.
@@ -95,9 +102,9 @@ struct TilePtrs {
     const char *st0, *st1;         // its row statistics
     bool cond;
 };
-template <bool SCLIN>
+template <bool SCLIN, int PW = kPW>
 __device__ __forceinline__ TilePtrs tile_ptrs(const BlockArgs& a, int g, int wave) {
-    const int traw = g * kPW + wave;
+    const int traw = g * PW + wave;
     const int tile = traw < a.ntiles ? traw : a.ntiles - 1;
     const int ptile = tile >= a.tiles_per_pass ? tile - a.tiles_per_pass : tile;      // at most two passes
     const int t0 = seg_tile(a.in0, tile), t1 = seg_tile(a.in1, tile);
@@ -202,7 +209,7 @@ constexpr int kPlaneAhead = 6;     // MFMA slots between a plane's read and its 
                                    // 8: 1 203, 10: 1 200 -- the LDS round trip is covered from 4 on, every two more cost four live registers)
 
 // slot k of a panel: term t = (k / 4) % 3 (hi*bhi, hi*blo, lo*bhi), out tile nt = k % 4, step s = k / 12
-__device__ __forceinline__ constexpr int slot_plane(int k) { return (((k % 4) * 4 + k / 12) * 2 + ((k / 4) % 3 == 2 ? 1 : 0)) * 64; }   // uint4 offset in the panel
+__device__ __forceinline__ constexpr int slot_plane(int k, int steps = 4) { return (((k % 4) * steps + k / 12) * 2 + ((k / 4) % 3 == 2 ? 1 : 0)) * 64; }   // uint4 offset in the panel
 
 // EPI: 0 = block only, 1 = + raw Linear (Down/Upsample), 2 = + final (LayerNorm + SiLU + Linear, row-major out)
 // ---- The MFMA stream of a panel WITH operand preparation between the MFMAs.  48 MFMA slots, 16 operand pairs (4 steps x 4 pairs
@@ -237,7 +244,7 @@ struct NextPrep {            // the operand prepared under step 3
     const float *pcc, *pdd;  // non-null: the constants are produced by consume_n() (next tile's row statistics), read them after it
 };
 enum { PIPE_NONE = 0 };
-template <bool FIRST, int PREP, int PREPN, typename Consume, typename ConsumeN>
+template <bool FIRST, int PREP, int PREPN, int STEPS = 4, typename Consume, typename ConsumeN>
 __device__ __forceinline__ void panel_pipe_s(f32x16 (&acc)[4], const uint4* pn /* + lane */, const BOp& b0, BOp& bcarry, const f32x16 (&in)[4], int S0,
                                              const float* gamma, const float* beta, float cc, float dd, int h, Consume&& consume, const NextPrep nx,
                                              ConsumeN&& consume_n) {
@@ -248,29 +255,32 @@ __device__ __forceinline__ void panel_pipe_s(f32x16 (&acc)[4], const uint4* pn /
     lds_cf4* const bl = (lds_cf4*)(beta + 4 * h);
     lds_cf4* const gln = (lds_cf4*)(nx.gamma + 4 * h);
     lds_cf4* const bln = (lds_cf4*)(nx.beta + 4 * h);
-    uint4 pl[48];
+    constexpr int NSLOT = 12 * STEPS, NJ = STEPS - 1;     // MFMA slots of the panel; prepared steps of THIS panel (the last prepared one is the carry)
+    uint4 pl[NSLOT];
     float cpin = cc, cpinn = nx.cc, ddn = nx.dd, u0 = 0.f, u1 = 0.f, p0 = 0.f, p1 = 0.f, v0 = 0.f, v1 = 0.f;
-    f32x4 gq[8], bq[8], xq[8];                       // per HALF step (two pairs) of the PREPARED steps: LayerNorm vectors, input values
-    float hq[17], lq[17];                            // results (bit patterns of half pairs); [16] is a dummy pin for the first statement
-    lds_cf4* slot[4];                                // private slot of each of the four prepared steps (+ lane)
-    hq[16] = 0.f; lq[16] = 0.f;
+    f32x4 gq[2 * STEPS], bq[2 * STEPS], xq[2 * STEPS];   // per HALF step (two pairs) of the PREPARED steps: LayerNorm vectors, input values
+    float hq[4 * STEPS + 1], lq[4 * STEPS + 1];      // results (bit patterns of half pairs); the last is a dummy pin for the first statement
+    lds_cf4* slot[STEPS];                            // private slot of each of the prepared steps (+ lane)
+    hq[4 * STEPS] = 0.f; lq[4 * STEPS] = 0.f;
     // prepared step j (0..2: this panel's step j + 1; 3: the carry)
-    auto has = [&](int j) { return j < 3 || HASN; };
-    auto is_ln = [&](int j) { return j < 3 ? LN_I : LN_N; };
-    auto is_mem = [&](int j) { return j < 3 ? MEM_I : MEM_N; };
+    auto has = [&](int j) { return j < NJ || HASN; };
+    auto is_ln = [&](int j) { return j < NJ ? LN_I : LN_N; };
+    auto is_mem = [&](int j) { return j < NJ ? MEM_I : MEM_N; };
     auto load_vec = [&](int hs) {                    // half step hs = 2 * j + (0: values 0-3, 1: values 4-7)
         const int j = hs >> 1;
-        if (j < 3) { const int S = S0 + 1 + j; gq[hs] = gl[4 * S + 2 * (hs & 1)]; bq[hs] = bl[4 * S + 2 * (hs & 1)]; }
+        if (j < NJ) { const int S = S0 + 1 + j; gq[hs] = gl[4 * S + 2 * (hs & 1)]; bq[hs] = bl[4 * S + 2 * (hs & 1)]; }
         else { gq[hs] = gln[4 * nx.S + 2 * (hs & 1)]; bq[hs] = bln[4 * nx.S + 2 * (hs & 1)]; }
     };
     auto load_x = [&](int hs) { xq[hs] = slot[hs >> 1][(hs & 1) * 64]; };
 #pragma unroll
     for (int k = 0; k < kPlaneAhead; ++k)
-        if ((k / 4) % 3 != 1) pl[k] = pn[slot_plane(k)];
-    if (MEM_I) { slot[0] = (lds_cf4*)consume(0); load_x(0); }
-    if (LN_I) load_vec(0);
+        if ((k / 4) % 3 != 1) pl[k] = pn[slot_plane(k, STEPS)];
+    if (NJ > 0) {
+        if (MEM_I) { slot[0] = (lds_cf4*)consume(0); load_x(0); }
+        if (LN_I) load_vec(0);
+    }
 #pragma unroll
-    for (int k = 0; k < 48; ++k) {
+    for (int k = 0; k < NSLOT; ++k) {
         const int s = k / 12, t = (k / 4) % 3, nt = k % 4;
         const int kp = t == 1 ? k - 4 : k;
         // operand of this step: step 0 arrives, the others were prepared under the step before
@@ -282,25 +292,25 @@ __device__ __forceinline__ void panel_pipe_s(f32x16 (&acc)[4], const uint4* pn /
             bh = __builtin_bit_cast(h8, hv); blo_ = __builtin_bit_cast(h8, lv);
         }
         const h8 bb = t == 1 ? blo_ : bh;
-        const int m = k / 3, ph = k % 3, mp = m == 0 ? 16 : m - 1, j = m >> 2;
+        const int m = k / 3, ph = k % 3, mp = m == 0 ? 4 * STEPS : m - 1, j = m >> 2;
         // private item of the next prepared step: six slots before its first piece
-        if (k % 12 == 6 && k / 12 < 3) {
+        if (k % 12 == 6 && k / 12 < NJ) {
             const int jn = k / 12 + 1;
-            if (jn < 3) { if (MEM_I) slot[jn] = (lds_cf4*)consume(jn); }
+            if (jn < NJ) { if (MEM_I) slot[jn] = (lds_cf4*)consume(jn); }
             else if (MEM_N) {
-                slot[3] = (lds_cf4*)consume_n();
+                slot[NJ] = (lds_cf4*)consume_n();
                 if (nx.pcc) { cpinn = *nx.pcc; ddn = *nx.pdd; }
             }
         }
         // the statement: MFMA k; pins = what flows from the piece behind the previous MFMA into the piece behind this one
-        float& cp = j < 3 ? cpin : cpinn;
+        float& cp = j < NJ ? cpin : cpinn;
         if (ph == 0) { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, cp, hq[mp], lq[mp], v0); else mfma_pin(acc[nt], pl[kp], bb, cp, hq[mp], lq[mp], v0); }
         else if (ph == 1) { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, u0, u1, p0, p1); else mfma_pin(acc[nt], pl[kp], bb, u0, u1, p0, p1); }
         else { if (FIRST && k < 4) mfma_pin0(acc[nt], pl[kp], bb, v0, v1, u0, u1); else mfma_pin(acc[nt], pl[kp], bb, v0, v1, u0, u1); }
         // loads of later slots: planes kPlaneAhead slots ahead; vectors / values of the next half step at the first pair of this one
         const int kn = k + kPlaneAhead;
-        if (kn < 48 && (kn / 4) % 3 != 1) pl[kn] = pn[slot_plane(kn)];
-        if (ph == 0 && (m & 1) == 0 && m / 2 + 1 < 8) {
+        if (kn < NSLOT && (kn / 4) % 3 != 1) pl[kn] = pn[slot_plane(kn, STEPS)];
+        if (ph == 0 && (m & 1) == 0 && m / 2 + 1 < 2 * STEPS) {
             const int hn = m / 2 + 1, jn = hn >> 1;
             if (has(jn)) {
                 if (is_ln(jn)) load_vec(hn);
@@ -310,10 +320,10 @@ __device__ __forceinline__ void panel_pipe_s(f32x16 (&acc)[4], const uint4* pn /
         // the piece behind MFMA k: pair q of prepared step j
         if (!has(j)) continue;
         const bool LN = is_ln(j), MEM = is_mem(j);
-        const int S = j < 3 ? S0 + 1 + j : nx.S, q = m & 3, tt = (S >> 1) & 3, r0 = 8 * (S & 1) + 2 * q, hs = m >> 1, e = 2 * (m & 1);
-        const float dcur = j < 3 ? dd : ddn;
+        const int S = j < NJ ? S0 + 1 + j : nx.S, q = m & 3, tt = (S >> 1) & 3, r0 = 8 * (S & 1) + 2 * q, hs = m >> 1, e = 2 * (m & 1);
+        const float dcur = j < NJ ? dd : ddn;
         if (ph == 0) {
-            const float x0 = MEM ? xq[hs][e] : (j < 3 ? in[tt][r0] : (*nx.in)[tt][r0]), x1 = MEM ? xq[hs][e + 1] : (j < 3 ? in[tt][r0 + 1] : (*nx.in)[tt][r0 + 1]);
+            const float x0 = MEM ? xq[hs][e] : (j < NJ ? in[tt][r0] : (*nx.in)[tt][r0]), x1 = MEM ? xq[hs][e + 1] : (j < NJ ? in[tt][r0 + 1] : (*nx.in)[tt][r0 + 1]);
             if (LN) {
                 u0 = fmaf(fmaf(x0, cp, dcur), gq[hs][e], bq[hs][e]);
                 u1 = fmaf(fmaf(x1, cp, dcur), gq[hs][e + 1], bq[hs][e + 1]);
@@ -334,8 +344,9 @@ __device__ __forceinline__ void panel_pipe_s(f32x16 (&acc)[4], const uint4* pn /
     }
     if (HASN) {
         // the last piece's results are complete here
-        asm volatile("" : "+v"(hq[15]), "+v"(lq[15]));
-        const f32x4 hv = {hq[12], hq[13], hq[14], hq[15]}, lv = {lq[12], lq[13], lq[14], lq[15]};
+        constexpr int L0 = 4 * NJ;
+        asm volatile("" : "+v"(hq[L0 + 3]), "+v"(lq[L0 + 3]));
+        const f32x4 hv = {hq[L0], hq[L0 + 1], hq[L0 + 2], hq[L0 + 3]}, lv = {lq[L0], lq[L0 + 1], lq[L0 + 2], lq[L0 + 3]};
         bcarry.hi = __builtin_bit_cast(h8, hv); bcarry.lo = __builtin_bit_cast(h8, lv);
     }
 }
@@ -343,20 +354,21 @@ __device__ __forceinline__ void panel_pipe_s(f32x16 (&acc)[4], const uint4* pn /
 #ifndef DSG_PANEL_TRAIL_PRIO
 #define DSG_PANEL_TRAIL_PRIO 1
 #endif
-template <bool SCLIN, int EPI, int NTO>
-__global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, const int ngroups) {
+template <bool SCLIN, int EPI, int NTO, int STEPS = 4>
+__global__ __launch_bounds__(64 * panel_pw(STEPS), 2) void k_panel128_h(const BlockLinArgsH A, const int ngroups) {
     constexpr int N = 128, NT = 4, NG = 16;
-    constexpr int KS1 = SCLIN ? 16 : 8, P1 = KS1 / 4, NE = SCLIN ? 16 : 8;   // k16-steps of stage 1; items of the shortcut / residual read
-    constexpr int NTOP = NTO <= 1 ? 1 : (NTO == 2 ? 2 : 4), ESTEPS = 16 / NTOP;    // epilogue Linear: k16-steps per panel (8 needed)
-    constexpr int EPANELS = EPI == 0 ? 0 : (ESTEPS >= 8 ? 1 : 2);
-    constexpr int PA = P1, PB = PA + 2, PD = PB + 2, PE = PD + (SCLIN ? P1 : 0), NP = PE + EPANELS;
-    __shared__ uint4 lds[kPanelLdsU4 + kPanelStampU4];
+    constexpr int PW = panel_pw(STEPS), PU4 = panel_u4(STEPS), NTHR = 64 * PW;
+    constexpr int KS1 = SCLIN ? 16 : 8, P1 = KS1 / STEPS, P2 = 8 / STEPS, NE = SCLIN ? 16 : 8;   // k16-steps of stage 1; items of the shortcut / residual read
+    constexpr int NTOP = NTO <= 1 ? 1 : (NTO == 2 ? 2 : 4), ESTEPS = 4 * STEPS / NTOP;    // epilogue Linear: k16-steps per panel (8 needed)
+    constexpr int EPANELS = EPI == 0 ? 0 : (ESTEPS >= 8 ? 1 : 8 / ESTEPS);
+    constexpr int PA = P1, PB = PA + P2, PD = PB + P2, PE = PD + (SCLIN ? P1 : 0), NP = PE + EPANELS;
+    __shared__ uint4 lds[panel_lds_u4(STEPS) + (STEPS == 4 ? kPanelStampU4 : 0)];
 #ifdef DSG_CYCLE_STAMPS
-    unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + kPanelLdsU4);
+    unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + panel_lds_u4(STEPS));
     int stamp_k = 0;
-    constexpr bool STAMPED = SCLIN && EPI == 0;
+    constexpr bool STAMPED = SCLIN && EPI == 0 && STEPS == 4;
 #endif
-    float* const vec = reinterpret_cast<float*>(lds + 2 * kPanelU4 + kPW * kPrivSlots * kPrivU4);
+    float* const vec = reinterpret_cast<float*>(lds + 2 * PU4 + PW * kPrivSlots * kPrivU4);
     float* const g1v = vec, * const b1v = vec + kLnLdsW1, * const v2 = vec + 2 * kLnLdsW1;
     float* const g2v = v2, * const b2v = v2 + 128, * const g3v = v2 + 256, * const b3v = v2 + 384, * const tbv = v2 + 512, * const c2v = v2 + 640,
          * const c3v = v2 + 768, * const gLv = v2 + 896, * const bLv = v2 + 1024, * const biasLv = v2 + 1152;
@@ -373,14 +385,15 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     // the next step between its MFMAs, panel_pipe_s); the younger half gets a static priority: at equal priority the older wave
     // of a SIMD wins every arbitration, finishes a panel ~1 400 cycles before its partner and idles at the barrier while the
     // partner runs alone (cycle stamps: 3 000 against 4 400 cycles per LayerNorm panel).  MI355X guide, "two waves per SIMD".
+    // (STEPS = 2: the workgroup has one wave per SIMD; its SIMD partners belong to the CU's other workgroup)
     const bool lead = wave < 4;
-    if (!lead) __builtin_amdgcn_s_setprio(DSG_PANEL_TRAIL_PRIO);
+    if (STEPS == 4 && !lead) __builtin_amdgcn_s_setprio(DSG_PANEL_TRAIL_PRIO);
     constexpr float kL2 = -1.44269504088896341f;
 
     // ---- per-feature vectors -> LDS, once per launch (LayerNorm vectors times -log2 e)
     {
         const int n1 = ln1_extent(a);
-        for (int i = threadIdx.x; i < n1; i += 512) { g1v[i] = a.gamma1[i] * kL2; b1v[i] = a.beta1[i] * kL2; }
+        for (int i = threadIdx.x; i < n1; i += NTHR) { g1v[i] = a.gamma1[i] * kL2; b1v[i] = a.beta1[i] * kL2; }
         if (threadIdx.x < 128) {
             const int i = threadIdx.x;
             g2v[i] = a.gamma2[i] * kL2; b2v[i] = a.beta2[i] * kL2; g3v[i] = a.gamma3[i] * kL2; b3v[i] = a.beta3[i] * kL2;
@@ -395,8 +408,8 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     if (EPI != 0) invL = A.l.kc[EPI == 2 ? 1 : 0];
     __syncthreads();                   // no DMA is in flight yet: a plain barrier
 
-    // ---- this wave's 4 KiB of every weight panel: (out tile, half of its four k16-steps)
-    const int wnt = wave >> 1, wsub = wave & 1;
+    // ---- this wave's 4 KiB of every weight panel: (out tile, two of its STEPS k16-steps)
+    const int wnt = wave / (STEPS / 2), wsub = wave % (STEPS / 2);
     const uint4* const w1p = ah.W1h + ((size_t)wnt * KS1) * 128 + wsub * 256;
     const uint4* const w2p = ah.W2h + ((size_t)wnt * 8) * 128 + wsub * 256;
     const uint4* const w3p = ah.W3h + ((size_t)wnt * 8) * 128 + wsub * 256;
@@ -405,16 +418,16 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     if (EPI != 0) {
         // NTOP = 4: as the block's panels (tiles >= NTO reload tile 0); 2: (tile, quarter of its 8 steps); 1: quarter of tile 0
         if (NTOP == 4) wlp = A.l.Wh + ((size_t)(wnt < NTO ? wnt : 0) * 8) * 128 + wsub * 256;
-        else if (NTOP == 2) wlp = A.l.Wh + ((size_t)(wave >> 2) * 8) * 128 + (wave & 3) * 256;
+        else if (NTOP == 2) wlp = A.l.Wh + ((size_t)(wave / STEPS) * 8) * 128 + (wave % STEPS) * 256;
         else wlp = A.l.Wh + (wave & 3) * 256;
     }
     // panel p of the block program (compile-time p at every call site): the weights do not depend on the tile
     auto panel_src = [&](int p) -> const uint4* {
-        if (p < PA) return w1p + (size_t)p * 512;
-        if (p < PB) return w2p + (size_t)(p - PA) * 512;
-        if (p < PD) return w3p + (size_t)(p - PB) * 512;
-        if (p < PE) return wsp + (size_t)(p - PD) * 512;
-        return wlp + (NTOP == 4 ? (size_t)(p - PE) * 512 : 0);
+        if (p < PA) return w1p + (size_t)p * (128 * STEPS);
+        if (p < PB) return w2p + (size_t)(p - PA) * (128 * STEPS);
+        if (p < PD) return w3p + (size_t)(p - PB) * (128 * STEPS);
+        if (p < PE) return wsp + (size_t)(p - PD) * (128 * STEPS);
+        return wlp + (ESTEPS < 8 ? (size_t)(p - PE) * (128 * ESTEPS) : 0);
     };
 
     const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds;
@@ -422,14 +435,14 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     c.lane16 = (unsigned)lane * 16u; c.lane4 = (unsigned)lane * 4u;
     c.w_lds = lds0 + (unsigned)wave * 4096u;
     c.w_rd = lds0 + (unsigned)lane * 16u;
-    c.p_lds = lds0 + 2u * kPanelU4 * 16u + (unsigned)wave * (kPrivSlots * 2048u);
+    c.p_lds = lds0 + 2u * PU4 * 16u + (unsigned)wave * (kPrivSlots * 2048u);
     c.wrd = lds + lane;
-    c.prd = lds + 2 * kPanelU4 + wave * (kPrivSlots * kPrivU4) + lane;
+    c.prd = lds + 2 * PU4 + wave * (kPrivSlots * kPrivU4) + lane;
     c.q = 0; c.islot = 0; c.cslot = 0;
 
     // prologue: panel 0 into buffer 0 and the first four private items of this wave's first tile
     {
-        const TilePtrs cur = tile_ptrs<SCLIN>(a, blockIdx.x < ngroups ? blockIdx.x : 0, wave);
+        const TilePtrs cur = tile_ptrs<SCLIN, PW>(a, blockIdx.x < ngroups ? blockIdx.x : 0, wave);
         priv_issue_stats(c, cur.st0, cur.st1);
         priv_issue(c, cur.x0);
         priv_issue(c, cur.x0 + 2048);
@@ -440,14 +453,20 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     // One barrier per panel: my pieces of the panel have landed (counted wait: `since_w` DMA operations of the private stream
     // went out behind them); everyone is done with the other buffer; refill that one with the panel after this (`next`: the block
     // program repeats for the next tile group; the request behind the launch's last panel is redundant and drained at the end).
-    int since_w = 8;                   // the four private requests of the prologue
+    // DMA operations of the private stream issued BEHIND the pending panel's own four.  (Rounds 2-4 started this at 8 for "the four
+    // private requests of the prologue" -- but those go out IN FRONT of panel 0, so the first panel of a launch was waited for with
+    // vmcnt(8) while it could be among the eight youngest operations: nothing ordered its arrival before the first reads.  It never
+    // showed with one workgroup per CU -- panel 0 is requested a statistics merge and an operand preparation ahead -- and did within
+    // minutes with two (round 5, the STEPS = 2 form: a handful of first-group tiles wrong, run-to-run different).)
+    int since_w = 0;
     auto panel_begin = [&](int next) -> int {
         if (since_w >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (STEPS < 4 && since_w >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // half panels: two items per panel
         else if (since_w >= 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int rd = c.q & 1;
-        glds_quad_s(c.lane16, panel_src(next), c.w_lds + (unsigned)((c.q + 1) & 1) * (kPanelU4 * 16u));
+        glds_quad_s(c.lane16, panel_src(next), c.w_lds + (unsigned)((c.q + 1) & 1) * (PU4 * 16u));
         since_w = 0;
         ++c.q;
         return rd;
@@ -463,13 +482,13 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
     BOp bcar;
     float cc_car = 0.f, dd_car = 0.f;
     for (int g = blockIdx.x; g < ngroups; g += stride) {
-        const int tile_raw = g * kPW + wave;
+        const int tile_raw = g * PW + wave;
         const bool live = tile_raw < a.ntiles;          // idle waves of the last group still move their pieces and meet the barriers
         const int tile = live ? tile_raw : a.ntiles - 1;
         const int ptile = tile >= a.tiles_per_pass ? tile - a.tiles_per_pass : tile;
-        const TilePtrs cur = tile_ptrs<SCLIN>(a, g, wave);
+        const TilePtrs cur = tile_ptrs<SCLIN, PW>(a, g, wave);
         const bool my_cond = cur.cond;
-        const TilePtrs nxt = tile_ptrs<SCLIN>(a, g + stride < ngroups ? g + stride : g, wave);
+        const TilePtrs nxt = tile_ptrs<SCLIN, PW>(a, g + stride < ngroups ? g + stride : g, wave);
         DSG_PSTAMP(0x01);
         // the item four places behind position `T` of the part that follows stage 1: condition embedding (conditional tiles),
         // then the shortcut / residual input, then the next tile's statistics and first steps
@@ -542,16 +561,16 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
                 const int bi = panel_begin(p + 1);
                 DSG_PSTAMP(0x14);
                 BOp bc;
-                const NextPrep nx{&acc1, 4 * (p + 1), g1v, b1v, cc, dd, nullptr, nullptr};
-                auto cs = [&](int jj) { return consume_s1(4 * p + 1 + jj); };
-                auto cn = [&]() { return consume_s1(4 * p + 4); };
+                const NextPrep nx{&acc1, STEPS * (p + 1), g1v, b1v, cc, dd, nullptr, nullptr};
+                auto cs = [&](int jj) { return consume_s1(STEPS * p + 1 + jj); };
+                auto cn = [&]() { return consume_s1(STEPS * p + STEPS); };
                 if (p + 1 < P1) {
-                    if (p == 0) panel_pipe_s<true, PIPE_LN, PIPE_LN>(acc1, c.wrd + bi * kPanelU4, b0, bc, acc1, 4 * p, g1v, b1v, cc, dd, h, cs, nx, cn);
-                    else panel_pipe_s<false, PIPE_LN, PIPE_LN>(acc1, c.wrd + bi * kPanelU4, b0, bc, acc1, 4 * p, g1v, b1v, cc, dd, h, cs, nx, cn);
+                    if (p == 0) panel_pipe_s<true, PIPE_LN, PIPE_LN, STEPS>(acc1, c.wrd + bi * PU4, b0, bc, acc1, STEPS * p, g1v, b1v, cc, dd, h, cs, nx, cn);
+                    else panel_pipe_s<false, PIPE_LN, PIPE_LN, STEPS>(acc1, c.wrd + bi * PU4, b0, bc, acc1, STEPS * p, g1v, b1v, cc, dd, h, cs, nx, cn);
                     b0 = bc;
                 } else {
-                    if (p == 0) panel_pipe_s<true, PIPE_LN, PIPE_NONE>(acc1, c.wrd + bi * kPanelU4, b0, bc, acc1, 4 * p, g1v, b1v, cc, dd, h, cs, nx, none_n);
-                    else panel_pipe_s<false, PIPE_LN, PIPE_NONE>(acc1, c.wrd + bi * kPanelU4, b0, bc, acc1, 4 * p, g1v, b1v, cc, dd, h, cs, nx, none_n);
+                    if (p == 0) panel_pipe_s<true, PIPE_LN, PIPE_NONE, STEPS>(acc1, c.wrd + bi * PU4, b0, bc, acc1, STEPS * p, g1v, b1v, cc, dd, h, cs, nx, none_n);
+                    else panel_pipe_s<false, PIPE_LN, PIPE_NONE, STEPS>(acc1, c.wrd + bi * PU4, b0, bc, acc1, STEPS * p, g1v, b1v, cc, dd, h, cs, nx, none_n);
                 }
                 DSG_PSTAMP(0x12);
             }
@@ -566,19 +585,24 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             acc_stats<N, NT>(acc1, h, mean, m2);
             const float rstd = rsqrtf(m2 * (1.0f / N) + kLnEps), cc = rstd, dd = -mean * rstd;
             DSG_PSTAMP(0x20);
-            BOp b0 = step0_reg(acc1, g2v, b2v, cc, dd), bc, bd;
+            BOp b0 = step0_reg(acc1, g2v, b2v, cc, dd), bc;
             asm volatile("" : "+v"(b0.hi), "+v"(b0.lo));
             DSG_PSTAMP(0x21);
-            int bi = panel_begin(PA + 1);
-            DSG_PSTAMP(0x24);
-            panel_pipe_s<true, PIPE_REG, PIPE_REG>(acc2, c.wrd + bi * kPanelU4, b0, bc, acc1, 0, g2v, b2v, cc, dd, h, no_consume,
-                                                   NextPrep{&acc1, 4, g2v, b2v, cc, dd, nullptr, nullptr}, none_n);
-            DSG_PSTAMP(0x22);
-            bi = panel_begin(PB);
-            DSG_PSTAMP(0x24);
-            panel_pipe_s<false, PIPE_REG, PIPE_NONE>(acc2, c.wrd + bi * kPanelU4, bc, bd, acc1, 4, g2v, b2v, cc, dd, h, no_consume,
-                                                     NextPrep{&acc1, 0, g2v, b2v, cc, dd, nullptr, nullptr}, none_n);
-            DSG_PSTAMP(0x22);
+#pragma unroll
+            for (int p = 0; p < P2; ++p) {           // 8 k16-steps in P2 panels
+                const int bi = panel_begin(PA + p + 1);
+                DSG_PSTAMP(0x24);
+                const NextPrep nx{&acc1, STEPS * (p + 1 < P2 ? p + 1 : 0), g2v, b2v, cc, dd, nullptr, nullptr};
+                if (p + 1 < P2) {
+                    if (p == 0) panel_pipe_s<true, PIPE_REG, PIPE_REG, STEPS>(acc2, c.wrd + bi * PU4, b0, bc, acc1, STEPS * p, g2v, b2v, cc, dd, h, no_consume, nx, none_n);
+                    else panel_pipe_s<false, PIPE_REG, PIPE_REG, STEPS>(acc2, c.wrd + bi * PU4, b0, bc, acc1, STEPS * p, g2v, b2v, cc, dd, h, no_consume, nx, none_n);
+                    b0 = bc;
+                } else {
+                    if (p == 0) panel_pipe_s<true, PIPE_REG, PIPE_NONE, STEPS>(acc2, c.wrd + bi * PU4, b0, bc, acc1, STEPS * p, g2v, b2v, cc, dd, h, no_consume, nx, none_n);
+                    else panel_pipe_s<false, PIPE_REG, PIPE_NONE, STEPS>(acc2, c.wrd + bi * PU4, b0, bc, acc1, STEPS * p, g2v, b2v, cc, dd, h, no_consume, nx, none_n);
+                }
+                DSG_PSTAMP(0x22);
+            }
             acc_unscale_add_lds<NT>(acc2, inv2, c2v, h);
         }
         if (my_cond) {                 // condition embedding of this tile: 8 private items, one accumulator tile per two
@@ -610,47 +634,55 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             BOp b0 = step0_reg(acc2, g3v, b3v, cc, dd), bc, bsc;
             asm volatile("" : "+v"(b0.hi), "+v"(b0.lo));
             DSG_PSTAMP(0x31);
-            int bi = panel_begin(PB + 1);
-            DSG_PSTAMP(0x34);
-            panel_pipe_s<true, PIPE_REG, PIPE_REG>(acc3, c.wrd + bi * kPanelU4, b0, bc, acc2, 0, g3v, b3v, cc, dd, h, no_consume,
-                                                   NextPrep{&acc2, 4, g3v, b3v, cc, dd, nullptr, nullptr}, none_n);
-            DSG_PSTAMP(0x32);
+            int bi = 0;
+#pragma unroll
+            for (int p = 0; p + 1 < P2; ++p) {       // every panel of the stage but its last
+                bi = panel_begin(PB + p + 1);
+                DSG_PSTAMP(0x34);
+                const NextPrep nx{&acc2, STEPS * (p + 1), g3v, b3v, cc, dd, nullptr, nullptr};
+                if (p == 0) panel_pipe_s<true, PIPE_REG, PIPE_REG, STEPS>(acc3, c.wrd + bi * PU4, b0, bc, acc2, STEPS * p, g3v, b3v, cc, dd, h, no_consume, nx, none_n);
+                else panel_pipe_s<false, PIPE_REG, PIPE_REG, STEPS>(acc3, c.wrd + bi * PU4, b0, bc, acc2, STEPS * p, g3v, b3v, cc, dd, h, no_consume, nx, none_n);
+                b0 = bc;
+                DSG_PSTAMP(0x32);
+            }
+            bc = b0;                                 // operand of the stage's last panel
+            constexpr int SL = 8 - STEPS;            // its first k16-step
             bi = panel_begin((PD) % NP);
             DSG_PSTAMP(0x34);
             if (SCLIN) {
                 const NextPrep raw{&acc2, 0, g3v, b3v, 1.f, 0.f, nullptr, nullptr};
-                panel_pipe_s<false, PIPE_REG, PIPE_RAW>(acc3, c.wrd + bi * kPanelU4, bc, bsc, acc2, 4, g3v, b3v, cc, dd, h, no_consume, raw,
-                                                        [&]() { return consume_sc(0); });
+                panel_pipe_s<false, PIPE_REG, PIPE_RAW, STEPS>(acc3, c.wrd + bi * PU4, bc, bsc, acc2, SL, g3v, b3v, cc, dd, h, no_consume, raw,
+                                                               [&]() { return consume_sc(0); });
                 DSG_PSTAMP(0x32);
 #pragma unroll
                 for (int p = 0; p < P1; ++p) {
                     bi = panel_begin((PD + p + 1) % NP);
                     DSG_PSTAMP(0x44);
                     BOp bn;
-                    auto cs = [&](int jj) { return consume_sc(4 * p + 1 + jj); };
+                    auto cs = [&](int jj) { return consume_sc(STEPS * p + 1 + jj); };
                     if (p + 1 < P1) {
-                        panel_pipe_s<false, PIPE_RAW, PIPE_RAW>(acc3, c.wrd + bi * kPanelU4, bsc, bn, acc3, 4 * p, g3v, b3v, 1.f, 0.f, h, cs, raw,
-                                                                [&]() { return consume_sc(4 * p + 4); });
+                        panel_pipe_s<false, PIPE_RAW, PIPE_RAW, STEPS>(acc3, c.wrd + bi * PU4, bsc, bn, acc3, STEPS * p, g3v, b3v, 1.f, 0.f, h, cs, raw,
+                                                                       [&]() { return consume_sc(STEPS * p + STEPS); });
                         bsc = bn;
                     } else if (XT) {
                         // the coming tile (the same one again behind the workgroup's last group: its requests are in flight either way): its
                         // row statistics, then its first stage-1 operand under this panel's last step
                         const NextPrep nt1{&acc3, 0, g1v, b1v, 0.f, 0.f, &cc_car, &dd_car};
-                        panel_pipe_s<false, PIPE_RAW, PIPE_LN>(acc3, c.wrd + bi * kPanelU4, bsc, bcar, acc3, 4 * p, g3v, b3v, 1.f, 0.f, h, cs, nt1, [&]() {
+                        panel_pipe_s<false, PIPE_RAW, PIPE_LN, STEPS>(acc3, c.wrd + bi * PU4, bsc, bcar, acc3, STEPS * p, g3v, b3v, 1.f, 0.f, h, cs, nt1, [&]() {
                             ln1_stats(nxt, cc_car, dd_car);
                             const uint4* rd = priv_consume(c);
                             priv_issue(c, xin(nxt, 4)); since_w += 2;
                             return rd;
                         });
                     } else {
-                        panel_pipe_s<false, PIPE_RAW, PIPE_NONE>(acc3, c.wrd + bi * kPanelU4, bsc, bn, acc3, 4 * p, g3v, b3v, 1.f, 0.f, h, cs, raw, none_n);
+                        panel_pipe_s<false, PIPE_RAW, PIPE_NONE, STEPS>(acc3, c.wrd + bi * PU4, bsc, bn, acc3, STEPS * p, g3v, b3v, 1.f, 0.f, h, cs, raw, none_n);
                     }
                     DSG_PSTAMP(0x42);
                 }
                 acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
             } else {
-                panel_pipe_s<false, PIPE_REG, PIPE_NONE>(acc3, c.wrd + bi * kPanelU4, bc, bsc, acc2, 4, g3v, b3v, cc, dd, h, no_consume,
-                                                         NextPrep{&acc2, 0, g3v, b3v, cc, dd, nullptr, nullptr}, none_n);
+                panel_pipe_s<false, PIPE_REG, PIPE_NONE, STEPS>(acc3, c.wrd + bi * PU4, bc, bsc, acc2, SL, g3v, b3v, cc, dd, h, no_consume,
+                                                                NextPrep{&acc2, 0, g3v, b3v, cc, dd, nullptr, nullptr}, none_n);
                 DSG_PSTAMP(0x32);
                 acc_unscale_add_lds<NT>(acc3, inv3, c3v, h);
 #pragma unroll
@@ -692,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void k_panel128_h(const BlockLinArgsH A, co
             const uint4* pn = nullptr;
 #pragma unroll
             for (int S = 0; S < 8; ++S) {
-                if (S % ESTEPS == 0) pn = c.wrd + panel_begin((PE + S / ESTEPS + 1) % NP) * kPanelU4;
+                if (S % ESTEPS == 0) pn = c.wrd + panel_begin((PE + S / ESTEPS + 1) % NP) * PU4;
                 const int sl = S % ESTEPS, t = S >> 1, r0 = 8 * (S & 1);
                 HFrag<NTO> w;
                 panel_wfrag<NTO>(w, pn, ESTEPS, sl);

@@ -1521,3 +1521,24 @@ def test_early_step_renorm_with_a_large_mean_to_std_ratio():
     e, budget = rel(got, ref64), rel(ref, ref64)
     print(f"renorm at mean 1e4: rel err vs float64 {e:.2e} (the reference's own float32: {budget:.2e})")
     assert e <= TOL + 3.0 * budget, (e, budget)
+
+
+def test_half_panel_form_of_the_128_wide_kernels_is_bit_identical():
+    """dsg_set_option(DSG_OPT_PANEL_HALF): the persistent 128-wide kernels with 16 KiB weight panels and two independent 4-wave
+    workgroups per CU (csrc/dsg_panel.hpp, STEPS = 2; round 5's test of "the eight waves' lock-step is what the kernel loses": it is not,
+    +0.3 %) compute every element in the order of the default form: bit-identical results at the bench shape, run to run as well.  The
+    form is what exposed the first-panel wait of rounds 2-4 (`since_w` counted the prologue's requests as issued behind panel 0): with
+    two workgroups per CU a handful of first-group tiles came out wrong, differently every run."""
+    import bench
+    dev = torch.device("cuda:0")
+    B, T = 65536 + 32 * 3, 3
+    ddpm = bench.build_model(dev, T)
+    cond = torch.rand(B, 80, generator=torch.Generator().manual_seed(4)).to(dev)
+    ref = ddpm.sample(cond, 1.0, seed=7)
+    ddpm.model.set_option("panel_half", 1)
+    try:
+        for _ in range(3):
+            assert torch.equal(ddpm.sample(cond, 1.0, seed=7), ref)
+    finally:
+        ddpm.model.set_option("panel_half", 0)
+    assert torch.equal(ddpm.sample(cond, 1.0, seed=7), ref)
