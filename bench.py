@@ -414,8 +414,8 @@ def main():
             step_bytes = (tj.get("step_traffic") or {}).get("bytes_per_step")
             tsrc = "imported, not measured in this run: profiles/traffic.json <- " + tj.get("summary", "profiles/") + " (kernel " + tj.get("kernel", "?") + ")"
         large = 2 * ((B + 31) // 32) > 512
-        panel = 2 * ((B + 31) // 32) >= 2048
-        kname = (("k_panel128_h<linear-shortcut> (persistent, 8 tiles per workgroup, weight panels through LDS, operand preparation "
+        panel = 2 * ((B + 31) // 32) >= 768
+        kname = (("k_panel128_h<linear-shortcut, half panels> (persistent, two 4-wave workgroups per CU, 16 KiB weight panels through LDS, operand preparation "
                   "interleaved with the MFMA stream)" if panel else
                   "k_wide128_h<linear-shortcut> (4 tiles per workgroup, weight planes through an LDS ring)") if large
                  else "k_resblock_c<128,linear-shortcut>") if split else "k_resblock<128,linear-shortcut>"

@@ -112,7 +112,11 @@ struct Op {
 // (narrow run: round 5 sweep, tools/policy_rows_ab.py -- at 1 536 / 2 048 tiles the small-launch form is 3-5 % of the step faster than the
 // large-launch form without the LDS image: 0.489 -> 0.477 and 0.503 -> 0.479 ms per step at 24 576 / 32 768 rows; the LDS-resident form takes over above)
 constexpr int kCoopMaxTilesDefault = 512, kNarrowSmallMaxTilesDefault = 2048, kCoopMaxTilesTrain = 1024;
-constexpr int kPanelMinTilesDefault = 2048;    // 256 CUs x 8 tiles: below this the persistent panel kernels leave CUs idle
+// Persistent LDS-weight kernels (dsg_panel.hpp, dsg_res64.hpp) from this many row tiles on.  Rounds 3-4: 2 048 = 256 CUs x 8 tiles.  Round 5
+// (tools/mid_batch_ab.py, same box): with the half-panel form (4-tile groups, two workgroups per CU) they beat the mid-size forms from 768
+// tiles on -- 12 288 rows 0.339 -> 0.302 ms per step, 16 384: 0.356 -> 0.346, 24 576: 0.483 -> 0.454, 49 152 (3 072 tiles, where 8-tile
+// groups left the second round half empty): 0.721 -> 0.674.
+constexpr int kPanelMinTilesDefault = 768;
 
 }  // namespace
 
@@ -197,7 +201,7 @@ struct dsg_handle {
     FusedOpH* tileops_dev = nullptr;
     std::vector<FusedOpH> tileops_host;
     bool tile_valid = false, opt_tile = true;
-    bool opt_panel_half = false;      // dsg_set_option(DSG_OPT_PANEL_HALF): the 128-wide panel kernels with 16 KiB panels, two workgroups per CU
+    bool opt_panel_half = true;       // dsg_set_option(DSG_OPT_PANEL_HALF): the 128-wide panel kernels with 16 KiB panels, two workgroups per CU
     FusedOpH* fusedh_train_dev = nullptr;   // the same run for the training forward (every output stored, h1/h2 saved)
     const void* fusedh_train_key[4] = {nullptr, nullptr, nullptr, nullptr}; int fusedh_train_rows = 0;
     // inference tables (dsg_sample / dsg_unet_forward / dsg_time_op share them): what the device copy was built for

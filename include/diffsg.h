@@ -99,10 +99,10 @@ int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_ma
  *                          feature_proj + ONE launch that carries every row tile through all the other operators (csrc/dsg_tile.hpp;
  *                          UNetCF.py:318-356 has no cross-row operation); 0: one launch per operator / fused run, as larger launches.
  *                          Same arithmetic per operator, bit-identical results.  Cached step graphs are dropped when the value changes.
- *   DSG_OPT_PANEL_HALF     0 (default) / 1: the persistent 128-wide kernels of large sampling launches with half-size weight panels and
+ *   DSG_OPT_PANEL_HALF     1 (default) / 0: the persistent 128-wide kernels of large sampling launches with half-size weight panels and
  *                          4-wave workgroups, two per CU, each streaming its own panels (csrc/dsg_panel.hpp, STEPS = 2): the two waves of a
  *                          SIMD then belong to different workgroups and no longer run the block program in lock-step.  Same arithmetic and
- *                          accumulation order per element: bit-identical results (round 5 experiment; measured in DESIGN.md 3.4). */
+ *                          accumulation order per element: bit-identical results; +0.3..0.9 % at 65 536 rows, 3-11 % at 12 288 - 49 152 rows. */
 enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2, DSG_OPT_WGRAD_NARROW_PART = 4, DSG_OPT_TILE_STEP = 8, DSG_OPT_PANEL_HALF = 16 };
 int dsg_set_option(dsg_handle* h, int option, int value);
 

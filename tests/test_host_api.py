@@ -176,7 +176,8 @@ def test_trajectory_writers_fail_loudly_without_gpu(tmp_path):
 # none of them may use scratch memory (a spilled register is a vector-memory round trip inside the inner loop).
 SAMPLING_STEP_KERNELS = [
     "dsg::k_linear_h<4, 1, 0, false>",          # feature_proj
-    "dsg::k_panel128_h<false, 0, 1>", "dsg::k_panel128_h<false, 1, 2>", "dsg::k_panel128_h<true, 0, 1>", "dsg::k_panel128_h<true, 2, 3>",
+    "dsg::k_panel128_h<false, 0, 1, 2>", "dsg::k_panel128_h<false, 1, 2, 2>", "dsg::k_panel128_h<true, 0, 1, 2>", "dsg::k_panel128_h<true, 2, 3, 2>",
+    "dsg::k_panel128_h<false, 0, 1, 4>", "dsg::k_panel128_h<false, 1, 2, 4>", "dsg::k_panel128_h<true, 0, 1, 4>", "dsg::k_panel128_h<true, 2, 3, 4>",
     "dsg::k_res64_dual", "dsg::k_res64_lds<true, 0>", "dsg::k_res64_lds<true, 4>",
     "dsg::k_fused_narrow_lds<2>", "dsg::k_fused_narrow_lds<3>", "dsg::k_fused_narrow_lds<0>",
     "dsg::k_update", "dsg::k_renorm_sum", "dsg::k_renorm_apply",

@@ -10,6 +10,6 @@ for B in 65536 131072 262144; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w$B -- python3 tools/prof_op.py up.17.res $B 10 > $OUT/w$B.log 2>&1
   python3 tools/prof_op.py up.17.res $B 20 > $OUT/t$B.log 2>&1
   echo "== B=$B"; tail -1 $OUT/t$B.log
-  python3 tools/pmc_summary.py $OUT/f$B "k_panel128_h<true, 0, 1>"; python3 tools/pmc_summary.py $OUT/w$B "k_panel128_h<true, 0, 1>"
+  python3 tools/pmc_summary.py $OUT/f$B "k_panel128_h<true, 0, 1, 2>"; python3 tools/pmc_summary.py $OUT/w$B "k_panel128_h<true, 0, 1, 2>"
 done > $OUT/summary.txt 2>&1
 rm -rf $OUT/f65536 $OUT/f131072 $OUT/f262144 $OUT/w65536 $OUT/w131072 $OUT/w262144
