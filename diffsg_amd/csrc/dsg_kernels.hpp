@@ -103,25 +103,107 @@ __device__ __forceinline__ void chain_from_mem(f32x16 (&acc)[NT], const float* _
                                                size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float mean, float rstd) {
     if (groups <= 0) return;
-    float4 wn[NT], xn, gmn = make_float4(0.f, 0.f, 0.f, 0.f), btn = gmn;
-    load_wfrag<NT>(wn, wp, nt_stride);
-    xn = ld4(xp);
-    if (LNACT) { gmn = ld4(gamma); btn = ld4(beta); }
-    for (int g = 0; g < groups; ++g) {
-        float4 wc[NT];
+    if constexpr (NT == 1) {
+        // one accumulator tile (the narrow run, <= 4 groups per tensor): "current" and "next" sets, copied every group -- 16 moves per
+        // group, but the fused narrow kernel has no registers for two full sets (the ping-pong form below spilled there)
+        float4 wn[NT], xn, gmn = make_float4(0.f, 0.f, 0.f, 0.f), btn = gmn;
+        load_wfrag<NT>(wn, wp, nt_stride);
+        xn = ld4(xp);
+        if (LNACT) { gmn = ld4(gamma); btn = ld4(beta); }
+        for (int g = 0; g < groups; ++g) {
+            float4 wc[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
-        float4 xv = xn;
-        const float4 gm = gmn, bt = btn;
-        if (g + 1 < groups) {
-            load_wfrag<NT>(wn, wp + (size_t)(g + 1) * 256, nt_stride);
-            xn = ld4(xp + (size_t)(g + 1) * 256);
-            if (LNACT) { gmn = ld4(gamma + 8 * (g + 1)); btn = ld4(beta + 8 * (g + 1)); }
+            for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
+            float4 xv = xn;
+            const float4 gm = gmn, bt = btn;
+            if (g + 1 < groups) {
+                load_wfrag<NT>(wn, wp + (size_t)(g + 1) * 256, nt_stride);
+                xn = ld4(xp + (size_t)(g + 1) * 256);
+                if (LNACT) { gmn = ld4(gamma + 8 * (g + 1)); btn = ld4(beta + 8 * (g + 1)); }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs (hipcc otherwise sinks it)
+            if (LNACT) xv = ln_silu4(xv, mean, rstd, gm, bt);
+            mfma_group<NT>(acc, wc, xv.x, xv.y, xv.z, xv.w);
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs (hipcc otherwise sinks it)
-        if (LNACT) xv = ln_silu4(xv, mean, rstd, gm, bt);
-        mfma_group<NT>(acc, wc, xv.x, xv.y, xv.z, xv.w);
+        return;
     }
+    // Two operand sets, the loop unrolled by two: each set is loaded and consumed in the same registers (ping-pong).  The round-1
+    // form kept "current" and "next" sets and copied next -> current every group: 28 register moves per group at NT = 4 -- and hipcc
+    // copied them back at the loop end -- more instructions than a raw group's arithmetic (round 5, disassembly).
+    float4 w0[NT], w1[NT], x0, x1, gm0 = make_float4(0.f, 0.f, 0.f, 0.f), bt0 = gm0, gm1 = gm0, bt1 = gm0;
+    load_wfrag<NT>(w0, wp, nt_stride);
+    x0 = ld4(xp);
+    if (LNACT) { gm0 = ld4(gamma); bt0 = ld4(beta); }
+    int g = 0;
+    for (; g + 1 < groups; g += 2) {
+        load_wfrag<NT>(w1, wp + (size_t)(g + 1) * 256, nt_stride);
+        x1 = ld4(xp + (size_t)(g + 1) * 256);
+        if (LNACT) { gm1 = ld4(gamma + 8 * (g + 1)); bt1 = ld4(beta + 8 * (g + 1)); }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs (hipcc otherwise sinks it)
+        {
+            float4 xv = x0;
+            if (LNACT) xv = ln_silu4(xv, mean, rstd, gm0, bt0);
+            mfma_group<NT>(acc, w0, xv.x, xv.y, xv.z, xv.w);
+        }
+        if (g + 2 < groups) {
+            load_wfrag<NT>(w0, wp + (size_t)(g + 2) * 256, nt_stride);
+            x0 = ld4(xp + (size_t)(g + 2) * 256);
+            if (LNACT) { gm0 = ld4(gamma + 8 * (g + 2)); bt0 = ld4(beta + 8 * (g + 2)); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            float4 xv = x1;
+            if (LNACT) xv = ln_silu4(xv, mean, rstd, gm1, bt1);
+            mfma_group<NT>(acc, w1, xv.x, xv.y, xv.z, xv.w);
+        }
+    }
+    if (g < groups) {                       // odd count: the last group sits in set 0
+        float4 xv = x0;
+        if (LNACT) xv = ln_silu4(xv, mean, rstd, gm0, bt0);
+        mfma_group<NT>(acc, w0, xv.x, xv.y, xv.z, xv.w);
+    }
+}
+
+// The same chain with the group count known at compile time (the >= 64-wide blocks: N / 8 groups per input tensor), fully unrolled:
+// the D + 1 operand sets are compile-time slots, so the prefetch rotates by renaming.  As a runtime loop hipcc rotated them with
+// register moves -- 56 v_mov_b32 per group, twice the LayerNorm + SiLU arithmetic of a raw group -- and waited for the NEXT group's
+// loads a third of the way into the current group's MFMAs (round 5, disassembly of k_resblock<128, true>: 3 600 moves per tile).
+// Same products in the same order as chain_from_mem: same bits.
+template <int NT, bool LNACT, int GROUPS, int D = 1>
+__device__ __forceinline__ void chain_from_mem_fixed(f32x16 (&acc)[NT], const float* __restrict__ xp, const float* __restrict__ wp,
+                                                     size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float mean, float rstd) {
+    float4 wb[D + 1][NT], xb[D + 1], gb[D + 1], bb[D + 1];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < GROUPS) {
+            load_wfrag<NT>(wb[d], wp + (size_t)d * 256, nt_stride);
+            xb[d] = ld4(xp + (size_t)d * 256);
+            if (LNACT) { gb[d] = ld4(gamma + 8 * d); bb[d] = ld4(beta + 8 * d); }
+        }
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        if (g + D < GROUPS) {
+            constexpr int M = D + 1;
+            const int s = (g + D) % M;
+            load_wfrag<NT>(wb[s], wp + (size_t)(g + D) * 256, nt_stride);
+            xb[s] = ld4(xp + (size_t)(g + D) * 256);
+            if (LNACT) { gb[s] = ld4(gamma + 8 * (g + D)); bb[s] = ld4(beta + 8 * (g + D)); }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs
+        float4 xv = xb[g % (D + 1)];
+        if (LNACT) xv = ln_silu4(xv, mean, rstd, gb[g % (D + 1)], bb[g % (D + 1)]);
+        mfma_group<NT>(acc, wb[g % (D + 1)], xv.x, xv.y, xv.z, xv.w);
+    }
+}
+// FIX > 0: the caller has checked that the tensor has exactly FIX groups (k_resblock picks the body per launch: a check in here
+// made hipcc join the two forms' accumulators with 32 - 64 register moves behind every chain)
+template <int NT, bool LNACT, int FIX>
+__device__ __forceinline__ void chain_from_mem_n(f32x16 (&acc)[NT], const float* __restrict__ xp, int groups, const float* __restrict__ wp,
+                                                 size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float mean, float rstd) {
+    if constexpr (FIX > 0) chain_from_mem_fixed<NT, LNACT, FIX>(acc, xp, wp, nt_stride, gamma, beta, mean, rstd);
+    else chain_from_mem<NT, LNACT>(acc, xp, groups, wp, nt_stride, gamma, beta, mean, rstd);
 }
 
 // acc <- per-feature vector (padded to NT*32 floats) in accumulator order.
@@ -350,10 +432,11 @@ __device__ __forceinline__ void globalize_params(BlockArgs& a) {
 
 // XIN / XOUT (round 5, the exact path's narrow run): in0 is handed over in registers `xr` with its row statistics instead of read from
 // memory / the output is handed on the same way and stored only if `store_out` (a skip tensor, the run's last tensor).  N <= 32.
-template <int N, bool SCLIN, bool XIN = false, bool XOUT = false>
+template <int N, bool SCLIN, bool XIN = false, bool XOUT = false, bool FIXED = false>
 __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile, const int lane, f32x16* xr = nullptr, float* xr_mean = nullptr,
                                               float* xr_m2 = nullptr, const bool store_out = true) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
+    constexpr int FIXG = FIXED ? N / 8 : 0;        // FIXED: in0 (and in1 of a concat) have exactly N / 8 groups (chain_from_mem_fixed)
     static_assert(!(XIN || XOUT) || NT == 1, "register hand-over: one accumulator tile");
     const int h = lane >> 5, j = lane & 31;
     const int ptile = tile % a.tiles_per_pass;
@@ -403,10 +486,10 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
         const size_t nt_stride = (size_t)KG * 256;
         if constexpr (XIN) chain_from_reg<NT, true>(acc1, (*xr), a.in0.groups, a.W1 + lane * 4, nt_stride, a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
         else
-        chain_from_mem<NT, true>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, a.W1 + lane * 4, nt_stride,
+        chain_from_mem_n<NT, true, FIXG>(acc1, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, a.W1 + lane * 4, nt_stride,
                                  a.gamma1 + 4 * h, a.beta1 + 4 * h, mean1, rstd1);
         if (a.in1.groups)
-            chain_from_mem<NT, true>(acc1, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
+            chain_from_mem_n<NT, true, FIXG>(acc1, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                      a.W1 + (size_t)a.in0.groups * 256 + lane * 4, nt_stride, a.gamma1 + 8 * a.in0.groups + 4 * h,
                                      a.beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1);
     }
@@ -462,10 +545,10 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
         const size_t nt_stride = (size_t)KG * 256;
         if constexpr (XIN) chain_from_reg<NT, false>(acc3, (*xr), a.in0.groups, a.Wsc + lane * 4, nt_stride, nullptr, nullptr, 0.f, 1.f);
         else
-        chain_from_mem<NT, false>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, a.Wsc + lane * 4, nt_stride,
+        chain_from_mem_n<NT, false, FIXG>(acc3, a.in0.data + (size_t)tile * a.in0.groups * 256 + lane * 4, a.in0.groups, a.Wsc + lane * 4, nt_stride,
                                   nullptr, nullptr, 0.f, 1.f);
         if (a.in1.groups)
-            chain_from_mem<NT, false>(acc3, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
+            chain_from_mem_n<NT, false, FIXG>(acc3, a.in1.data + (size_t)tile * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                       a.Wsc + (size_t)a.in0.groups * 256 + lane * 4, nt_stride, nullptr, nullptr, 0.f, 1.f);
     } else if constexpr (XIN) {
 #pragma unroll
@@ -499,13 +582,16 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
     }
 }
 
-template <int N, bool SCLIN>
-__global__ __launch_bounds__(256) void k_resblock(const BlockArgs a) {   // (bounded to 2 waves per SIMD hipcc keeps the accumulators in
-                                                                         // plain registers: measured 7 % slower at N = 128, round 5)
+// FIXED (chosen by the host, launch_res): in0 -- and in1 of a concat -- have exactly N / 8 groups, as in every shipped net: the unrolled
+// chains.  A kernel of its own per form: both bodies in one kernel cost the larger register count for both and spills at N = 64.
+// Waves per SIMD: the unrolled chains leave hipcc free to take 332 / 192 registers at N = 128 / 64 -- one / two waves per SIMD where
+// the runtime-loop form runs two / four; bounded to what that form has.
+template <int N, bool SCLIN, bool FIXED = false>
+__global__ __launch_bounds__(256, !FIXED ? 1 : (N >= 128 ? 2 : 4)) void k_resblock(const BlockArgs a) {
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.ntiles) return;
-    resblock_body<N, SCLIN>(a, tile, lane);
+    resblock_body<N, SCLIN, false, false, FIXED>(a, tile, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -571,6 +657,7 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, const int tile, co
         const bool vec4 = (a.in_width & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in_rm) & 15) == 0;
         const bool rowok = row < a.nrows;
         const float* rp = a.in_rm + (size_t)(rowok ? row : 0) * a.in_width;
+        // (weights one group ahead in ping-pong sets, as chain_from_mem, measured SLOWER here: feature_proj 40.4 -> 45.4 us at 65 536 rows)
         float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
         if (vec4 && rowok && 4 * h < a.in_width) xn = ld4(rp + 4 * h);
         for (int g = 0; g < KG; ++g) {
@@ -703,6 +790,8 @@ __device__ __forceinline__ void linear_reg(const LinArgs& a, const int tile, con
 // bit 0 = store the output anyway (a skip tensor, the run's last tensor).  pad = 0: an independent operator, memory in, memory out
 // (the condition-embedding Linears of run_cond_embed share this kernel).
 __global__ __launch_bounds__(256, 4) void k_fused_narrow(const FusedOp* __restrict__ ops, int nops, int ntiles) {
+    // (36 bytes of scratch per lane: 8 spilled registers under the 128-register bound.  The opaque-lane-per-operator construction that
+    // freed k_fused_narrow_lds of its spills makes it worse here -- 79 scratch instructions against 40, round 5.)
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= ntiles) return;

@@ -194,9 +194,15 @@ OTHER_HOT_KERNELS = [
     "dsg::k_resblock_h<128, true>", "dsg::k_resblock_h<128, false>", "dsg::k_wide128_h<false, 1, 2>", "dsg::k_wide128_h<true, 2, 3>",
     "dsg::k_linear_h<4, 0, 0, false>", "dsg::k_linear_h<2, 0, 0, false>", "dsg::k_linear_h<3, 0, 1, true>",
 ]
+# the exact-float32 reverse step at the bench size: the unrolled-chain forms of the wide blocks and the plain Linears
+F32_STEP_KERNELS = [
+    "dsg::k_resblock<128, true, true>", "dsg::k_resblock<128, false, true>", "dsg::k_resblock<64, true, true>", "dsg::k_resblock<64, false, true>",
+    "dsg::k_linear<4, 1, 0, false>", "dsg::k_linear<3, 0, 1, true>", "dsg::k_linear<2, 0, 0, false>", "dsg::k_linear<4, 0, 0, false>",
+]
 # kernels that MAY keep a few bytes of scratch (stated, bounded): the whole-net tile kernel is the union of every small-launch body under
 # one 256-register budget (two workgroups per CU); what it spills is reloaded once per operator, not inside a loop
-BOUNDED_SCRATCH_KERNELS = {"dsg::k_unet_tile<2>": 32, "dsg::k_unet_tile<3>": 32, "dsg::k_unet_tile<0>": 32}
+BOUNDED_SCRATCH_KERNELS = {"dsg::k_unet_tile<2>": 32, "dsg::k_unet_tile<3>": 32, "dsg::k_unet_tile<0>": 32,
+                           "dsg::k_fused_narrow": 36}      # the exact path's narrow run: 8 spilled registers under its 128-register bound
 
 
 TABLE_DRIVEN_KERNELS = ["k_fused_narrow_lds", "k_fused_narrow_h", "k_fused_narrow_bwd_h", "k_wgrad_h", "k_wgrad", "k_colsum", "k_fused_narrow"]
@@ -234,7 +240,7 @@ def test_table_driven_kernels_issue_no_flat_memory_instructions(tmp_path):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("group", ["sampling_step", "other_hot"])
+@pytest.mark.parametrize("group", ["sampling_step", "other_hot", "f32_step"])
 def test_hot_kernels_use_no_scratch_memory(group):
     """Compiled with -Rpass-analysis=kernel-resource-usage (diffsg_amd/_lib.build keeps hipcc's remarks beside the library): every
     kernel of the bench-size reverse step, and the large kernels of the training step / the other launch forms, report
@@ -242,7 +248,7 @@ def test_hot_kernels_use_no_scratch_memory(group):
     from diffsg_amd import _lib
     _lib.build()
     res = _lib.kernel_resources()
-    names = SAMPLING_STEP_KERNELS if group == "sampling_step" else OTHER_HOT_KERNELS
+    names = {"sampling_step": SAMPLING_STEP_KERNELS, "other_hot": OTHER_HOT_KERNELS, "f32_step": F32_STEP_KERNELS}[group]
     missing = [n for n in names if n not in res]
     assert not missing, f"kernels not in the build record (renamed?): {missing}"
     spilled = {n: res[n]["scratch"] for n in names if res[n]["scratch"] != 0}
