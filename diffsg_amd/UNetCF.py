@@ -333,8 +333,9 @@ class UNet1D(nn.Module):
         unit in float32 inside large sampling launches (default on); "train_time_beside" -- the time-path backward of large
         training steps on the side stream beside the last weight-gradient launch (default on); "wgrad_narrow_part" -- the narrow
         run's weight gradients as a third early part (default off); "tile_step" -- small launches run a denoiser pass as feature_proj + one
-        launch that walks every operator per row tile (default on; csrc/dsg_tile.hpp)."""
-        code = {"narrow_valu8": 1, "train_time_beside": 2, "wgrad_narrow_part": 4, "tile_step": 8, "panel_half": 16}[name]
+        launch that walks every operator per row tile (default on; csrc/dsg_tile.hpp); "panel_half" -- half-size weight panels in the
+        persistent 128-wide kernels (default on); "f32_pair" -- exact path: a wide block and its consuming Linear in one launch (default on)."""
+        code = {"narrow_valu8": 1, "train_time_beside": 2, "wgrad_narrow_part": 4, "tile_step": 8, "panel_half": 16, "f32_pair": 32}[name]
         for hd in self._all_handles():
             _lib.check(_lib.lib().dsg_set_option(hd, code, int(value)))
         self.__dict__.setdefault("_settings", {}).setdefault("options", {})[code] = int(value)

@@ -219,6 +219,7 @@ struct dsg_handle {
     // in float32 by the LDS form of the narrow run (dsg_narrow8.hpp); opt_v8: dsg_set_option(DSG_OPT_NARROW_VALU8)
     int v8_lo = -1, v8_hi = -1;
     bool opt_v8 = true;
+    bool opt_f32_pair = true;          // exact path: block + consuming Linear in one launch (k_resblock_lin); DSG_OPT_F32_PAIR
     bool opt_time_beside = true;       // dsg_set_option(DSG_OPT_TRAIN_TIME_BESIDE): see the tail of dsg_train_step
     bool opt_wg_narrow_part = false;   // dsg_set_option(DSG_OPT_WGRAD_NARROW_PART); read when the descriptor tables are (re)built
     // the section's image in global memory (V8SecL layout: raw nn.Linear matrices and parameter vectors), gathered at every bind; the LDS
@@ -1195,6 +1196,34 @@ bool try_pair(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
     return launch_res_lin_h(h, r, ba, h->lin[b.p], la, b.kind == OP_FINAL, h->tensors[a.out].is_skip, s);
 }
 
+// exact path: the same pairs (k_resblock_lin, dsg_kernels.hpp) when both input tensors of the block have N / 8 groups
+bool try_pair_f32(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
+    if (split_ctx(h, c) || c.train || !h->opt_f32_pair || i + 1 >= (int)h->ops.size()) return false;
+    const Op& a = h->ops[i];
+    const Op& b = h->ops[i + 1];
+    if (a.kind != OP_RES || (b.kind != OP_LIN && b.kind != OP_FINAL) || b.in0 != a.out) return false;
+    const bool fuse = h->fuse_hi - h->fuse_lo >= 2;
+    if (fuse && i + 1 >= h->fuse_lo && i < h->fuse_hi) return false;
+    const ResP& r = h->res[a.p];
+    if (r.N < 64) return false;
+    BlockArgs ba; LinArgs la;
+    fill_block_args(h, a, c, ba);
+    fill_lin_args(h, b, c, la);
+    if (ba.in0.groups != r.N / 8 || ba.in1.groups != (r.sclin ? r.N / 8 : 0) || la.in_groups != r.N / 8) return false;
+    const bool fin = b.kind == OP_FINAL;
+    const int NTO = cdiv(h->lin[b.p].l.N, 32), store = h->tensors[a.out].is_skip ? 1 : 0;
+    const dim3 grid(cdiv(ba.ntiles, kWavesPerBlock)), block(256);
+#define DSG_TRYF(N_, SC_, NTO_, FIN_)                                                                        \
+    if (r.N == N_ && r.sclin == SC_ && NTO == NTO_ && fin == FIN_) {                                         \
+        hipLaunchKernelGGL((k_resblock_lin<N_, SC_, NTO_, FIN_>), grid, block, 0, s, ba, la, store);         \
+        return true;                                                                                         \
+    }
+    DSG_TRYF(128, false, 2, false) DSG_TRYF(64, true, 4, false) DSG_TRYF(128, true, 3, true) DSG_TRYF(128, true, 1, true)
+    DSG_TRYF(128, false, 1, false) DSG_TRYF(64, true, 2, false) DSG_TRYF(64, true, 1, true) DSG_TRYF(64, true, 3, true)
+#undef DSG_TRYF
+    return false;
+}
+
 // two consecutive down-64 blocks of a large sampling launch in one launch (k_res64_dual)
 bool try_dual64(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
     if (!split_ctx(h, c) || c.train || i + 1 >= (int)h->ops.size()) return false;
@@ -1245,7 +1274,7 @@ void run_unet(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
             i = h->fuse_hi - 1 + launch_fused(h, c, s);
             continue;
         }
-        if (try_dual64(h, i, c, s) || try_pair(h, i, c, s)) { ++i; continue; }
+        if (try_dual64(h, i, c, s) || try_pair(h, i, c, s) || try_pair_f32(h, i, c, s)) { ++i; continue; }
         launch_op(h, h->ops[i], c, s);
     }
 }
@@ -2150,6 +2179,9 @@ int dsg_set_option(dsg_handle* h, int option, int value) {
         case DSG_OPT_TRAIN_TIME_BESIDE: h->opt_time_beside = value != 0; return 0;
         case DSG_OPT_PANEL_HALF:
             if ((value != 0) != h->opt_panel_half) { (void)hipDeviceSynchronize(); free_graphs(h); h->opt_panel_half = value != 0; }
+            return 0;
+        case DSG_OPT_F32_PAIR:
+            if ((value != 0) != h->opt_f32_pair) { (void)hipDeviceSynchronize(); free_graphs(h); h->opt_f32_pair = value != 0; }
             return 0;
         case DSG_OPT_TILE_STEP:
             if ((value != 0) != h->opt_tile) { (void)hipDeviceSynchronize(); free_graphs(h); h->opt_tile = value != 0; }

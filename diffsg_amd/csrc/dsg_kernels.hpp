@@ -437,7 +437,7 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
                                               float* xr_m2 = nullptr, const bool store_out = true) {
     constexpr int NG = (N + 7) / 8, NT = (N + 31) / 32;
     constexpr int FIXG = FIXED ? N / 8 : 0;        // FIXED: in0 (and in1 of a concat) have exactly N / 8 groups (chain_from_mem_fixed)
-    static_assert(!(XIN || XOUT) || NT == 1, "register hand-over: one accumulator tile");
+    static_assert(!XIN || NT == 1, "register input: one accumulator tile");      // XOUT: xr[NT] (k_resblock_lin hands a wide block's output on)
     const int h = lane >> 5, j = lane & 31;
     const int ptile = tile % a.tiles_per_pass;
     const int KG = a.in0.groups + a.in1.groups;
@@ -570,7 +570,11 @@ __device__ __forceinline__ void resblock_body(const BlockArgs& a, const int tile
     {
         float mean, m2;
         acc_stats<N, NT>(acc3, h, mean, m2);
-        if constexpr (XOUT) { *xr = acc3[0]; *xr_mean = mean; *xr_m2 = m2; }
+        if constexpr (XOUT) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) xr[nt] = acc3[nt];
+            *xr_mean = mean; *xr_m2 = m2;
+        }
         if (!XOUT || store_out) {
             if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(mean, m2);
 #pragma unroll
@@ -630,55 +634,13 @@ __device__ __forceinline__ void globalize_params(LinArgs& a) {
 enum { IN_FRAG = 0, IN_ROWMAJOR = 1 };
 enum { OUT_FRAG = 0, OUT_ROWMAJOR = 1 };
 
-template <int NT, int INMODE, int OUTMODE, bool LNACT>
-__device__ __forceinline__ void linear_body(const LinArgs& a, const int tile, const int lane) {
+// The output side of a Linear: fragment layout with the row statistics of the true width, or row-major rows at the network boundary.
+template <int NT, int OUTMODE>
+__device__ __forceinline__ void linear_store(const LinArgs& a, const int tile, const int lane, const f32x16 (&acc)[NT]) {
     const int h = lane >> 5, j = lane & 31;
     const int ptile = tile % a.tiles_per_pass;
     const int pass = tile / a.tiles_per_pass;
     const int row = ptile * 32 + j;
-    const int KG = a.in_groups;
-    const size_t nt_stride = (size_t)KG * 256;
-
-    f32x16 acc[NT];
-    acc_init<NT>(acc, a.bias, h);
-
-    float mean = 0.f, rstd = 1.f;
-    if (LNACT) {
-        const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)tile * 32 + j];
-        mean = s.x;
-        rstd = rsqrtf(s.y / (float)a.in.width + kLnEps);
-    }
-    if (INMODE == IN_FRAG) {
-        chain_from_mem<NT, LNACT>(acc, a.in.data + (size_t)tile * KG * 256 + lane * 4, KG, a.W + lane * 4, nt_stride,
-                                  LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
-    } else {
-        // rows of a multiple of 4 floats (MSR-80c: 80): one 16-byte load per lane and group instead of four 4-byte ones (a wave's
-        // load touches 32 rows = 32 cache lines either way; round 5: feature_proj 53 us at 65 536 rows on the exact path)
-        const bool vec4 = (a.in_width & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in_rm) & 15) == 0;
-        const bool rowok = row < a.nrows;
-        const float* rp = a.in_rm + (size_t)(rowok ? row : 0) * a.in_width;
-        // (weights one group ahead in ping-pong sets, as chain_from_mem, measured SLOWER here: feature_proj 40.4 -> 45.4 us at 65 536 rows)
-        float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vec4 && rowok && 4 * h < a.in_width) xn = ld4(rp + 4 * h);
-        for (int g = 0; g < KG; ++g) {
-            float4 wc[NT];
-            load_wfrag<NT>(wc, a.W + (size_t)g * 256 + lane * 4, nt_stride);
-            float v[4];
-            if (vec4) {
-                v[0] = xn.x; v[1] = xn.y; v[2] = xn.z; v[3] = xn.w;
-                xn = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rowok && 8 * (g + 1) + 4 * h < a.in_width && g + 1 < KG) xn = ld4(rp + 8 * (g + 1) + 4 * h);
-            } else {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int f = 8 * g + 4 * h + p;
-                    v[p] = (rowok && f < a.in_width) ? rp[f] : 0.f;
-                }
-            }
-            mfma_group<NT>(acc, wc, v[0], v[1], v[2], v[3]);
-        }
-    }
-
     if (OUTMODE == OUT_FRAG) {
         const int NG = (a.out_width + 7) / 8;
         // statistics over the true width
@@ -729,6 +691,58 @@ __device__ __forceinline__ void linear_body(const LinArgs& a, const int tile, co
     }
 }
 
+template <int NT, int INMODE, int OUTMODE, bool LNACT>
+__device__ __forceinline__ void linear_body(const LinArgs& a, const int tile, const int lane) {
+    const int h = lane >> 5, j = lane & 31;
+    const int ptile = tile % a.tiles_per_pass;
+    const int pass = tile / a.tiles_per_pass;
+    const int row = ptile * 32 + j;
+    const int KG = a.in_groups;
+    const size_t nt_stride = (size_t)KG * 256;
+
+    f32x16 acc[NT];
+    acc_init<NT>(acc, a.bias, h);
+
+    float mean = 0.f, rstd = 1.f;
+    if (LNACT) {
+        const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)tile * 32 + j];
+        mean = s.x;
+        rstd = rsqrtf(s.y / (float)a.in.width + kLnEps);
+    }
+    if (INMODE == IN_FRAG) {
+        chain_from_mem<NT, LNACT>(acc, a.in.data + (size_t)tile * KG * 256 + lane * 4, KG, a.W + lane * 4, nt_stride,
+                                  LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
+    } else {
+        // rows of a multiple of 4 floats (MSR-80c: 80): one 16-byte load per lane and group instead of four 4-byte ones (a wave's
+        // load touches 32 rows = 32 cache lines either way; round 5: feature_proj 53 us at 65 536 rows on the exact path)
+        const bool vec4 = (a.in_width & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in_rm) & 15) == 0;
+        const bool rowok = row < a.nrows;
+        const float* rp = a.in_rm + (size_t)(rowok ? row : 0) * a.in_width;
+        // (weights one group ahead in ping-pong sets, as chain_from_mem, measured SLOWER here: feature_proj 40.4 -> 45.4 us at 65 536 rows)
+        float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec4 && rowok && 4 * h < a.in_width) xn = ld4(rp + 4 * h);
+        for (int g = 0; g < KG; ++g) {
+            float4 wc[NT];
+            load_wfrag<NT>(wc, a.W + (size_t)g * 256 + lane * 4, nt_stride);
+            float v[4];
+            if (vec4) {
+                v[0] = xn.x; v[1] = xn.y; v[2] = xn.z; v[3] = xn.w;
+                xn = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowok && 8 * (g + 1) + 4 * h < a.in_width && g + 1 < KG) xn = ld4(rp + 8 * (g + 1) + 4 * h);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int f = 8 * g + 4 * h + p;
+                    v[p] = (rowok && f < a.in_width) ? rp[f] : 0.f;
+                }
+            }
+            mfma_group<NT>(acc, wc, v[0], v[1], v[2], v[3]);
+        }
+    }
+
+    linear_store<NT, OUTMODE>(a, tile, lane, acc);
+}
+
 // (Without a waves-per-SIMD bound hipcc gave these kernels 174-302 registers -- up to 128 of them accumulator registers for 64
 // accumulator values -- and one or two waves per SIMD: a handful of MFMAs per memory round trip then runs at 1 TB/s.  Round 5.)
 template <int NT, int INMODE, int OUTMODE, bool LNACT>
@@ -738,6 +752,50 @@ __global__ __launch_bounds__(256, NT >= 4 ? 3 : 4) void k_linear(const LinArgs a
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.ntiles) return;
     linear_body<NT, INMODE, OUTMODE, LNACT>(a, tile, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact path, large launches: a >= 64-wide block and the Linear that consumes it (Down / Upsample, or `final`: LayerNorm + SiLU +
+// Linear) in one launch -- the Linear reads the block's accumulators instead of a stored tensor (round 5; the split path has had
+// the pairs since round 2).  Same operands, same MFMA order, same statistics as the two launches: same bits
+// (test_exact_path_pair_kernels_are_the_two_launches_bit_for_bit).
+// ---------------------------------------------------------------------------------------------
+template <int N, bool SCLIN, int NTO, bool FINAL>
+__global__ __launch_bounds__(256, N >= 128 ? 2 : 4) void k_resblock_lin(const BlockArgs a, const LinArgs l, const int store_block_out) {
+    constexpr int NT = N / 32, NG = N / 8;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (tile >= a.ntiles) return;
+    f32x16 x[NT];
+    float xmean, xm2;
+    resblock_body<N, SCLIN, false, true, true>(a, tile, lane, x, &xmean, &xm2, store_block_out != 0);
+    f32x16 acc[NTO];
+    acc_init<NTO>(acc, l.bias, h);
+    const float rstd = FINAL ? rsqrtf(xm2 / (float)N + kLnEps) : 1.f;      // as linear_body computes it from the stored statistics
+    const size_t nt_stride = (size_t)NG * 256;
+    const float* wp = l.W + lane * 4;
+    // weights one group ahead in two slots -- except at N = 64 with >= 3 out tiles, where the second slot does not fit the 128
+    // registers of four waves per SIMD (164 bytes of scratch): there the group's own loads, covered by the SIMD's other waves
+    constexpr int PF = (N == 64 && NTO >= 3) ? 0 : 1;
+    float4 wb[PF + 1][NTO], gb[PF + 1], bb[PF + 1];
+    if (PF) {
+        load_wfrag<NTO>(wb[0], wp, nt_stride);
+        if (FINAL) { gb[0] = ld4(l.gamma + 4 * h); bb[0] = ld4(l.beta + 4 * h); }
+    }
+#pragma unroll
+    for (int G = 0; G < NG; ++G) {
+        const int GL = G + PF, sl = PF ? (GL & 1) : 0, sc = PF ? (G & 1) : 0;
+        if (GL < NG) {
+            load_wfrag<NTO>(wb[sl], wp + (size_t)GL * 256, nt_stride);
+            if (FINAL) { gb[sl] = ld4(l.gamma + 8 * GL + 4 * h); bb[sl] = ld4(l.beta + 8 * GL + 4 * h); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float4 b = make_float4(x[G >> 2][4 * (G & 3) + 0], x[G >> 2][4 * (G & 3) + 1], x[G >> 2][4 * (G & 3) + 2], x[G >> 2][4 * (G & 3) + 3]);
+        if (FINAL) b = ln_silu4(b, xmean, rstd, gb[sc], bb[sc]);
+        mfma_group<NTO>(acc, wb[sc], b.x, b.y, b.z, b.w);
+        if (!PF) __builtin_amdgcn_sched_barrier(0);
+    }
+    linear_store<NTO, FINAL ? OUT_ROWMAJOR : OUT_FRAG>(l, tile, lane, acc);
 }
 
 // ---------------------------------------------------------------------------------------------

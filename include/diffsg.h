@@ -102,8 +102,12 @@ int dsg_set_launch_policy(dsg_handle* h, int coop_max_tiles, int narrow_small_ma
  *   DSG_OPT_PANEL_HALF     1 (default) / 0: the persistent 128-wide kernels of large sampling launches with half-size weight panels and
  *                          4-wave workgroups, two per CU, each streaming its own panels (csrc/dsg_panel.hpp, STEPS = 2): the two waves of a
  *                          SIMD then belong to different workgroups and no longer run the block program in lock-step.  Same arithmetic and
- *                          accumulation order per element: bit-identical results; +0.3..0.9 % at 65 536 rows, 3-11 % at 12 288 - 49 152 rows. */
-enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2, DSG_OPT_WGRAD_NARROW_PART = 4, DSG_OPT_TILE_STEP = 8, DSG_OPT_PANEL_HALF = 16 };
+ *                          accumulation order per element: bit-identical results; +0.3..0.9 % at 65 536 rows, 3-11 % at 12 288 - 49 152 rows.
+ *   DSG_OPT_F32_PAIR       1 (default) / 0: exact-float32 path, inference: a >= 64-wide ResidualBlock and the Linear that consumes its
+ *                          output (Downsample / Upsample, UNetCF.py:230-257; `final`, UNetCF.py:356) in one launch, the Linear fed from
+ *                          the block's accumulators (csrc/dsg_kernels.hpp, k_resblock_lin).  Bit-identical to the two launches. */
+enum { DSG_OPT_NARROW_VALU8 = 1, DSG_OPT_TRAIN_TIME_BESIDE = 2, DSG_OPT_WGRAD_NARROW_PART = 4, DSG_OPT_TILE_STEP = 8, DSG_OPT_PANEL_HALF = 16,
+       DSG_OPT_F32_PAIR = 32 };
 int dsg_set_option(dsg_handle* h, int option, int value);
 
 /* Pre-size the workspace for up to `max_rows` batch rows and `max_entries` time-table rows. */

@@ -1542,3 +1542,27 @@ def test_half_panel_form_of_the_128_wide_kernels_is_bit_identical():
     ddpm.model.set_option("panel_half", 0)
     assert torch.equal(ddpm.sample(cond, 1.0, seed=7), ref)
     ddpm.model.set_option("panel_half", 1)
+
+
+def test_exact_path_pair_kernels_are_the_two_launches_bit_for_bit():
+    """dsg_set_option(DSG_OPT_F32_PAIR): on the exact-float32 path a >= 64-wide block and the Linear that consumes it (down.2.lin,
+    up.15.lin, `final`: UNetCF.py:230-257, 356) run in one launch, the Linear fed from the block's accumulators (k_resblock_lin).  Same
+    operands, MFMA order and statistics as the two launches: bit-identical samples, ragged batch included; and the exact path (unrolled
+    chains of round 5) against the CPU oracle at a size that takes the large launches."""
+    import bench
+    dev = torch.device("cuda:0")
+    T = 3
+    ddpm = bench.build_model(dev, T)
+    ddpm.model.set_precision("f32")
+    try:
+        for B in (4096 + 7, 65536):
+            cond = torch.rand(B, 80, generator=torch.Generator().manual_seed(5)).to(dev)
+            ddpm.model.set_option("f32_pair", 0)
+            ref = ddpm.sample(cond, 1.0, seed=11)
+            ddpm.model.set_option("f32_pair", 1)
+            for _ in range(2):
+                assert torch.equal(ddpm.sample(cond, 1.0, seed=11), ref)
+    finally:
+        ddpm.model.set_option("f32_pair", 1)
+        ddpm.model.set_precision("split_f16")
+

@@ -198,11 +198,13 @@ OTHER_HOT_KERNELS = [
 F32_STEP_KERNELS = [
     "dsg::k_resblock<128, true, true>", "dsg::k_resblock<128, false, true>", "dsg::k_resblock<64, true, true>", "dsg::k_resblock<64, false, true>",
     "dsg::k_linear<4, 1, 0, false>", "dsg::k_linear<3, 0, 1, true>", "dsg::k_linear<2, 0, 0, false>", "dsg::k_linear<4, 0, 0, false>",
+    "dsg::k_resblock_lin<128, false, 2, false>", "dsg::k_resblock_lin<128, true, 3, true>",      # the pairs of the bench shape
 ]
 # kernels that MAY keep a few bytes of scratch (stated, bounded): the whole-net tile kernel is the union of every small-launch body under
 # one 256-register budget (two workgroups per CU); what it spills is reloaded once per operator, not inside a loop
 BOUNDED_SCRATCH_KERNELS = {"dsg::k_unet_tile<2>": 32, "dsg::k_unet_tile<3>": 32, "dsg::k_unet_tile<0>": 32,
-                           "dsg::k_fused_narrow": 36}      # the exact path's narrow run: 8 spilled registers under its 128-register bound
+                           "dsg::k_fused_narrow": 36,
+                           "dsg::k_resblock_lin<64, true, 4, false>": 20}      # up.14.res + up.15.lin: four registers stored / reloaded once per tile      # the exact path's narrow run: 8 spilled registers under its 128-register bound
 
 
 TABLE_DRIVEN_KERNELS = ["k_fused_narrow_lds", "k_fused_narrow_h", "k_fused_narrow_bwd_h", "k_wgrad_h", "k_wgrad", "k_colsum", "k_fused_narrow"]
