@@ -703,7 +703,9 @@ __device__ __forceinline__ void linear_bwd_body(const LinBwdArgs& a, int tile, i
     acc_zero<OT>(dx);
     const size_t nt_stride = (size_t)NGo * 256;
     {
-        float4 wn[OT], gn;
+        // two operand sets, the loop unrolled by two (ping-pong, as chain_from_mem: the "current / next" form rotated its prefetch through
+        // 4 OT + 4 register moves per group and copied them back at the loop end -- 725 of this kernel's 2 539 loop instructions at OT = 4)
+        float4 w0[OT], w1[OT], g0, g1;
         auto load_g = [&](int g) {
             float4 gv = ld4(a.gout_a + ((size_t)tile * NGo + g) * 256 + lane * 4);
             if (a.gout_b) {
@@ -712,20 +714,22 @@ __device__ __forceinline__ void linear_bwd_body(const LinBwdArgs& a, int tile, i
             }
             return gv;
         };
-        load_wfrag<OT>(wn, a.WT + lane * 4, nt_stride);
-        gn = load_g(0);
-        for (int g = 0; g < NGo; ++g) {
-            float4 wc[OT];
-#pragma unroll
-            for (int nt = 0; nt < OT; ++nt) wc[nt] = wn[nt];
-            const float4 gv = gn;
-            if (g + 1 < NGo) {
-                load_wfrag<OT>(wn, a.WT + (size_t)(g + 1) * 256 + lane * 4, nt_stride);
-                gn = load_g(g + 1);
+        load_wfrag<OT>(w0, a.WT + lane * 4, nt_stride);
+        g0 = load_g(0);
+        int g = 0;
+        for (; g + 1 < NGo; g += 2) {
+            load_wfrag<OT>(w1, a.WT + (size_t)(g + 1) * 256 + lane * 4, nt_stride);
+            g1 = load_g(g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group<OT>(dx, w0, g0.x, g0.y, g0.z, g0.w);
+            if (g + 2 < NGo) {
+                load_wfrag<OT>(w0, a.WT + (size_t)(g + 2) * 256 + lane * 4, nt_stride);
+                g0 = load_g(g + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfma_group<OT>(dx, wc, gv.x, gv.y, gv.z, gv.w);
+            mfma_group<OT>(dx, w1, g1.x, g1.y, g1.z, g1.w);
         }
+        if (g < NGo) mfma_group<OT>(dx, w0, g0.x, g0.y, g0.z, g0.w);
     }
     if (LNBWD) {
         const float2 s = reinterpret_cast<const float2*>(a.in.stats)[(size_t)tile * 32 + j];
@@ -778,8 +782,10 @@ __device__ __forceinline__ void linear_bwd_body(const LinBwdArgs& a, int tile, i
                 make_float4(dx[G >> 2][4 * (G & 3)], dx[G >> 2][4 * (G & 3) + 1], dx[G >> 2][4 * (G & 3) + 2], dx[G >> 2][4 * (G & 3) + 3]));
 }
 
+// (two waves per SIMD as a bound: without one hipcc keeps dx in accumulation registers and moves every value in and out of them for the
+// LayerNorm backward -- 657 v_accvgpr moves at OT = 4)
 template <int OT, bool LNBWD>
-__global__ __launch_bounds__(256) void k_linear_bwd(const LinBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_linear_bwd(const LinBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));  // wave-uniform: SGPR address math
     if (tile >= a.ntiles) return;
