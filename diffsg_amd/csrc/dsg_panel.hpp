@@ -748,20 +748,8 @@ __global__ __launch_bounds__(64 * panel_pw(STEPS), 2) void k_panel128_h(const Bl
         if (!live) continue;
         if (EPI == 1) {
             const int NGo = (la.out_width + 7) / 8;
-            float s = 0.f;
-#pragma unroll
-            for (int G = 0; G < NTO * 4; ++G)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq)
-                    if (8 * G + 4 * h + qq < la.out_width) s += acc[G >> 2][4 * (G & 3) + qq];
-            const float m = xhalf_sum(s) * la.inv_out_w;
-            float sq = 0.f;
-#pragma unroll
-            for (int G = 0; G < NTO * 4; ++G)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq)
-                    if (8 * G + 4 * h + qq < la.out_width) { const float dv = acc[G >> 2][4 * (G & 3) + qq] - m; sq = fmaf(dv, dv, sq); }
-            sq = xhalf_sum(sq);
+            float m, sq;
+            lin_out_stats<NTO>(acc, h, la.out_width, la.inv_out_w, m, sq);       // (dsg_split.hpp: compile-time form at full width)
             if (h == 0) reinterpret_cast<float2*>(la.out_stats)[(size_t)tile * 32 + j] = make_float2(m, sq);
 #pragma unroll
             for (int G = 0; G < NTO * 4; ++G)

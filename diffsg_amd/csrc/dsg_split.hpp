@@ -944,6 +944,35 @@ __global__ __launch_bounds__(256) void k_resblock_c(const BlockArgsH ah) {
 // A wide block followed by the Linear that consumes it (Down/Upsample: raw; final: LayerNorm + SiLU, row-major out),
 // fused: the block's output stays in registers, which saves one launch, one store (unless it is a skip) and one reload.
 struct LinArgsH;
+// Row statistics (mean, M2 over the true width) of a Linear's output held in NT accumulator tiles.  With a run-time width every
+// element is a compare + add + select and the whole sum ONE dependent chain of selects (disassembly of k_fused_narrow_lds, round 5:
+// 5 instructions per element, 64 elements per lane at NT = 4, twice).  A width that is a multiple of 8 makes the mask a function of the
+// 8-feature group alone: W > 0 is that compile-time form -- same elements in the same order, same bits.  W = 0: run-time width.
+template <int NT, int W>
+__device__ __forceinline__ void lin_out_stats_w(const f32x16 (&acc)[NT], const int h, const int width, const float inv_w, float& m, float& q) {
+    float s = 0.f;
+#pragma unroll
+    for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (W > 0 ? 8 * G < W : 8 * G + 4 * h + p < width) s += acc[G >> 2][4 * (G & 3) + p];
+    m = xhalf_sum(s) * inv_w;
+    float qq = 0.f;
+#pragma unroll
+    for (int G = 0; G < NT * 4; ++G)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (W > 0 ? 8 * G < W : 8 * G + 4 * h + p < width) { const float d = acc[G >> 2][4 * (G & 3) + p] - m; qq = fmaf(d, d, qq); }
+    q = xhalf_sum(qq);
+}
+template <int NT>
+__device__ __forceinline__ void lin_out_stats(const f32x16 (&acc)[NT], const int h, const int width, const float inv_w, float& m, float& q) {
+    if (width == 32 * NT) lin_out_stats_w<NT, 32 * NT>(acc, h, width, inv_w, m, q);              // every shipped wide Linear
+    else if (NT == 1 && width == 16) lin_out_stats_w<NT, (NT == 1 ? 16 : 0)>(acc, h, width, inv_w, m, q);
+    else if (NT == 1 && width == 8) lin_out_stats_w<NT, (NT == 1 ? 8 : 0)>(acc, h, width, inv_w, m, q);
+    else lin_out_stats_w<NT, 0>(acc, h, width, inv_w, m, q);
+}
+
 template <int NTO, int NTI, bool FINAL>
 __device__ __forceinline__ void linear_epilogue_h(const LinArgsH& ah, int tile, int lane, const f32x16 (&x)[NTI], float xmean, float xm2);
 
@@ -983,20 +1012,8 @@ __device__ __forceinline__ void linear_epilogue_h(const LinArgsH& ah, int tile, 
     acc_unscale_add<NTO>(acc, ah.kc[FINAL ? 1 : 0], a.bias, h);
     if (!FINAL) {
         const int NG = (a.out_width + 7) / 8;
-        float s = 0.f;
-#pragma unroll
-        for (int G = 0; G < NTO * 4; ++G)
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if (8 * G + 4 * h + p < a.out_width) s += acc[G >> 2][4 * (G & 3) + p];
-        const float m = xhalf_sum(s) * a.inv_out_w;
-        float q = 0.f;
-#pragma unroll
-        for (int G = 0; G < NTO * 4; ++G)
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if (8 * G + 4 * h + p < a.out_width) { const float d = acc[G >> 2][4 * (G & 3) + p] - m; q = fmaf(d, d, q); }
-        q = xhalf_sum(q);
+        float m, q;
+        lin_out_stats<NTO>(acc, h, a.out_width, a.inv_out_w, m, q);
         if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
 #pragma unroll
         for (int G = 0; G < NTO * 4; ++G)
@@ -1129,23 +1146,8 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
 
     if (OUTMODE == OUT_FRAG) {
         const int NG = (a.out_width + 7) / 8;
-        float s = 0.f;
-#pragma unroll
-        for (int G = 0; G < NT * 4; ++G)
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if (8 * G + 4 * h + p < a.out_width) s += acc[G >> 2][4 * (G & 3) + p];
-        const float m = xhalf_sum(s) * a.inv_out_w;
-        float q = 0.f;
-#pragma unroll
-        for (int G = 0; G < NT * 4; ++G)
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if (8 * G + 4 * h + p < a.out_width) {
-                    const float d = acc[G >> 2][4 * (G & 3) + p] - m;
-                    q = fmaf(d, d, q);
-                }
-        q = xhalf_sum(q);
+        float m, q;
+        lin_out_stats<NT>(acc, h, a.out_width, a.inv_out_w, m, q);
         if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
 #pragma unroll
         for (int G = 0; G < NT * 4; ++G)
@@ -1206,20 +1208,8 @@ __device__ __forceinline__ void linear_reg_h(const LinArgsH& ah, const int tile,
     chain_raw_from_reg_h<1, 1, true>(acc, x, a.in_groups, ah.Wh, (size_t)KS * 128, lane);
     acc_unscale_add<1>(acc, ah.kc[0], a.bias, h);
     const int NG = (a.out_width + 7) / 8;
-    float s = 0.f;
-#pragma unroll
-    for (int G = 0; G < 4; ++G)
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if (8 * G + 4 * h + p < a.out_width) s += acc[0][4 * G + p];
-    const float m = xhalf_sum(s) * a.inv_out_w;
-    float q = 0.f;
-#pragma unroll
-    for (int G = 0; G < 4; ++G)
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if (8 * G + 4 * h + p < a.out_width) { const float d = acc[0][4 * G + p] - m; q = fmaf(d, d, q); }
-    q = xhalf_sum(q);
+    float m, q;
+    lin_out_stats<1>(acc, h, a.out_width, a.inv_out_w, m, q);
     x[0] = acc[0]; xmean = m; xm2 = q;
     if (store_out) {
         if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
@@ -1241,20 +1231,8 @@ __device__ __forceinline__ void linear_reg_out_h(const LinArgsH& ah, const int t
     chain_raw_from_reg_h<NTO, 1, true>(acc, x, a.in_groups, ah.Wh, (size_t)KS * 128, lane);
     acc_unscale_add<NTO>(acc, ah.kc[0], a.bias, h);
     const int NG = (a.out_width + 7) / 8;
-    float s = 0.f;
-#pragma unroll
-    for (int G = 0; G < 4 * NTO; ++G)
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if (8 * G + 4 * h + p < a.out_width) s += acc[G >> 2][4 * (G & 3) + p];
-    const float m = xhalf_sum(s) * a.inv_out_w;
-    float q = 0.f;
-#pragma unroll
-    for (int G = 0; G < 4 * NTO; ++G)
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if (8 * G + 4 * h + p < a.out_width) { const float d = acc[G >> 2][4 * (G & 3) + p] - m; q = fmaf(d, d, q); }
-    q = xhalf_sum(q);
+    float m, q;
+    lin_out_stats<NTO>(acc, h, a.out_width, a.inv_out_w, m, q);
     if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
 #pragma unroll
     for (int G = 0; G < 4 * NTO; ++G)

@@ -455,20 +455,8 @@ __global__ __launch_bounds__(256, 2) void k_wide128_h(const BlockLinArgsH A) {
     if (!live) return;
     if (EPI == 1) {
         const int NGo = (la.out_width + 7) / 8;
-        float s = 0.f;
-#pragma unroll
-        for (int G = 0; G < NTO * 4; ++G)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (8 * G + 4 * h + q < la.out_width) s += acc[G >> 2][4 * (G & 3) + q];
-        const float m = xhalf_sum(s) * la.inv_out_w;
-        float qq = 0.f;
-#pragma unroll
-        for (int G = 0; G < NTO * 4; ++G)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (8 * G + 4 * h + q < la.out_width) { const float dd = acc[G >> 2][4 * (G & 3) + q] - m; qq = fmaf(dd, dd, qq); }
-        qq = xhalf_sum(qq);
+        float m, qq;
+        lin_out_stats<NTO>(acc, h, la.out_width, la.inv_out_w, m, qq);
         if (h == 0) reinterpret_cast<float2*>(la.out_stats)[(size_t)tile * 32 + j] = make_float2(m, qq);
 #pragma unroll
         for (int G = 0; G < NTO * 4; ++G)
