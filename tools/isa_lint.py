@@ -3,7 +3,8 @@
 (DESIGN.md 9):  python tools/isa_lint.py [substring of kernel names ...]
 per kernel: instructions, FLAT accesses (a pointer read from memory: as_global it), global loads that are followed within four
 instructions by `s_waitcnt vmcnt(0)` (a load inside a wave-uniform branch, or a load-use pair the scheduler could not separate), full
-LDS drains (`lgkmcnt(0)`), register moves, branches.  Runs on the CPU (llvm-objdump from the ROCm tree)."""
+LDS drains (`lgkmcnt(0)`), register moves, branches, MFMAs, and the register moves that sit inside LOOP bodies (a prefetch the compiler rotates
+through moves every iteration: the round-1 exact-float32 block kernel spent 56 per k-group that way).  Runs on the CPU (llvm-objdump from the ROCm tree)."""
 import os, re, shutil, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,12 +23,38 @@ def disassemble(so):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+LOOP_MOVES = {}    # kernel symbol -> register moves (v_mov / v_accvgpr) inside loop bodies, i.e. between a backward branch and its target
+
+
 def kernels(dis):
     syms = [(m.start(), m.group(1)) for m in re.finditer(r"^[0-9a-f]+ <([^>]+)>:$", dis, re.M)]
     for k, (pos, name) in enumerate(syms):
         body = dis[pos:syms[k + 1][0] if k + 1 < len(syms) else len(dis)]
-        ins = [l.split("\t")[1].split("//")[0].strip() for l in body.split("\n") if "\t" in l]
-        yield name, [i for i in ins if i]
+        ins, addr = [], []
+        for l in body.split("\n"):
+            if "\t" not in l:
+                continue
+            txt = l.split("\t")[1].split("//")[0].strip()
+            m = re.search(r"//\s*([0-9A-F]+):", l)
+            if txt:
+                ins.append(txt)
+                addr.append(int(m.group(1), 16) if m else -1)
+        # loop bodies: a branch with a negative offset closes a loop that starts at its target (a prefetch rotated through register
+        # moves every iteration shows up here: round 5, k_resblock<128, true> -- 56 moves per k-group)
+        idx = {a: i for i, a in enumerate(addr) if a >= 0}
+        inloop = set()
+        for i, t in enumerate(ins):
+            if t.startswith("s_cbranch") or t.startswith("s_branch"):
+                try:
+                    off = int(t.split()[-1])
+                except ValueError:
+                    continue
+                off = off - 65536 if off >= 32768 else off
+                tgt = addr[i] + 4 + 4 * off
+                if off < 0 and tgt in idx:
+                    inloop.update(range(idx[tgt], i + 1))
+        LOOP_MOVES[name] = sum(1 for i in inloop if ins[i].startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr")))
+        yield name, ins
 
 
 def demangle(names):
@@ -50,14 +77,14 @@ def main():
         load_then_wait = sum(1 for k in vm0 if any(x.startswith("global_load") or x.startswith("flat_load") for x in ins[max(0, k - 4):k]))
         rows.append((name, len(ins), sum(v for o, v in ops.items() if o.startswith("flat_")), load_then_wait, len(vm0),
                      sum(1 for k in waits if "lgkmcnt(0)" in ins[k]), ops.get("v_mov_b32_e32", 0) + ops.get("v_mov_b64_e32", 0),
-                     sum(v for o, v in ops.items() if o.startswith("s_cbranch")), sum(v for o, v in ops.items() if o.startswith("v_mfma"))))
+                     sum(v for o, v in ops.items() if o.startswith("s_cbranch")), sum(v for o, v in ops.items() if o.startswith("v_mfma")), LOOP_MOVES.get(name, 0)))
     names = demangle([r[0] for r in rows])
-    print(f"{'kernel':72s} {'instr':>6s} {'flat':>5s} {'ld->vm0':>7s} {'vm0':>4s} {'lgkm0':>5s} {'v_mov':>5s} {'br':>4s} {'mfma':>5s}")
+    print(f"{'kernel':72s} {'instr':>6s} {'flat':>5s} {'ld->vm0':>7s} {'vm0':>4s} {'lgkm0':>5s} {'v_mov':>5s} {'br':>4s} {'mfma':>5s} {'mov@loop':>8s}")
     for r in sorted(rows, key=lambda r: -r[1]):
         dn = re.sub(r"\(.*", "", names[r[0]]).replace("void ", "").replace("dsg::", "")
         if want and not any(w in dn for w in want):
             continue
-        print(f"{dn[:72]:72s} {r[1]:6d} {r[2]:5d} {r[3]:7d} {r[4]:4d} {r[5]:5d} {r[6]:5d} {r[7]:4d} {r[8]:5d}")
+        print(f"{dn[:72]:72s} {r[1]:6d} {r[2]:5d} {r[3]:7d} {r[4]:4d} {r[5]:5d} {r[6]:5d} {r[7]:4d} {r[8]:5d} {r[9]:8d}")
 
 
 if __name__ == "__main__":
