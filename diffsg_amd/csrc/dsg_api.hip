@@ -734,7 +734,8 @@ void launch_res_h(const dsg_handle* h, const ResP& r, const BlockArgs& b, hipStr
     BlockArgsH a;
     fill_block_args_h(h, r, b, a);
     const int ks1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2;
-    const bool coop_fits = ks1 * 128 <= kCoopLdsU4 / (4 / (r.N / 32 > 0 ? r.N / 32 : 1)) / 2 && ks1 <= (r.sclin ? r.N / 8 : r.N / 16);   // LDS images, register bound
+    // the cooperative body is written for inputs exactly N wide (compile-time step counts: resblock_coop_body)
+    const bool coop_fits = ks1 * 128 <= kCoopLdsU4 / (4 / (r.N / 32 > 0 ? r.N / 32 : 1)) / 2 && r.in0 == r.N && r.in1 == (r.sclin ? r.N : 0);
     // the training forward (it stores h1 / h2) takes the cooperative form up to 1 024 tiles -- 32 768 rows: 1.939 -> 1.923 ms per step
     // (profiles/r04_train_tail_ab.txt); a sampling launch of that size has two passes' worth of tiles per row and stays as measured
     const int coop_max = (a.b.save_h1 && h->coop_max_tiles > 0 && h->coop_max_tiles < kCoopMaxTilesTrain) ? kCoopMaxTilesTrain : h->coop_max_tiles;
@@ -975,7 +976,7 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
                 fill_block_args_h(h, r, b, f.b);
                 // the cooperative body's shapes: inputs exactly N wide, images within the LDS slot (launch_res_h, coop_fits)
                 const int ks1 = (groups_of(r.in0) + 1) / 2 + (groups_of(r.in1) + 1) / 2;
-                if (!((r.N == 64 || r.N == 128) && r.in0 == r.N && (r.in1 == 0 || r.in1 == r.N) && ks1 <= (r.sclin ? r.N / 8 : r.N / 16) && b.cond_pre)) ok = false;
+                if (!((r.N == 64 || r.N == 128) && r.in0 == r.N && r.in1 == (r.sclin ? r.N : 0) && ks1 <= (r.sclin ? r.N / 8 : r.N / 16) && b.cond_pre)) ok = false;
                 ++wide;
             } else {
                 const LinOpP& l = h->lin[op.p];

@@ -675,14 +675,14 @@ constexpr int kCoopBarriers = 7;
 
 // The body: `tile_raw` = the tile of this wave's slot (>= ntiles: an idle slot that only meets the barriers and stores nothing),
 // `slot` / `w` = the wave's tile slot and 32-feature slice, `img` / `stats` = the workgroup's LDS (kCoopLdsU4 uint4, 4 x 32 float2).
-// `vlds` (7 * N floats of LDS, or null): the per-feature vectors every stage reads -- gamma2 | beta2 | gamma3 | beta3 | c2 | c3 | this step's
+// `vlds` (7 * N floats of LDS): the per-feature vectors every stage reads -- gamma2 | beta2 | gamma3 | beta3 | c2 | c3 | this step's
 // time-bias row -- staged by the workgroup at the top and read from LDS behind the first barrier.  Round 5 (tools/tile_stamps.py): read
 // from global memory right where they are used, each was an exposed L2 round trip on the tile's critical path (the transforms of stages
 // 2 and 3 took 5x their arithmetic); likewise the condition embedding is requested a stage early and the second batch of the planes
 // of a 2N-wide input refills the registers of the first behind each step's MFMAs.
 template <int N, bool SCLIN>
 __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const int tile_raw, const int slot, const int w, uint4* __restrict__ img,
-                                                   float2* __restrict__ stats, float* __restrict__ vlds = nullptr) {
+                                                   float2* __restrict__ stats, float* __restrict__ vlds) {
     constexpr int NG = N / 8, NT = N / 32, TPW = 4 / NT, KS = NG / 2;
     constexpr int kSlotU4 = kCoopLdsU4 / TPW;
     const BlockArgs& a = ah.b;
@@ -693,9 +693,17 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
     uint4* const Bimg = img + slot * kSlotU4;
     uint4* const Rimg = Bimg + kSlotU4 / 2;
     float2* const st = stats + slot * NT * 32;
-    const int ks0 = (a.in0.groups + 1) >> 1, ks1 = (a.in1.groups + 1) >> 1, KS1 = ks0 + ks1;
-    const bool tb_lds = vlds && !a.ts;                  // one time-bias row for the whole launch (sampling); per-row entries stay in memory
-    if (vlds) {
+    // The input tensors are exactly N wide (in0, and in1 of an up block's concat): the host launches this body for those shapes only
+    // (launch_res_h, the tile table), so the k16-step counts are compile-time constants.  With run-time counts every plane load of
+    // coop_load_w / coop_mma_refill is conditional, hipcc cannot count the loads in flight, and each k16-step of a refilled chain waited
+    // with vmcnt(0) -- for the REFILL requested one step earlier, a full L2 round trip per step (round 5, disassembly).
+    constexpr int ks0 = NG / 2, ks1 = SCLIN ? NG / 2 : 0, KS1 = ks0 + ks1;
+    if (a.in0.groups != NG || a.in1.groups != (SCLIN ? NG : 0)) __builtin_trap();
+    // (`vlds` is NOT optional: a pointer that is "the LDS copy or the global original" is a generic pointer to hipcc, every read through
+    // it a FLAT instruction, and every wait behind one drains the wave's global loads as well -- the weight planes in flight.  Round 5,
+    // tools/isa_lint.py: 28 FLAT loads per block in k_resblock_c, 224 in k_unet_tile, each followed by vmcnt(0) lgkmcnt(0).)
+    const bool tb_lds = !a.ts;                          // one time-bias row for the whole launch (sampling); per-row entries stay in memory
+    {
         // thread t stages one float4: 7 vectors x N / 4 quads (N = 128: 224 threads; N = 64: 112, the two waves that run a 64-wide block)
         constexpr int per = N / 4;
         const int t = threadIdx.x, v = t / per, o = (t % per) * 4;
@@ -705,8 +713,8 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
             *reinterpret_cast<float4*>(vlds + v * N + o) = ld4(src + o);
         }
     }
-    const float* const g2p = vlds ? vlds : a.gamma2, * const b2p = vlds ? vlds + N : a.beta2, * const g3p = vlds ? vlds + 2 * N : a.gamma3,
-               * const b3p = vlds ? vlds + 3 * N : a.beta3, * const c2p = vlds ? vlds + 4 * N : a.c2, * const c3p = vlds ? vlds + 5 * N : a.c3;
+    const float* const g2p = vlds, * const b2p = vlds + N, * const g3p = vlds + 2 * N, * const b3p = vlds + 3 * N, * const c2p = vlds + 4 * N,
+               * const c3p = vlds + 5 * N;
 
     // ---- LN1 statistics (Chan merge of the producers' (mean, M2)), as k_resblock_h
     float mean1, rstd1;
@@ -798,8 +806,21 @@ __device__ __forceinline__ void resblock_coop_body(const BlockArgsH& ah, const i
         } else if (a.step_ptr) {
             entry = *a.step_ptr;
         }
-        if (tb_lds) acc_unscale_add<1>(acc1, inv1, vlds + 6 * N + 32 * w, h);
-        else acc_unscale_add<1>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride + 32 * w, h);
+        if (tb_lds) {
+            // through an explicit LDS pointer: as two calls of acc_unscale_add hipcc merged the branches into one body behind a select of
+            // the two pointers -- a generic pointer again, four FLAT loads
+            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) const f32x4_ lds_f4;
+            lds_f4* const tp = (lds_f4*)(vlds + 6 * N + 32 * w + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_ b = tp[2 * q];
+                acc1[0][4 * q + 0] = fmaf(acc1[0][4 * q + 0], inv1, b.x); acc1[0][4 * q + 1] = fmaf(acc1[0][4 * q + 1], inv1, b.y);
+                acc1[0][4 * q + 2] = fmaf(acc1[0][4 * q + 2], inv1, b.z); acc1[0][4 * q + 3] = fmaf(acc1[0][4 * q + 3], inv1, b.w);
+            }
+        } else {
+            acc_unscale_add<1>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride + 32 * w, h);
+        }
     }
     if (a.save_h1 && live) {
 #pragma unroll
