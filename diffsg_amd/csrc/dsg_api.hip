@@ -1252,7 +1252,7 @@ bool try_dual64(const dsg_handle* h, int i, const RunCtx& c, hipStream_t s) {
 
 // Small launches: feature_proj, then ONE launch that carries every row tile through the rest of the net (dsg_tile.hpp)
 bool tile_step_ok(const dsg_handle* h, const RunCtx& c) {
-    return h->opt_tile && h->tile_valid && split_ctx(h, c) && !c.train && h->fuse_hi - h->fuse_lo >= 2 &&
+    return h->opt_tile && h->tile_valid && split_ctx(h, c) && !c.train && !c.ts && h->fuse_hi - h->fuse_lo >= 2 &&
            cdiv(c.nrows, 32) * c.npass <= h->coop_max_tiles;
 }
 void launch_tile_step(const dsg_handle* h, const RunCtx& c, hipStream_t s) {

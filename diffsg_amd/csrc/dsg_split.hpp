@@ -1287,9 +1287,13 @@ struct V8TableSave {
 // V8NB > 0: operators [v8_at, v8_at + v8_nops) of the run are the 8-wide bottom of the net (n_blocks = V8NB) and run on the vector unit in
 // float32 from the global image `v8_img` (dsg_narrow8.hpp); v8_store: the training forward (every tensor of the section is stored).
 // The run for ONE wave and its tile (k_fused_narrow_h below; k_unet_tile runs it on the first wave of a tile's workgroup).
-template <bool PRE, int V8NB>
+// V8LDS (k_unet_tile): the section's image and its blocks' slices of the step's time-table row were staged in LDS by the workgroup, at
+// `v8_lds` ([V8SecL::SIZE floats | (2 V8NB + 3) x 32 floats]); the caller guarantees one time-table row per launch (no per-row entries).
+// Read from global memory the section waits for an L2 round trip in front of every product (~25 full drains per tile, disassembly).
+template <bool PRE, int V8NB, bool V8LDS = false>
 __device__ __forceinline__ void narrow_run_body(const FusedOpH* __restrict__ ops, const int nops, const int tile, const int lane, const int v8_at,
-                                                const int v8_nops, const float* __restrict__ v8_img, const int v8_store) {
+                                                const int v8_nops, const float* __restrict__ v8_img, const int v8_store,
+                                                const float* v8_lds = nullptr) {
     f32x16 x[1];
     float xmean = 0.f, xm2 = 0.f;
     bool have_x = false;
@@ -1327,11 +1331,16 @@ __device__ __forceinline__ void narrow_run_body(const FusedOpH* __restrict__ ops
             }
         }
         const V8Sec sc{as_global(b0.cond_pre), (long long)(b1.cond_pre - b0.cond_pre), b0.tiles_per_pass, b0.uncond_tiles};
-        const float* const tb0 = as_global(b0.tbias) + (size_t)entry * b0.tb_stride;      // this lane's row of the time table, the first block's slice
         const float xi[8] = {x[0][0], x[0][1], x[0][2], x[0][3], x[0][4], x[0][5], x[0][6], x[0][7]};
         float xo[8];
         const V8TableSave sv{ops + i, tile, lane, v8_store != 0};
-        v8_section<(V8NB > 0 ? V8NB : 2)>(v8_img, tb0, sc, tile, lane, xi, xo, xmean, xm2, sv);
+        if constexpr (V8LDS) {
+            v8_lf* const S = (v8_lf*)v8_lds;
+            v8_section<(V8NB > 0 ? V8NB : 2)>(S, S + V8SecL<(V8NB > 0 ? V8NB : 2)>::SIZE, sc, tile, lane, xi, xo, xmean, xm2, V8NoSave{});
+        } else {
+            const float* const tb0 = as_global(b0.tbias) + (size_t)entry * b0.tb_stride;  // this lane's row of the time table, the first block's slice
+            v8_section<(V8NB > 0 ? V8NB : 2)>(v8_img, tb0, sc, tile, lane, xi, xo, xmean, xm2, sv);
+        }
         x[0] = f32x16{xo[0], xo[1], xo[2], xo[3], xo[4], xo[5], xo[6], xo[7], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const FusedOpH& lz = ops[i + v8_nops - 1];
         if (lz.store_out) {                          // the Upsample output is read from memory by somebody (training: the backward pass)

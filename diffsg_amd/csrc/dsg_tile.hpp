@@ -80,7 +80,19 @@ __global__ __launch_bounds__(256, 2) void k_unet_tile(const FusedOpH* __restrict
     tile_wide_ops(ops, op_lo, has_run ? run_lo : nops, tile, wave, lane, img, stats, vecs);
     if (has_run) {
         DSG_STAMP(blockIdx.x == 0 && wave == 0, 0x1000 + run_lo);
-        if (wave == 0) narrow_run_body<true, V8NB>(ops + run_lo, run_hi - run_lo, tile, lane, v8_at, v8_nops, v8_img, 0);
+        if (V8NB > 0 && v8_at >= 0) {
+            // the float32 section's image (11-14 KiB) and its blocks' slices of this step's time-table row into the (now idle) image buffer:
+            // the whole workgroup copies, one wave then walks the section out of LDS (the host sends launches with per-row time entries
+            // to the per-operator kernels: tile_step_ok)
+            constexpr int NBs = V8NB > 0 ? V8NB : 2, SZ4 = V8SecL<NBs>::SIZE / 4, TB4 = (2 * NBs + 3) * kV8TbStride / 4;
+            static_assert(V8SecL<NBs>::SIZE % 4 == 0 && SZ4 + TB4 <= kCoopLdsU4, "the section's image fits the cooperative image buffer");
+            const BlockArgs& b0 = ops[run_lo + v8_at + 1].b.b;
+            const float* const tb = as_global(b0.tbias) + (size_t)(b0.step_ptr ? *as_global(b0.step_ptr) : 0) * b0.tb_stride;
+            float4* const dst = reinterpret_cast<float4*>(img);
+            for (int i = threadIdx.x; i < SZ4 + TB4; i += 256) dst[i] = i < SZ4 ? ld4(v8_img + 4 * i) : ld4(tb + 4 * (i - SZ4));
+            __syncthreads();
+        }
+        if (wave == 0) narrow_run_body<true, V8NB, (V8NB > 0)>(ops + run_lo, run_hi - run_lo, tile, lane, v8_at, v8_nops, v8_img, 0, reinterpret_cast<const float*>(img));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                      // the run's stored tensors (skips, its last output) are visible to the whole workgroup
         tile_wide_ops(ops, run_hi, nops, tile, wave, lane, img, stats, vecs);
