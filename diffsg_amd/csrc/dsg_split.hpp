@@ -210,6 +210,34 @@ template <int NT, int NTI = NT, bool ZERO = false>
 __device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f32x16 (&in)[NTI], int groups, const uint4* __restrict__ wp,
                                                      size_t nt_stride, int lane, const HFrag<NT>* w0 = nullptr) {
     const int steps = (groups + 1) >> 1;
+    if constexpr (NT * NTI <= 2) {
+        // every plane of the chain first, pinned above the arithmetic: left to itself hipcc sank each load to its first use -- the hi plane
+        // in front of the step's first MFMA, the lo plane in front of its third, a full wait behind each -- two exposed L2 round trips
+        // per k16-step of a Linear that is a handful of MFMAs (round 5, disassembly of k_fused_narrow_h; one tile's latency is the whole
+        // small-batch step).  At most 32 plane registers; the wide pair kernels (NT * NTI > 2) keep the step-by-step form.
+        HFrag<NT> wall[2 * NTI];
+#pragma unroll
+        for (int S = 0; S < 2 * NTI; ++S)
+            if (S < steps) {
+                if (S == 0 && w0) wall[0] = *w0;
+                else load_hfrag<NT>(wall[S], wp + (size_t)S * 128 + lane, nt_stride);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int S = 0; S < 2 * NTI; ++S) {
+            if (S < steps) {
+                const int t = S >> 1, r0 = 8 * (S & 1);
+                float v[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) v[p] = kRawScale * in[t][r0 + p];
+                h8 bhi, blo;
+                split8(v, bhi, blo);
+                if (ZERO && S == 0) mfma_step_h0<NT>(out, wall[S], bhi, blo);
+                else mfma_step_h<NT>(out, wall[S], bhi, blo);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int S = 0; S < 2 * NTI; ++S) {
         if (S < steps) {
@@ -316,6 +344,22 @@ __device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float*
 // of the vector reads and FMAs of an 8-wide block's three stages
 template <int NT, int NQ = NT * 4>
 __device__ __forceinline__ void acc_unscale_add(f32x16 (&acc)[NT], float inv, const float* __restrict__ vec, int h) {
+    if constexpr (NT == 1) {
+        // one accumulator tile (the narrow operators: latency-bound): the vector's groups in one batch of loads pinned above the
+        // multiply-adds -- hipcc otherwise reuses one register quad: load, full wait, four FMAs, four times in a row
+        float4 b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < NQ) b[q] = ld4(vec + 8 * q + 4 * h);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= NQ) continue;
+            acc[0][4 * q + 0] = fmaf(acc[0][4 * q + 0], inv, b[q].x); acc[0][4 * q + 1] = fmaf(acc[0][4 * q + 1], inv, b[q].y);
+            acc[0][4 * q + 2] = fmaf(acc[0][4 * q + 2], inv, b[q].z); acc[0][4 * q + 3] = fmaf(acc[0][4 * q + 3], inv, b[q].w);
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
