@@ -339,6 +339,50 @@ __device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float*
     }
 }
 
+// The same chain for ONE wave on a latency-bound path (k_unet_tile's plain Linears: nothing else runs on the SIMD, and a k16-step's
+// arithmetic is a fraction of an L2 round trip): the k16-steps in batches of B, every load of a batch issued before its first MFMA --
+// one exposed round trip per batch instead of one per step.  Same products in the same order: same bits.
+template <int NT, bool LNACT, int B>
+__device__ __forceinline__ void chain_from_mem_h_batched(f32x16 (&acc)[NT], const float* __restrict__ xp, int groups, const uint4* __restrict__ wp,
+                                                         size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float mean, float rstd) {
+    const int steps = (groups + 1) >> 1;
+    const float c = rstd, d = -mean * rstd;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int S0 = 0; S0 < steps; S0 += B) {
+        HFrag<NT> w[B];
+        float4 x0[B], x1[B], g0[B], b0[B], g1[B], b1[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int S = S0 + i;
+            x0[i] = z4; x1[i] = z4; g0[i] = z4; b0[i] = z4; g1[i] = z4; b1[i] = z4;
+            if (S < steps) {
+                load_hfrag<NT>(w[i], wp + (size_t)S * 128, nt_stride);
+                x0[i] = ld4(xp + (size_t)(2 * S) * 256);
+                if (2 * S + 1 < groups) x1[i] = ld4(xp + (size_t)(2 * S + 1) * 256);
+                if (LNACT) { g0[i] = ld4(gamma + 16 * S); b0[i] = ld4(beta + 16 * S); g1[i] = ld4(gamma + 16 * S + 8); b1[i] = ld4(beta + 16 * S + 8); }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            if (S0 + i < steps) {
+                float v[8];
+                if (LNACT) {
+                    act8(v, x0[i], x1[i], c, d, g0[i], b0[i], g1[i], b1[i]);
+                } else {
+                    v[0] = kRawScale * x0[i].x; v[1] = kRawScale * x0[i].y; v[2] = kRawScale * x0[i].z; v[3] = kRawScale * x0[i].w;
+                    v[4] = kRawScale * x1[i].x; v[5] = kRawScale * x1[i].y; v[6] = kRawScale * x1[i].z; v[7] = kRawScale * x1[i].w;
+                }
+                h8 bhi, blo;
+                split8(v, bhi, blo);
+                mfma_step_h<NT>(acc, w[i], bhi, blo);
+            }
+        }
+    }
+}
+
 // acc <- acc * inv + vec  (un-scale and add the per-feature vector, padded to NT*32).  NQ = real 8-feature groups: the padded
 // groups of a narrow block (N < 32) hold exact zeros (zero weight rows, zero vector padding) and are left alone - a quarter
 // of the vector reads and FMAs of an 8-wide block's three stages
@@ -1125,7 +1169,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_lin_h(const BlockLinArgsH a
     linear_epilogue_h<NTO, NT, FINAL>(a.l, tile, lane, x, xmean, xm2);
 }
 
-template <int NT, int INMODE, int OUTMODE, bool LNACT>
+// DEEP (k_unet_tile): the fragment-input chain in batches of loads (chain_from_mem_h_batched)
+template <int NT, int INMODE, int OUTMODE, bool LNACT, bool DEEP = false>
 __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile, const int lane) {
     const LinArgs& a = ah.l;
     const int h = lane >> 5, j = lane & 31;
@@ -1150,6 +1195,10 @@ __device__ __forceinline__ void linear_body_h(const LinArgsH& ah, const int tile
     }
     float vmax = 0.f;
     if (INMODE == IN_FRAG) {
+        if constexpr (DEEP)
+            chain_from_mem_h_batched<NT, LNACT, 2>(acc, a.in.data + (size_t)seg_tile(a.in, tile) * KG * 256 + lane * 4, KG, ah.Wh + lane,
+                                                                          nt_stride, LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
+        else
         chain_from_mem_h<NT, LNACT>(acc, a.in.data + (size_t)seg_tile(a.in, tile) * KG * 256 + lane * 4, KG, ah.Wh + lane, nt_stride,
                                     LNACT ? a.gamma + 4 * h : nullptr, LNACT ? a.beta + 4 * h : nullptr, mean, rstd);
     } else {

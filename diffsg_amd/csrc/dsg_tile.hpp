@@ -26,8 +26,8 @@ template <int NT>
 __device__ __forceinline__ void tile_linear(const FusedOpH& op, const int tile, const int lane) {
     LinArgsH l = op.l;
     globalize<false>(l);
-    if (op.kind == 3) linear_body_h<NT, IN_FRAG, OUT_ROWMAJOR, true>(l, tile, lane);
-    else linear_body_h<NT, IN_FRAG, OUT_FRAG, false>(l, tile, lane);
+    if (op.kind == 3) linear_body_h<NT, IN_FRAG, OUT_ROWMAJOR, true, true>(l, tile, lane);
+    else linear_body_h<NT, IN_FRAG, OUT_FRAG, false, true>(l, tile, lane);
 }
 
 // operators [lo, hi) outside the narrow run, one after the other
