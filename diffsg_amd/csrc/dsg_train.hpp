@@ -228,7 +228,9 @@ __device__ __forceinline__ void ln_silu_bwd_acc(f32x16 (&da)[NT], const f32x16 (
                     const bool ok = 8 * G + 4 * h + p < W;
                     const float xh = (x[G >> 2][4 * (G & 3) + p] - mean) * rstd;
                     const float u = fmaf(xh, gmv[p], btv[p]);
-                    const float du = ok ? da[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
+                    float dsu = da[G >> 2][4 * (G & 3) + p] * silu_grad(u);
+                    asm volatile("" : "+v"(dsu));      // computed for every lane: as `ok ? ... : 0` hipcc branched around it per element, the beta load inside the branch
+                    const float du = ok ? dsu : 0.f;
                     db[4 * Gl + p] = du;
                     dg[4 * Gl + p] = du * xh;
                     const float t = du * gmv[p];
@@ -508,7 +510,9 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
                             const bool ok = 8 * gl + 4 * h + p < sg.width;
                             const float xh = (xs[p] - mean1) * rstd1;
                             const float u = fmaf(xh, gmv[p], btv[p]);
-                            const float du = ok ? dxh[Gl >> 2][4 * (Gl & 3) + p] * silu_grad(u) : 0.f;
+                            float dsu = dxh[Gl >> 2][4 * (Gl & 3) + p] * silu_grad(u);
+                            asm volatile("" : "+v"(dsu));      // computed for every lane: as `ok ? ... : 0` hipcc branched around it per element, the beta load inside the branch
+                            const float du = ok ? dsu : 0.f;
                             duv[p] = du;
                             db[4 * G8 + p] = du;
                             dg[4 * G8 + p] = du * xh;
@@ -598,7 +602,9 @@ __device__ __forceinline__ void resblock_bwd_body(const BlockBwdArgs& a, const G
                         const bool ok = 8 * gl + 4 * h + p < sg.width;
                         const float xh = (xs[p] - mean1) * rstd1;
                         const float u = fmaf(xh, gmv[p], btv[p]);
-                        const float du = ok ? dx[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
+                        float dsu = dx[G >> 2][4 * (G & 3) + p] * silu_grad(u);
+                        asm volatile("" : "+v"(dsu));      // computed for every lane: as `ok ? ... : 0` hipcc branched around it per element, the beta load inside the branch
+                        const float du = ok ? dsu : 0.f;
                         db[4 * Gl + p] = du;
                         dg[4 * Gl + p] = du * xh;
                         const float t = du * gmv[p];
@@ -748,7 +754,9 @@ __device__ __forceinline__ void linear_bwd_body(const LinBwdArgs& a, int tile, i
                     const bool ok = 8 * G + 4 * h + p < a.in.width;
                     const float xh = (xs[p] - mean) * rstd;
                     const float u = fmaf(xh, gmv[p], btv[p]);
-                    const float du = ok ? dx[G >> 2][4 * (G & 3) + p] * silu_grad(u) : 0.f;
+                    float dsu = dx[G >> 2][4 * (G & 3) + p] * silu_grad(u);
+                    asm volatile("" : "+v"(dsu));      // computed for every lane: as `ok ? ... : 0` hipcc branched around it per element, the beta load inside the branch
+                    const float du = ok ? dsu : 0.f;
                     duv[p] = du;
                     const float t = du * gmv[p];
                     dx[G >> 2][4 * (G & 3) + p] = t;
