@@ -102,8 +102,8 @@ __device__ __forceinline__ void v8_stats(const float (&v)[4], float& mean, float
 // P: the block's LDS record; tb: its slice of the current step's time-table row (b1 + Wt silu(temb) + bt); cp: this lane's four values of the
 // block's precomputed condition embedding Wc silu(cond) (null on an unconditional tile: silu(0) = 0, only the bias bc, which sits in c2).
 // sv: what the training forward keeps for the backward pass (h1, h2: the pre-LayerNorm tensors of stages 2 and 3); a no-op otherwise.
-template <bool UP, typename PF, typename Save>
-__device__ __forceinline__ void v8_block(PF P, PF tb, const int h, float (&x)[4], float& xmean, float& xm2, const float (&sk)[4], float smean,
+template <bool UP, typename PF, typename PT, typename Save>       // PF: the image's pointer type, PT: the time-table row's (LDS or global each)
+__device__ __forceinline__ void v8_block(PF P, PT tb, const int h, float (&x)[4], float& xmean, float& xm2, const float (&sk)[4], float smean,
                                          float sm2, const float* __restrict__ cp, const Save& sv, const int blk) {
     using L = V8BlockL<UP>;
     constexpr int K1 = L::K1;
@@ -209,8 +209,8 @@ struct V8Sec {                    // what the section needs beyond its LDS image
 // tensor that leaves it, with its row statistics.  (Plain arrays, not the f32x16 of the matrix-core operators: with a partially read and
 // element-wise rewritten 16-register vector in the interface hipcc kept two whole tuples alive across the section and spilled both.)
 // sv.lin_down / sv.out(blk, ...): the Downsample output and block blk's output (blk counts the section's blocks from 0), for the backward pass.
-template <int NB, typename PF, typename Save>
-__device__ __forceinline__ void v8_section(PF S, PF tb0, const V8Sec& sc, const int tile, const int lane, const float (&xin)[8], float (&xout)[8],
+template <int NB, typename PF, typename PT, typename Save>
+__device__ __forceinline__ void v8_section(PF S, PT tb0, const V8Sec& sc, const int tile, const int lane, const float (&xin)[8], float (&xout)[8],
                                            float& xmean, float& xm2, const Save& sv) {
     using L = V8SecL<NB>;
     using BD = V8BlockL<false>;

@@ -1383,7 +1383,8 @@ struct V8TableSave {
 // V8LDS (k_unet_tile): the section's image and its blocks' slices of the step's time-table row were staged in LDS by the workgroup, at
 // `v8_lds` ([V8SecL::SIZE floats | (2 V8NB + 3) x 32 floats]); the caller guarantees one time-table row per launch (no per-row entries).
 // Read from global memory the section waits for an L2 round trip in front of every product (~25 full drains per tile, disassembly).
-template <bool PRE, int V8NB, bool V8LDS = false>
+// V8LDS = 2 (k_fused_narrow_h): the image alone is in LDS at `v8_lds`; the time-table rows stay in global memory (training: an entry per row).
+template <bool PRE, int V8NB, int V8LDS = 0>
 __device__ __forceinline__ void narrow_run_body(const FusedOpH* __restrict__ ops, const int nops, const int tile, const int lane, const int v8_at,
                                                 const int v8_nops, const float* __restrict__ v8_img, const int v8_store,
                                                 const float* v8_lds = nullptr) {
@@ -1427,9 +1428,12 @@ __device__ __forceinline__ void narrow_run_body(const FusedOpH* __restrict__ ops
         const float xi[8] = {x[0][0], x[0][1], x[0][2], x[0][3], x[0][4], x[0][5], x[0][6], x[0][7]};
         float xo[8];
         const V8TableSave sv{ops + i, tile, lane, v8_store != 0};
-        if constexpr (V8LDS) {
+        if constexpr (V8LDS == 1) {
             v8_lf* const S = (v8_lf*)v8_lds;
             v8_section<(V8NB > 0 ? V8NB : 2)>(S, S + V8SecL<(V8NB > 0 ? V8NB : 2)>::SIZE, sc, tile, lane, xi, xo, xmean, xm2, V8NoSave{});
+        } else if constexpr (V8LDS == 2) {
+            const float* const tb0 = as_global(b0.tbias) + (size_t)entry * b0.tb_stride;
+            v8_section<(V8NB > 0 ? V8NB : 2)>((v8_lf*)v8_lds, tb0, sc, tile, lane, xi, xo, xmean, xm2, sv);
         } else {
             const float* const tb0 = as_global(b0.tbias) + (size_t)entry * b0.tb_stride;  // this lane's row of the time table, the first block's slice
             v8_section<(V8NB > 0 ? V8NB : 2)>(v8_img, tb0, sc, tile, lane, xi, xo, xmean, xm2, sv);
@@ -1528,8 +1532,20 @@ __global__ __launch_bounds__(256, PRE ? 2 : 4) void k_fused_narrow_h(const Fused
                                                                      const float* __restrict__ v8_img, int v8_store) {
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (tile >= ntiles) return;
-    narrow_run_body<PRE, V8NB>(ops, nops, tile, lane, v8_at, v8_nops, v8_img, v8_store);
+    if constexpr (V8NB > 0) {
+        // the float32 section's image (11-14 KiB) into LDS, once per workgroup: read from global memory the section waits for an L2 round
+        // trip in front of every product (round 5: ~25 full drains per tile in the disassembly; k_unet_tile stages it the same way)
+        __shared__ float4 v8s[V8SecL<V8NB>::SIZE / 4];
+        if (v8_at >= 0) {
+            for (int i = threadIdx.x; i < V8SecL<V8NB>::SIZE / 4; i += 256) v8s[i] = ld4(v8_img + 4 * i);
+            __syncthreads();
+        }
+        if (tile >= ntiles) return;
+        narrow_run_body<PRE, V8NB, 2>(ops, nops, tile, lane, v8_at, v8_nops, v8_img, v8_store, reinterpret_cast<const float*>(v8s));
+    } else {
+        if (tile >= ntiles) return;
+        narrow_run_body<PRE, V8NB>(ops, nops, tile, lane, v8_at, v8_nops, v8_img, v8_store);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

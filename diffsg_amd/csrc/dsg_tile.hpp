@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void k_unet_tile(const FusedOpH* __restrict
             for (int i = threadIdx.x; i < SZ4 + TB4; i += 256) dst[i] = i < SZ4 ? ld4(v8_img + 4 * i) : ld4(tb + 4 * (i - SZ4));
             __syncthreads();
         }
-        if (wave == 0) narrow_run_body<true, V8NB, (V8NB > 0)>(ops + run_lo, run_hi - run_lo, tile, lane, v8_at, v8_nops, v8_img, 0, reinterpret_cast<const float*>(img));
+        if (wave == 0) narrow_run_body<true, V8NB, (V8NB > 0 ? 1 : 0)>(ops + run_lo, run_hi - run_lo, tile, lane, v8_at, v8_nops, v8_img, 0, reinterpret_cast<const float*>(img));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                      // the run's stored tensors (skips, its last output) are visible to the whole workgroup
         tile_wide_ops(ops, run_hi, nops, tile, wave, lane, img, stats, vecs);
