@@ -743,6 +743,21 @@ __device__ __forceinline__ void coop_mma_refill(f32x16 (&acc)[1], const uint4* _
         }
 }
 
+// A chain of KSM steps whose plane registers are needed again right behind it (the next out tile of the same stage, the next stage): behind
+// the MFMAs of step S the planes of the NEXT chain's step S go into the registers step S has released -- requested KSM - 1 steps before
+// the next chain starts instead of behind this chain's last MFMA.  (k_resblock_bwd_c, round 5: with the request behind the chain and 256
+// registers in use hipcc reloaded every plane of the following chain right in front of its MFMAs -- sixteen exposed round trips.)
+template <int KSM>
+__device__ __forceinline__ void coop_mma_reload(f32x16 (&acc)[1], const uint4* __restrict__ img, HFrag<1> (&wf)[KSM], const uint4* __restrict__ wp_next,
+                                                int lane) {
+#pragma unroll
+    for (int S = 0; S < KSM; ++S) {
+        const h8 bhi = __builtin_bit_cast(h8, img[(size_t)(2 * S) * 64 + lane]), blo = __builtin_bit_cast(h8, img[(size_t)(2 * S + 1) * 64 + lane]);
+        mfma_step_h<1>(acc, wf[S], bhi, blo);
+        load_hfrag<1>(wf[S], wp_next + (size_t)S * 128, 0);
+    }
+}
+
 // (mean, M2) of a row over N = 32 * NT features from the per-slice (mean, M2) in `st` (Chan, equal counts)
 template <int NT>
 __device__ __forceinline__ void coop_merge_stats(const float2* __restrict__ st /* [NT][32] of this tile slot */, int j, float& mean, float& m2) {

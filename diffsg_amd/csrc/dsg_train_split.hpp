@@ -881,8 +881,7 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
     // ---- stage 2: d a2 = W2^T dh2, LN2 / SiLU backward with h1
 #pragma unroll
     for (int r = 0; r < 16; ++r) d[0][r] = 0.f;
-    coop_mma<KS>(d, Bimg, wf, KS, lane);
-    coop_load_w<KS>(wf, ah.W1Th + (size_t)w * KS * 128 + lane, KS);      // stage 1, first out tile (the in0 slice)
+    coop_mma_reload<KS>(d, Bimg, wf, ah.W1Th + (size_t)w * KS * 128 + lane, lane);      // + stage 1's planes, first out tile (the in0 slice)
     {
         const float post = sdinv * winv_of(2);
 #pragma unroll
@@ -918,9 +917,9 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
             const int T = t * NT + w;                                    // 32-feature out tile of dL/dx
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx[t][0][r] = 0.f;
-            coop_mma<KS>(dx[t], Bimg, wf, KS, lane);
-            if (t + 1 < DT) coop_load_w<KS>(wf, ah.W1Th + (size_t)(T + NT) * KS * 128 + lane, KS);
-            else if (SCLIN) coop_load_w<KS>(wf, ah.WscTh + (size_t)w * KS * 128 + lane, KS);
+            if (t + 1 < DT) coop_mma_reload<KS>(dx[t], Bimg, wf, ah.W1Th + (size_t)(T + NT) * KS * 128 + lane, lane);
+            else if (SCLIN) coop_mma_reload<KS>(dx[t], Bimg, wf, ah.WscTh + (size_t)w * KS * 128 + lane, lane);
+            else coop_mma<KS>(dx[t], Bimg, wf, KS, lane);
             const float post = sdinv * winv_of(1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx[t][0][r] *= post;
@@ -953,8 +952,8 @@ __global__ __launch_bounds__(256, 2) void k_resblock_bwd_c(const BlockBwdArgsH a
         for (int t = 0; t < DT; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx[t][0][r] *= pre;
-            coop_mma<KS>(dx[t], Bimg, wf, KS, lane);
-            if (t + 1 < DT) coop_load_w<KS>(wf, ah.WscTh + (size_t)(NT + w) * KS * 128 + lane, KS);
+            if (t + 1 < DT) coop_mma_reload<KS>(dx[t], Bimg, wf, ah.WscTh + (size_t)(NT + w) * KS * 128 + lane, lane);
+            else coop_mma<KS>(dx[t], Bimg, wf, KS, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx[t][0][r] *= post;
         }
