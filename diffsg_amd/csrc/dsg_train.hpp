@@ -214,6 +214,15 @@ __device__ __forceinline__ void ln_silu_bwd_acc(f32x16 (&da)[NT], const f32x16 (
                                                 float* __restrict__ cs_beta, float* __restrict__ cs_gamma) {
     constexpr int GB = CsBlock<NG>::GB;
     float s1 = 0.f, s2 = 0.f;
+    // narrow operators (NG <= 4: the fused narrow backward, one wave per SIMD): every group's vectors in one batch of loads pinned above
+    // the arithmetic -- read group by group each pair was an exposed round trip (load, full wait, four silu_grad, next pair: disassembly)
+    constexpr bool PREV = NG <= 4;
+    float4 gmA[PREV ? NG : 1], btA[PREV ? NG : 1];
+    if constexpr (PREV) {
+#pragma unroll
+        for (int G = 0; G < NG; ++G) { gmA[G] = ld4(gamma + 8 * G + 4 * h); btA[G] = ld4(beta + 8 * G + 4 * h); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int G0 = 0; G0 < NG; G0 += GB) {
         float db[GB * 4], dg[GB * 4];
@@ -221,7 +230,7 @@ __device__ __forceinline__ void ln_silu_bwd_acc(f32x16 (&da)[NT], const f32x16 (
         for (int Gl = 0; Gl < GB; ++Gl) {
             const int G = G0 + Gl;
             if (G < NG) {
-                const float4 gm = ld4(gamma + 8 * G + 4 * h), bt = ld4(beta + 8 * G + 4 * h);
+                const float4 gm = PREV ? gmA[PREV ? G : 0] : ld4(gamma + 8 * G + 4 * h), bt = PREV ? btA[PREV ? G : 0] : ld4(beta + 8 * G + 4 * h);
                 const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
