@@ -1,4 +1,7 @@
 #!/bin/bash
+# Same-box A-B-A-B-A-B of two source trees on the latency-bound shapes: the tree itself and a copy of an older one under ab_old/ (git archive <rev> |
+# tar -x -C ab_old, built there: ab_old/ is git-ignored but travels with gpurun).  Per round and tree: the T = 20 sample() call of MSR-3c 8 192 rows
+# (BASELINE config 2) and of MSR-80c 512 rows (tools/small_batch.py), and 40 training steps at 32 768 rows.   usage (GPU box): bash tools/ab_small.sh
 for r in 1 2 3; do
   for tree in ab_old .; do
     (cd $tree && echo "== $tree" && python3 tools/small_batch.py msr3 8192 2>&1 | grep "ms per" && python3 tools/small_batch.py msr80 512 2>&1 | grep "ms per" && PART_AB= python3 - <<'PY'
