@@ -1393,7 +1393,7 @@ struct V8TableSave {
 };
 
 // V8NB > 0: operators [v8_at, v8_at + v8_nops) of the run are the 8-wide bottom of the net (n_blocks = V8NB) and run on the vector unit in
-// float32 from the global image `v8_img` (dsg_narrow8.hpp); v8_store: the training forward (every tensor of the section is stored).
+// float32 from the section's image `v8_img` (dsg_narrow8.hpp; global, or staged in LDS by the caller: V8LDS); v8_store: the training forward (every tensor of the section is stored).
 // The run for ONE wave and its tile (k_fused_narrow_h below; k_unet_tile runs it on the first wave of a tile's workgroup).
 // V8LDS (k_unet_tile): the section's image and its blocks' slices of the step's time-table row were staged in LDS by the workgroup, at
 // `v8_lds` ([V8SecL::SIZE floats | (2 V8NB + 3) x 32 floats]); the caller guarantees one time-table row per launch (no per-row entries).
