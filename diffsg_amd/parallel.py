@@ -34,12 +34,14 @@ class global_renorm:
         self.ddpm, self._lib = ddpm, _lib
         self.reduce = reduce if reduce is not None else (lambda t: dist.all_reduce(t))
         self.error = None
+        self.n_reduced = 0            # reductions this rank has taken part in since __enter__
 
     def _callback(self, _user):
         # ctypes swallows an exception raised inside a callback: the rank would silently standardise with its local moments
         # while the others wait in the collective.  Keep it and re-raise once the library call has returned (`check`).
         try:
             self.reduce(self.stats)
+            self.n_reduced += 1
         except BaseException as e:  # noqa: BLE001 - re-raised in check()
             if self.error is None:
                 self.error = e
@@ -52,14 +54,21 @@ class global_renorm:
     def contribute_nothing(self):
         """A rank whose shard is empty launches nothing, but the other ranks wait in the renorm all-reduces: issue the same
         number of reductions (min(T, 4), MSR.py:136) with zero moments."""
-        for _ in range(min(self.ddpm.T, 4)):
+        self.contribute_remaining()
+
+    def contribute_remaining(self):
+        """Issue the reductions this rank still owes the group (all of them for an empty shard; the rest of them when its `sample` call
+        raised part-way): the other ranks wait in exactly min(T, 4) all-reduces."""
+        while self.n_reduced < min(self.ddpm.T, 4):
             self.stats.zero_()
             self.reduce(self.stats)
+            self.n_reduced += 1
 
     def __enter__(self):
         import ctypes
         dev = next(self.ddpm.model.parameters()).device
         self.stats = torch.zeros(3, device=dev, dtype=torch.float64)
+        self.n_reduced = 0
         self.cb = self._lib.RENORM_REDUCE_FN(self._callback)
         hd = self.ddpm.model.native_handle()
         self._lib.check(self._lib.lib().dsg_set_renorm_hook(hd, self._lib.ptr(self.stats), ctypes.cast(self.cb, ctypes.c_void_p), None))
@@ -80,14 +89,30 @@ def sample_sharded(ddpm, cond_all, omega=1.0, gather=False, global_renorm_stats=
     `cond_all`.  With gather=True the shards are all-gathered afterwards (a convenience for evaluation, outside the path)."""
     rank, ws = world()
     lo, hi = shard_rows(cond_all.shape[0], rank, ws)
+    err, y = None, None
     if global_renorm_stats and ws > 1:
         with global_renorm(ddpm) as gr:
+            try:
+                y = ddpm.sample(cond_all[lo:hi], omega, **kw)
+                if hi == lo:
+                    gr.contribute_nothing()
+                gr.check()
+            except Exception as e:  # noqa: BLE001 - re-raised below, on every rank
+                # this rank failed before (or between) its renorm reductions: the others are waiting in them -- pay what is owed, then
+                # tell them (VERDICT r5, next 6).  A failure of the reduction itself is not retried: the group is gone.
+                err = e
+                if gr.error is None:
+                    gr.contribute_remaining()
+                gr.error = None
+    elif ws > 1 and gather:
+        try:
             y = ddpm.sample(cond_all[lo:hi], omega, **kw)
-            if hi == lo:
-                gr.contribute_nothing()
-            gr.check()
+        except Exception as e:  # noqa: BLE001 - the other ranks would wait in the all-gather below
+            err = e
     else:
         y = ddpm.sample(cond_all[lo:hi], omega, **kw)
+    if ws > 1 and (global_renorm_stats or gather):
+        raise_everywhere(err, cond_all.device, "sample_sharded")
     if not gather or ws == 1:
         return y
     sizes = [shard_rows(cond_all.shape[0], r, ws) for r in range(ws)]
@@ -97,6 +122,19 @@ def sample_sharded(ddpm, cond_all, omega=1.0, gather=False, global_renorm_stats=
     parts = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(parts, pad)
     return torch.cat([p[: b - a] for p, (a, b) in zip(parts, sizes)])
+
+
+def raise_everywhere(err, device, where):
+    """A call that holds collectives must fail on every rank or on none: all-reduce(MAX) of "this rank failed"; the failing rank
+    re-raises its own exception, the others raise a RuntimeError that says so.  No-op when nobody failed."""
+    rank, ws = world()
+    if ws > 1:
+        t = torch.tensor([1.0 if err is not None else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if err is None and t.item() > 0:
+            raise RuntimeError(f"{where}: the call failed on another rank of {ws}; this rank's result is discarded")
+    if err is not None:
+        raise err
 
 
 def broadcast_parameters(module, src=0):

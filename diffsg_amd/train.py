@@ -148,6 +148,34 @@ def sync_replicas(diffusion_model):
             m.mark_weights_changed()
 
 
+def step_health(diffusion_model, loss_value, device, world, where=""):
+    """Raise FloatingPointError on EVERY rank if ANY rank's step was invalid: its fp16 range flag is set (`UNet1D.range_exceeded`, the twin
+    handle's included) or its loss is not finite.  world > 1: one all-reduce(MAX) of two scalars (gloo / RCCL), issued by every rank in
+    every step -- the healthy path pays a 8-byte collective behind the gradient bucket's, a failing rank can no longer leave the job
+    hanging in the next step's gradient all-reduce."""
+    import math
+    model = diffusion_model.model
+    bad_range = bool(hasattr(model, "range_exceeded") and model.range_exceeded())
+    bad_loss = not math.isfinite(loss_value)
+    here = (bad_range, bad_loss)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([float(bad_range), float(bad_loss)], dtype=torch.float32, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bad_range, bad_loss = bool(t[0].item() > 0), bool(t[1].item() > 0)
+    if not (bad_range or bad_loss):
+        return
+    who = "this rank" if any(here) else "another rank"
+    what = []
+    if bad_range:
+        what.append("an activation of the training step left the fp16 range of the split-f16 path (|x| > 6e4; the float32 reference "
+                    "has no such limit): scale the targets, or train with model.set_precision('f32')")
+    if bad_loss:
+        what.append("the loss is not finite")
+    raise FloatingPointError(f"{where}: invalid training step on {who} of {world}: " + "; ".join(what) +
+                             ".  The gradients of this step and the update made from them are invalid on every rank")
+
+
 def run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, warmup_epoch, device, log=print):
     from . import parallel
     rank, world = parallel.world()
@@ -169,14 +197,14 @@ def run_epochs(diffusion_model, loader, optimizer, scheduler, epochs, use_ema, w
             if (use_ema and epoch > warmup_epoch and ema_step_cnt > diffusion_model.ema_start
                     and ema_step_cnt % diffusion_model.ema_update_rate == 0):
                 diffusion_model.ema.update_parameters(diffusion_model.model)
-            epoch_loss += loss.item()
-            # loss.item() has just synchronised: reading the fp16 range flag of the split-f16 path costs nothing more.  A step whose
-            # raw operands left fp16's range saturated silently where the reference would print inf / NaN: the
-            # update it made is wrong, so stop here and say what to do.
-            if hasattr(diffusion_model.model, "range_exceeded") and diffusion_model.model.range_exceeded():
-                raise FloatingPointError(
-                    f"epoch {epoch}: an activation of the training step left the fp16 range of the split-f16 path (|x| > 6e4); the "
-                    "gradients of this step are invalid.  Scale the targets, or train with model.set_precision('f32')")
+            loss_value = loss.item()
+            epoch_loss += loss_value
+            # loss.item() has just synchronised: reading the fp16 range flag of the split-f16 path costs nothing more.  A step whose raw
+            # operands left fp16's range saturated silently (the float32 reference is fine at |x| > 6e4): its gradients, and the update
+            # just made from them, are wrong -- stop and say what to do.  Data parallel: EVERY rank takes part in step_health's
+            # two-scalar all-reduce(MAX) and every rank raises in the same step; a rank that raised alone would leave the others
+            # waiting in the next gradient all-reduce.  The gradient bucket stays the step's only large message.
+            step_health(diffusion_model, loss_value, device, world, where=f"epoch {epoch}")
             epoch_rows += x.shape[0]
             ema_step_cnt += 1
         # the reference prints (sum of batch-mean losses) / (row count), MSR.py:233 -- reproduced as is

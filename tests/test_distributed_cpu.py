@@ -118,6 +118,73 @@ def _worker(rank, ws, port, q):
         after = d2.model.final.weight.detach().clone()
         dist.all_gather(ws_, after)
         assert torch.equal(ws_[0], ws_[1]) and not torch.equal(after, before)
+        # ---- healthy path: per step exactly ONE gradient-bucket all-reduce, plus step_health's two scalars
+        sizes_seen = []
+        orig_ar = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (sizes_seen.append(t.numel()), orig_ar(t, *a, **k))[1]
+        tr.run_epochs(d2, loader, opt, sched, 1, False, 5, torch.device("cpu"), logs.append)
+        dist.all_reduce = orig_ar
+        assert sizes_seen == [total2, 2, total2, 2], sizes_seen
+        # ---- a failing rank fails the JOB, in the same step, instead of leaving the others in the next gradient all-reduce: rank 1 reports
+        # a set fp16 range flag -> both ranks raise FloatingPointError, each after exactly one step
+        seen.clear()
+        d2.model.range_exceeded = lambda: rank == 1
+        try:
+            tr.run_epochs(d2, loader, opt, sched, 1, False, 5, torch.device("cpu"), logs.append)
+            raise AssertionError("run_epochs returned although rank 1 reported a set range flag")
+        except FloatingPointError as e:
+            assert len(seen) == 1 and ("this rank" in str(e)) == (rank == 1) and "fp16 range" in str(e), str(e)
+        del d2.model.range_exceeded
+        # ... and a non-finite loss on one rank
+        seen.clear()
+        real_forward = d2.forward
+
+        def nan_forward(y, cond):
+            out = real_forward(y, cond)
+            return out * float("nan") if rank == 0 else out
+        d2.forward = nan_forward
+        try:
+            tr.run_epochs(d2, loader, opt, sched, 1, False, 5, torch.device("cpu"), logs.append)
+            raise AssertionError("run_epochs returned although rank 0's loss was NaN")
+        except FloatingPointError as e:
+            assert len(seen) == 1 and "not finite" in str(e), str(e)
+        d2.forward = real_forward
+        # ---- sharded sampling with collectives inside or behind the call: a rank whose sample() raises must not leave the others waiting
+        class Failing:
+            T = 20
+
+            def sample(self, cond, omega=1.0, **kw):
+                gr = getattr(self, "gr", None)
+                for k in range(4):                   # the library calls the hook on each of the min(T, 4) early steps
+                    if gr is not None:
+                        gr.stats.fill_(1.0)
+                        gr._callback(None)
+                    if rank == 1 and k == 0:
+                        raise ValueError("rank 1 fails after its first renorm reduction")
+                return cond * 2.0
+        fail = Failing()
+        for kw in ({"gather": True}, {"global_renorm_stats": True}, {"global_renorm_stats": True, "gather": True}):
+            class FakeRenorm(par.global_renorm):     # the real bookkeeping (n_reduced, contribute_remaining, check) without the library
+                def __enter__(self):
+                    self.stats = torch.zeros(3, dtype=torch.float64)
+                    self.n_reduced = 0
+                    fail.gr = self if "global_renorm_stats" in kw else None
+                    return self
+
+                def __exit__(self, *exc):
+                    fail.gr = None
+                    return False
+            real_gr, par.global_renorm = par.global_renorm, FakeRenorm
+            try:
+                par.sample_sharded(fail, cond_all, 0.5, **kw)
+                raise AssertionError(f"sample_sharded({kw}) returned although rank 1 failed")
+            except ValueError as e:
+                assert rank == 1 and "rank 1 fails" in str(e)
+            except RuntimeError as e:
+                assert rank == 0 and "another rank" in str(e), str(e)
+            finally:
+                par.global_renorm = real_gr
+        dist.barrier()                               # both ranks are past every collective of the failed calls: nothing is left pending
         # ---- the evidence a multi-rank bench line carries (bench.py): every rank counted, per-rank rates gathered, and the
         # post-all-reduce bucket identical bit for bit on every rank -- and the check FAILS when one rank's bucket differs
         ev = par.run_evidence(torch.device("cpu"), 0.5 + 0.25 * rank, 10)
