@@ -242,6 +242,36 @@ def test_table_driven_kernels_issue_no_flat_memory_instructions(tmp_path):
     assert not bad, bad
 
 
+def test_no_partial_register_write_hazard_behind_the_fp16_split():
+    """`split_pair_nowait` (csrc/dsg_split.hpp) drops the wait state behind v_fma_mixhi_f16, which writes HALF a
+    register; on gfx940+ a vector / matrix instruction issued directly behind it that names that register reads the OLD contents, and
+    hipcc does not pad inline asm.  The call sites place something else there by construction, but the asm is not pinned: this check
+    disassembles every kernel of the built library and requires that no v_fma_mixhi_f16 is directly followed by a v_* instruction that
+    mentions its destination (tools/isa_lint.py, mixhi_hazards).  Runs on the CPU on every build."""
+    import importlib.util
+    from diffsg_amd import _lib
+    _lib.build()
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not found")
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    # the checker itself: a dependent pair is caught, a separated pair and an independent neighbour are not
+    assert lint.mixhi_hazards(["v_fma_mixhi_f16 v5, v1, 1.0, -v2 op_sel:[0,0,1]", "v_pk_mul_f32 v[8:9], v[4:5], v[6:7]"])
+    assert lint.mixhi_hazards(["v_fma_mixhi_f16 v5, v1, 1.0, -v2", "v_mfma_f32_32x32x16_f16 a[0:15], v[2:5], v[6:9], a[0:15]"])
+    assert not lint.mixhi_hazards(["v_fma_mixhi_f16 v5, v1, 1.0, -v2", "s_nop 0", "v_mov_b32_e32 v6, v5"])
+    assert not lint.mixhi_hazards(["v_fma_mixhi_f16 v5, v1, 1.0, -v2", "v_mov_b32_e32 v6, v15"])
+    dis = lint.disassemble(_lib.LIB_PATH)
+    n_mixhi, bad = 0, {}
+    for name, ins in lint.kernels(dis):
+        n_mixhi += sum(1 for t in ins if t.startswith("v_fma_mixhi_f16"))
+        hz = lint.mixhi_hazards(ins)
+        if hz:
+            bad[name] = [(a, b) for _, a, b in hz[:3]]
+    assert n_mixhi > 1000, n_mixhi            # the split is in every split-path kernel: the disassembly was read
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("group", ["sampling_step", "other_hot", "f32_step"])
 def test_hot_kernels_use_no_scratch_memory(group):
     """Compiled with -Rpass-analysis=kernel-resource-usage (diffsg_amd/_lib.build keeps hipcc's remarks beside the library): every

@@ -57,6 +57,32 @@ def kernels(dis):
         yield name, ins
 
 
+def _vregs(operand_text):
+    """VGPR numbers named in an operand list: v7, v[4:7] (accumulators a[..] are a different file)."""
+    regs = set()
+    for m in re.finditer(r"(?<![a-z_0-9])v(\d+)\b", operand_text):
+        regs.add(int(m.group(1)))
+    for m in re.finditer(r"(?<![a-z_0-9])v\[(\d+):(\d+)\]", operand_text):
+        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return regs
+
+
+def mixhi_hazards(ins):
+    """gfx940+ "dst_sel forwarding" hazard: v_fma_mixhi_f16 writes HALF of its destination register; a vector or matrix
+    instruction issued directly behind it that names that register gets the old contents.  hipcc pads the pairs it emits itself, not
+    inline asm (split_pair closes with s_nop 0; split_pair_nowait relies on its call site): list every v_fma_mixhi_f16 whose NEXT
+    instruction is a v_* instruction mentioning its vdst.  Any instruction in between (s_nop, scalar, memory) is the wait state."""
+    bad = []
+    for k, t in enumerate(ins[:-1]):
+        if not t.startswith("v_fma_mixhi_f16"):
+            continue
+        m = re.match(r"v_fma_mixhi_f16\s+v(\d+)\s*,", t)
+        nxt = ins[k + 1]
+        if m and nxt.startswith("v_") and int(m.group(1)) in _vregs(nxt.split(None, 1)[1] if " " in nxt else ""):
+            bad.append((k, t, nxt))
+    return bad
+
+
 def demangle(names):
     if not FILT:
         return {n: n for n in names}
@@ -68,9 +94,13 @@ def main():
     want = sys.argv[1:]
     dis = disassemble(os.path.join(ROOT, "diffsg_amd", "libdiffsg_hip.so"))
     rows = []
+    hazards = {}
     for name, ins in kernels(dis):
         if not name.startswith("_ZN3dsg"):
             continue
+        hz = mixhi_hazards(ins)
+        if hz:
+            hazards[name] = hz
         ops = Counter(i.split()[0] for i in ins)
         waits = [k for k, i in enumerate(ins) if i.startswith("s_waitcnt")]
         vm0 = [k for k in waits if "vmcnt(0)" in ins[k]]
@@ -85,6 +115,12 @@ def main():
         if want and not any(w in dn for w in want):
             continue
         print(f"{dn[:72]:72s} {r[1]:6d} {r[2]:5d} {r[3]:7d} {r[4]:4d} {r[5]:5d} {r[6]:5d} {r[7]:4d} {r[8]:5d} {r[9]:8d}")
+
+
+    print(f"v_fma_mixhi_f16 -> dependent vector instruction with no wait state between them: {sum(len(v) for v in hazards.values())} in {len(hazards)} kernel(s)")
+    for name, hz in hazards.items():
+        for k, a, b in hz[:4]:
+            print(f"  HAZARD {names.get(name, name)[:60]} @{k}: {a}  ->  {b}")
 
 
 if __name__ == "__main__":
