@@ -1052,9 +1052,8 @@ int prepare_fused(dsg_handle* h, const RunCtx& c, hipStream_t s) {
             const unsigned tb_now = tb_first < 0 ? 0 : (unsigned)(tb_last_end - tb_first) / 4;
             if (used + need + tb_now + need_tb > (unsigned)kNarrowLdsU4) {
                 close_phase(i);
-                // the running tensor crosses the boundary through memory
-                if (s_lo >= 0 && i == s_hi) h->nlds_phases.back().v8_store = 1;
-                else lops[i - 1].store_out = 1;
+                // (round 6: one launch walks every phase, the running tensor crosses the boundary in registers)
+                if ((int)h->nlds_phases.size() >= kNarrowMaxPhases) { fits = false; break; }
                 phase_base.push_back(image_base);
                 phase_lo = i; used = 0; tb_first = -1; tb_last_end = 0;
             }
@@ -1156,13 +1155,15 @@ int launch_fused(const dsg_handle* h, const RunCtx& c, hipStream_t s) {
         if (!c.train && !c.ts && h->nlds_valid && ntiles >= h->panel_min_tiles && ntiles > h->narrow_small_max_tiles) {
             // large sampling launch: the run's planes and vectors resident in LDS, one launch per phase (dsg_split.hpp)
             const int v8nb = (h->opt_v8 && h->v8_lo >= 0) ? h->d.n_blocks : 0;
-            for (const auto& ph : h->nlds_phases) {
-                const dim3 g(cdiv(ntiles, 16)), b(1024);
-                const NarrowLdsOp* lops = h->nlds_ops_dev;
-                if (v8nb == 2) hipLaunchKernelGGL(k_fused_narrow_lds<2>, g, b, 0, s, tab, lops, ph, ntiles, c.step_ptr, h->tb_stride);
-                else if (v8nb == 3) hipLaunchKernelGGL(k_fused_narrow_lds<3>, g, b, 0, s, tab, lops, ph, ntiles, c.step_ptr, h->tb_stride);
-                else hipLaunchKernelGGL(k_fused_narrow_lds<0>, g, b, 0, s, tab, lops, ph, ntiles, c.step_ptr, h->tb_stride);
-            }
+            NarrowPhases P;
+            memset(&P, 0, sizeof P);
+            P.n = (int)h->nlds_phases.size();
+            for (int k = 0; k < P.n; ++k) P.p[k] = h->nlds_phases[k];
+            const dim3 g(cdiv(ntiles, 16)), b(1024);
+            const NarrowLdsOp* lops = h->nlds_ops_dev;
+            if (v8nb == 2) hipLaunchKernelGGL(k_fused_narrow_lds<2>, g, b, 0, s, tab, lops, P, ntiles, c.step_ptr, h->tb_stride);
+            else if (v8nb == 3) hipLaunchKernelGGL(k_fused_narrow_lds<3>, g, b, 0, s, tab, lops, P, ntiles, c.step_ptr, h->tb_stride);
+            else hipLaunchKernelGGL(k_fused_narrow_lds<0>, g, b, 0, s, tab, lops, P, ntiles, c.step_ptr, h->tb_stride);
             return h->nlds_tail ? 1 : 0;
         }
         // the 8-wide bottom of the net on the vector unit (float32, dsg_narrow8.hpp) from the global image: sampling launches below the
@@ -2932,7 +2933,7 @@ int dsg_time_op(dsg_handle* h, int op, int B, int iters, float* ms_avg, void* st
 //                       of the block kernels -- in 1e9 (MFMA + 6 vector) slots per second over the chip;
 //   out[2] copy_gbs     a 256 MiB float4 copy inside a buffer allocated for the call (read + written bytes per second);
 //   out[3] panel_gslots the frozen miniature of the panel kernels' load profile (k_calib_panel), 1e9 MFMA slots per second.
-int dsg_box_calibrate(float* out3, void* stream) {
+int dsg_box_calibrate(float* out3 /* four floats */, void* stream) {
     if (!out3) return fail("dsg_box_calibrate: null output");
     hipStream_t s = (hipStream_t)stream;
     hipDeviceProp_t prop;
@@ -2940,12 +2941,16 @@ int dsg_box_calibrate(float* out3, void* stream) {
     HIPCK(hipGetDevice(&devid));
     HIPCK(hipGetDeviceProperties(&prop, devid));
     const int cus = prop.multiProcessorCount;
-    hipEvent_t e0, e1;
-    HIPCK(hipEventCreate(&e0));
-    HIPCK(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float* sink = nullptr;
     const size_t copy_bytes = (size_t)256 << 20;
     char* buf = nullptr;
+    struct Guard {          // every early return below (a failed 512 MiB allocation beside a large batch) frees what exists
+        hipEvent_t &a, &b; float*& s; char*& c;
+        ~Guard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); if (s) (void)hipFree(s); if (c) (void)hipFree(c); }
+    } guard{e0, e1, sink, buf};
+    HIPCK(hipEventCreate(&e0));
+    HIPCK(hipEventCreate(&e1));
     HIPCK(hipMalloc(&sink, (size_t)cus * 2 * 512 * sizeof(float)));
     HIPCK(hipMalloc(&buf, 2 * copy_bytes));
     hipLaunchKernelGGL(dsg::k_calib_fill, dim3(cus * 8), dim3(256), 0, s, reinterpret_cast<uint4*>(buf), 2 * copy_bytes / 16);
@@ -2981,10 +2986,6 @@ int dsg_box_calibrate(float* out3, void* stream) {
                                              reinterpret_cast<const uint4*>(buf + copy_bytes), copy_bytes / 16 - 1, panels, sink); }, msp)) return 1;
         out3[3] = (float)((double)cus * 8 * panels * 48 / (msp * 1e-3) / 1e9);
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(sink);
-    (void)hipFree(buf);
     return 0;
 }
 

@@ -462,7 +462,7 @@ __device__ __forceinline__ void globalize(BlockArgsH& a) {
 // XOUT: the output goes (back) into `xr`; it is stored only when `store_out` (something outside this wave reads it).
 constexpr int kLnLdsW1 = 272, kLnLdsN = 128;   // LDS copy of the LayerNorm vectors: stage-1 width (<= 256 + pad), block width
 
-template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN, bool PRE = false, bool LDSLN = false>
+template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN, bool PRE = false, bool LDSLN = false, bool PC = false>
 __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane, f32x16 (*xr)[(N + 31) / 32] = nullptr,
                                                 float* xr_mean = nullptr, float* xr_m2 = nullptr, bool store_out = true,
                                                 const float* lnp = nullptr, int entry_pre = -1) {
@@ -521,11 +521,17 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         load_vec4<NT, NG>(vtb, a.tbias + (size_t)entry * a.tb_stride, h);
         load_vec4<NT, NG>(vc2, a.c2, h);
         load_vec4<NT, NG>(vc3, a.c3, h);
+    }
+    if (PRE || PC) {
+        // PC (round 6, the LDS form of the narrow run): the block's condition embedding is a row-dependent stream from HBM (329 MB per step
+        // over all blocks: nothing of it is cached) -- requested here, two stages before it is added
         if (tile >= a.uncond_tiles) {
             const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
 #pragma unroll
             for (int G = 0; G < NG; ++G) vcp[G] = ld4(cp + (size_t)G * 256);
         }
+    }
+    if (PRE) {
         const size_t s1 = (size_t)KS1 * 128, s2 = (size_t)(((N + 7) / 8 + 1) / 2) * 128;
         load_hfrag<NT>(p1a, ah.W1h + lane, s1);
         if (a.in1.groups) load_hfrag<NT>(p1b, ah.W1h + (size_t)ks0 * 128 + lane, s1);
@@ -585,7 +591,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
-            const float4 cv = PRE ? vcp[G] : ld4(cp + (size_t)G * 256);
+            const float4 cv = (PRE || PC) ? vcp[G] : ld4(cp + (size_t)G * 256);
             acc2[G >> 2][4 * (G & 3) + 0] += cv.x; acc2[G >> 2][4 * (G & 3) + 1] += cv.y;
             acc2[G >> 2][4 * (G & 3) + 2] += cv.z; acc2[G >> 2][4 * (G & 3) + 3] += cv.w;
         }
@@ -1370,6 +1376,63 @@ __device__ __forceinline__ void linear_reg_out_h(const LinArgsH& ah, const int t
                 make_float4(acc[G >> 2][4 * (G & 3)], acc[G >> 2][4 * (G & 3) + 1], acc[G >> 2][4 * (G & 3) + 2], acc[G >> 2][4 * (G & 3) + 3]));
 }
 
+// The Linear that OPENS the narrow run (Downsample 64 -> 32 of the shipped nets): input from a fragment tensor in memory (<= 8 groups), output
+// (<= 32 wide) in registers.  Round 6 (profiles/r06_narrow_op_stamps.txt): as "linear_body_h, wait for its stores, read the result back" the
+// operator took 20 000 cycles of a 175 000-cycle launch -- five dependent memory round trips (its k16-step loop prefetches one step ahead,
+// then store -> reload) for a handful of MFMAs.  Here every input group is requested at once -- by the LDS kernel BEFORE it stages its image,
+// so the loads fly under the staging -- and the result never leaves the registers (it is stored only because it is a skip tensor).
+// Same operands, same products in the same order, same statistics as linear_body_h: same bits.
+constexpr int kLinPreG = 8;
+struct LinPre { float4 x[kLinPreG]; float2 st; };
+__device__ __forceinline__ void linear_mem_prefetch(LinPre& p, const LinArgs& a /* globalized */, const int tile, const int lane) {
+    const int j = lane & 31;
+    const size_t t = (size_t)seg_tile(a.in, tile);
+    p.st = make_float2(0.f, 0.f);
+    if (a.in.stats) p.st = reinterpret_cast<const float2*>(a.in.stats)[t * 32 + j];
+    const float* xp = a.in.data + t * a.in_groups * 256 + lane * 4;
+#pragma unroll
+    for (int G = 0; G < kLinPreG; ++G) {       // unconditional loads: a group that does not exist re-reads the last one (and is zeroed below)
+        const int g = G < a.in_groups ? G : a.in_groups - 1;
+        p.x[G] = ld4(xp + (size_t)g * 256);
+    }
+}
+__device__ __forceinline__ void linear_pre_to_reg_h(const LinArgsH& ah, const LinPre& p, const int tile, const int lane, f32x16 (&x)[1], float& xmean,
+                                                    float& xm2, const bool store_out) {
+    const LinArgs& a = ah.l;
+    const int h = lane >> 5, j = lane & 31;
+    const int groups = a.in_groups, steps = (groups + 1) >> 1;
+    const size_t nt_stride = (size_t)steps * 128;
+    if (a.range_flag && a.in.stats) range_check(a.range_flag, p.st.x, p.st.y);
+    f32x16 acc[1];
+#pragma unroll
+    for (int S = 0; S < kLinPreG / 2; ++S) {
+        if (S < steps) {
+            HFrag<1> w;
+            load_hfrag<1>(w, ah.Wh + (size_t)S * 128 + lane, nt_stride);
+            const float4 x0 = p.x[2 * S];
+            float4 x1 = p.x[2 * S + 1];
+            if (2 * S + 1 >= groups) x1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float v[8] = {kRawScale * x0.x, kRawScale * x0.y, kRawScale * x0.z, kRawScale * x0.w,
+                                kRawScale * x1.x, kRawScale * x1.y, kRawScale * x1.z, kRawScale * x1.w};
+            h8 bhi, blo;
+            split8(v, bhi, blo);
+            if (S == 0) mfma_step_h0<1>(acc, w, bhi, blo);
+            else mfma_step_h<1>(acc, w, bhi, blo);
+        }
+    }
+    acc_unscale_add<1>(acc, ah.kc[0], a.bias, h);
+    const int NG = (a.out_width + 7) / 8;
+    float m, q;
+    lin_out_stats<1>(acc, h, a.out_width, a.inv_out_w, m, q);
+    x[0] = acc[0]; xmean = m; xm2 = q;
+    if (store_out) {
+        if (h == 0) reinterpret_cast<float2*>(a.out_stats)[(size_t)tile * 32 + j] = make_float2(m, q);
+#pragma unroll
+        for (int G = 0; G < 4; ++G)
+            if (G < NG) st4(a.out + ((size_t)tile * NG + G) * 256 + lane * 4, make_float4(acc[0][4 * G], acc[0][4 * G + 1], acc[0][4 * G + 2], acc[0][4 * G + 3]));
+    }
+}
+
 // What the training forward keeps of the float32 section for the backward pass: every operator's output with its row statistics and the
 // blocks' pre-LayerNorm tensors, at the places the matrix-core forms write them (8-wide fragment tensors: one float4 per lane).
 struct V8TableSave {
@@ -1609,31 +1672,76 @@ struct NarrowPhaseArgs {
     unsigned v8_sec, v8_tb;
 };
 
+constexpr int kNarrowMaxPhases = 4;
+struct NarrowPhases { NarrowPhaseArgs p[kNarrowMaxPhases]; int n; };
+
+// Round 6: ONE launch for the whole run.  The phases (images that fit the LDS) are staged one after the other by the same workgroup, a
+// workgroup barrier on either side; the running tensor stays in registers across a phase boundary (rounds 2-5: one launch per phase, the
+// tensor through memory -- per-operator stamps, profiles/r06_narrow_op_stamps.txt: 10 000 + 5 500 cycles of staging, a launch ramp per
+// phase and a 5 000-cycle reload in front of the second phase's first operator).  The run's opening Linear requests its whole input
+// before the first image is staged (linear_mem_prefetch).
 template <int V8NB>    // n_blocks of the float32 section the plan may contain (0: none; one instance per shape keeps one copy of the section in the kernel)
-__global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __restrict__ ops, const NarrowLdsOp* __restrict__ lops, const NarrowPhaseArgs ph,
+__global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __restrict__ ops, const NarrowLdsOp* __restrict__ lops, const NarrowPhases P,
                                                               int ntiles, const int* step_ptr, int tb_stride) {
     __shared__ uint4 lds[kNarrowLdsU4];
-    {   // the phase's image: every thread copies 16-byte pieces, one piece in flight per thread.  More loads in flight per thread
-        // are SLOWER here (same box, us per launch: 1 or 2 pieces 75.3, 4 pieces 80.7, all ten 84.3): 256 workgroups pull the same
-        // 75-150 KiB from L2 at the same moment, and the burst costs more than the round trips it saves.  The staging is 7 us of a
-        // phase's 60 / 89 us (same box, staging skipped: 53 / 82).
-        const uint4* tbs = reinterpret_cast<const uint4*>(ph.tb + (size_t)(step_ptr ? *step_ptr : 0) * tb_stride);
-        for (unsigned i = threadIdx.x; i < ph.n_u4; i += blockDim.x) lds[i] = ph.image[i];
-        for (unsigned i = threadIdx.x; i < ph.tb_u4; i += blockDim.x) lds[ph.n_u4 + i] = tbs[i];
-    }
-    const int op_lo = ph.op_lo, op_hi = ph.op_hi;
-    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (tile >= ntiles) return;
+    const int tile_raw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const bool active = tile_raw < ntiles;                 // every wave of the workgroup meets the staging barriers
+    const int tile = active ? tile_raw : ntiles - 1;
+#ifdef DSG_CYCLE_STAMPS
+    DSG_STAMP(blockIdx.x == 0 && threadIdx.x < 64, 0x400);
+#endif
     const float* const ldsf = reinterpret_cast<const float*>(lds);
     f32x16 x[1];
     float xmean = 0.f, xm2 = 0.f;
     bool have_x = false;
     const int lane_id = lane;
+    // the run's opening operator, when it is a Linear fed from memory: its input on the way before anything else
+    LinPre pre;
+    const int first = P.p[0].op_lo;
+    const bool pre_lin = ops[first].kind == 1 && ops[first].l.l.in_groups <= kLinPreG && !(V8NB > 0 && P.p[0].v8_at == first);
+    if (pre_lin) {
+        LinArgs l0 = ops[first].l.l;
+        globalize_io(l0);
+        linear_mem_prefetch(pre, l0, tile, lane);
+    }
+    // the phase's image: every thread copies 16-byte pieces, one piece in flight per thread.  More loads in flight per thread
+    // are SLOWER here (same box, us per launch: 1 or 2 pieces 75.3, 4 pieces 80.7, all ten 84.3): 256 workgroups pull the same
+    // 75-150 KiB from L2 at the same moment, and the burst costs more than the round trips it saves.
+    auto stage = [&](const NarrowPhaseArgs& ph) {
+        const uint4* tbs = reinterpret_cast<const uint4*>(ph.tb + (size_t)(step_ptr ? *step_ptr : 0) * tb_stride);
+        for (unsigned i = threadIdx.x; i < ph.n_u4; i += blockDim.x) lds[i] = ph.image[i];
+        for (unsigned i = threadIdx.x; i < ph.tb_u4; i += blockDim.x) lds[ph.n_u4 + i] = tbs[i];
+    };
+    stage(P.p[0]);
+    __syncthreads();
+    DSG_STAMP(tile_raw == 0, 0x401);
+    int i_first = first;
+    if (pre_lin) {
+        // the run's opening Linear, OUTSIDE the operator loops (inside them its 34 prefetch registers would stay live across the whole run)
+        DSG_STAMP(tile_raw == 0, 0x410 + first);
+        LinArgsH l = ops[first].l;
+        const NarrowLdsOp lo = lops[first];
+        l.Wh = lds + lo.w1; l.l.bias = ldsf + lo.c2;
+        globalize<true>(l);
+        linear_pre_to_reg_h(l, pre, tile, lane, x, xmean, xm2, active && lo.store_out != 0);
+        have_x = true;
+        i_first = first + 1;
+    }
+#pragma unroll 1
+    for (int pi = 0; pi < P.n; ++pi) {
+    const NarrowPhaseArgs& ph = P.p[pi];
+    if (pi > 0) {
+        __syncthreads();              // every wave is done with the previous image
+        stage(ph);
+        __syncthreads();
+        DSG_STAMP(tile_raw == 0, 0x401);
+    }
+    const int op_hi = ph.op_hi;
+    if (!active) continue;
     // The float32 section sits BETWEEN two runs of the operator loop, not inside it (`part`): as one more case of the loop body it made
     // hipcc keep two 16-register tuples of the matrix-core operators in scratch memory.
-    int i = op_lo;
+    int i = pi == 0 ? i_first : ph.op_lo;
 #pragma unroll 1
     for (int part = 0; part < 2; ++part) {
     const int stop = (V8NB > 0 && part == 0 && ph.v8_at >= 0) ? ph.v8_at : op_hi;
@@ -1642,10 +1750,11 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
         asm volatile("" : "+v"(lane));
         const int h = lane >> 5, j = lane & 31;
         const FusedOpH& op = ops[i];
+        DSG_STAMP(tile_raw == 0, 0x480);
         {
             // the 8-wide bottom of the net on the vector unit: Downsample 16 -> 8 ... Upsample 8 -> 16, skip tensors in registers
             const LinArgs& la = op.l.l;
-            if (!have_x) {                           // first operator of the phase: its 16-wide input comes from memory
+            if (!have_x) {                           // first operator of the run: its 16-wide input comes from memory
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1663,7 +1772,7 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             float xo[8];
             v8_section<(V8NB > 0 ? V8NB : 2)>(S, tb0, sc, tile, lane, xi, xo, xmean, xm2, V8NoSave{});
             x[0] = f32x16{xo[0], xo[1], xo[2], xo[3], xo[4], xo[5], xo[6], xo[7], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (ph.v8_store) {                       // the section ends the phase: hand the 16-wide tensor on through memory
+            if (ph.v8_store) {                       // something outside this wave reads the section's 16-wide output
                 const LinArgs& lz = ops[i + ph.v8_nops - 1].l.l;
                 if (h == 0) reinterpret_cast<float2*>(as_global(lz.out_stats))[(size_t)tile * 32 + j] = make_float2(xmean, xm2);
 #pragma unroll
@@ -1680,6 +1789,7 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
         int lane = lane_id;
         asm volatile("" : "+v"(lane));
         const int h = lane >> 5, j = lane & 31;
+        DSG_STAMP(tile_raw == 0, 0x410 + i);
         const FusedOpH& op = ops[i];
         const NarrowLdsOp lo = lops[i];
         if (op.kind == 0) {
@@ -1689,7 +1799,7 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             b.b.gamma3 = ldsf + lo.g3; b.b.beta3 = ldsf + lo.b3; b.b.c2 = ldsf + lo.c2; b.b.c3 = ldsf + lo.c3;
             b.b.tbias = ldsf + lo.tb;            // the staged row of this step: entry 0
             globalize<true>(b);
-            if (!have_x) {  // first operator of the phase: bring its (<= 32 wide) input into registers once
+            if (!have_x) {  // first operator of the run: bring its (<= 32 wide) input into registers once
                 const Seg& s0 = b.b.in0;
                 const float2 st = reinterpret_cast<const float2*>(s0.stats)[(size_t)seg_tile(s0, tile) * 32 + j];
                 xmean = st.x; xm2 = st.y;
@@ -1701,7 +1811,7 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
                 }
                 have_x = true;
             }
-            // skip tensors were stored by this wave earlier in the run (possibly in an earlier launch): make sure this wave's stores have landed
+            // skip tensors were stored by this wave earlier in the run: make sure this wave's stores have landed
             if (b.b.in1.groups) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const bool st = lo.store_out != 0;
             // with the float32 section in the plan every 8-wide block of the net is inside it (dims[-1] = 8): those kernels carry no
@@ -1709,17 +1819,17 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             const int N = (V8NB > 0 && op.N < 16) ? 16 : op.N;
             if (op.sclin) {
                 switch (N) {
-                    case 4: if (V8NB == 0) resblock_body_h<4, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 8: if (V8NB == 0) resblock_body_h<8, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 16: resblock_body_h<16, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    default: resblock_body_h<32, true, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 4: if (V8NB == 0) resblock_body_h<4, true, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, true, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 16: resblock_body_h<16, true, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    default: resblock_body_h<32, true, true, true, false, false, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                 }
             } else {
                 switch (N) {
-                    case 4: if (V8NB == 0) resblock_body_h<4, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 8: if (V8NB == 0) resblock_body_h<8, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 16: resblock_body_h<16, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    default: resblock_body_h<32, false, true, true, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 4: if (V8NB == 0) resblock_body_h<4, false, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, false, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 16: resblock_body_h<16, false, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    default: resblock_body_h<32, false, true, true, false, false, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                 }
             }
         } else if (op.kind == 2) {
@@ -1733,8 +1843,7 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             l.Wh = lds + lo.w1; l.l.bias = ldsf + lo.c2;
             globalize<true>(l);
             if (!have_x || l.l.in_groups > 4) {
-                // Linear whose input is wider than one tile (the entry of the run) or the first operator of a phase: memory in, memory
-                // out, then reload
+                // any other Linear whose input is wider than one tile or that opens the run: memory in, memory out, then reload
                 linear_body_h<1, IN_FRAG, OUT_FRAG, false>(l, tile, lane);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const LinArgs& a = l.l;
@@ -1754,6 +1863,8 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
         }
     }
     }
+    }
+    { const int lane = lane_id; DSG_STAMP(tile_raw == 0, 0x4ff); }
 }
 
 // ---------------------------------------------------------------------------------------------
