@@ -263,16 +263,57 @@ __device__ __forceinline__ void chain_raw_from_reg_h(f32x16 (&out)[NT], const f3
 // FIXG > 0: the segment's group count is known at compile time (the skip input of a narrow up block is as wide as the block): the
 // per-step conditions below fold away -- with a runtime count every array element is a conditional definition, and hipcc keeps the
 // whole set of prefetched operands alive through the merges (spilled, next to the float32 section's larger live state).
+// the activations of a <= 32-wide segment requested AHEAD of its chain (round 6: the skip input of a narrow up block -- a row-dependent read
+// that was issued right where the chain starts: an exposed L2 / HBM round trip in front of stage 1's second half and another in front of the shortcut)
+struct SegPre { float4 x0[2], x1[2]; };
+template <int FIXG>
+__device__ __forceinline__ void seg_prefetch(SegPre& p, const float* __restrict__ xp /* tile base + lane * 4 */) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int S = 0; S < 2; ++S) {
+        p.x0[S] = z4; p.x1[S] = z4;
+        if (2 * S < FIXG) p.x0[S] = ld4(xp + (size_t)(2 * S) * 256);
+        if (2 * S + 1 < FIXG) p.x1[S] = ld4(xp + (size_t)(2 * S + 1) * 256);
+    }
+}
+
 template <int NT, bool LNACT, int MAXS = 0, int FIXG = 0>
 __device__ __forceinline__ void chain_from_mem_h(f32x16 (&acc)[NT], const float* __restrict__ xp, int groups_rt, const uint4* __restrict__ wp,
                                                  size_t nt_stride, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                 float mean, float rstd, const HFrag<NT>* w0 = nullptr) {
+                                                 float mean, float rstd, const HFrag<NT>* w0 = nullptr, const SegPre* xpre = nullptr) {
     if (FIXG > 0 && groups_rt != FIXG) __builtin_trap();
     const int groups = FIXG > 0 ? FIXG : groups_rt;
     const int steps = (groups + 1) >> 1;
     if (steps <= 0) return;
     if constexpr (MAXS > 0) {
         if (steps > MAXS) __builtin_trap();             // a narrow block's segments are at most 32 features wide (plan builder)
+        if (xpre) {
+            // the activations are in registers already (requested a stage ago): planes and LayerNorm vectors step by step from LDS -- all
+            // steps' operands at once (below) cost 48 registers the 32-wide up block does not have beside the prefetched tensor
+            const float c = rstd, d = -mean * rstd;
+#pragma unroll
+            for (int S = 0; S < MAXS; ++S) {
+                if (S < steps) {
+                    HFrag<NT> w;
+                    if (S == 0 && w0) w = *w0;
+                    else load_hfrag<NT>(w, wp + (size_t)S * 128, nt_stride);
+                    float v[8];
+                    if (LNACT) {
+                        const float4 g0 = ld4(gamma + 16 * S), b0 = ld4(beta + 16 * S), g1 = ld4(gamma + 16 * S + 8), b1 = ld4(beta + 16 * S + 8);
+                        act8(v, xpre->x0[S], xpre->x1[S], c, d, g0, b0, g1, b1);
+                    } else {
+                        const float4 x0 = xpre->x0[S], x1 = xpre->x1[S];
+                        v[0] = kRawScale * x0.x; v[1] = kRawScale * x0.y; v[2] = kRawScale * x0.z; v[3] = kRawScale * x0.w;
+                        v[4] = kRawScale * x1.x; v[5] = kRawScale * x1.y; v[6] = kRawScale * x1.z; v[7] = kRawScale * x1.w;
+                    }
+                    h8 bhi, blo;
+                    split8(v, bhi, blo);
+                    mfma_step_h<NT>(acc, w, bhi, blo);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            return;
+        }
         const float c = rstd, d = -mean * rstd;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         HFrag<NT> w[MAXS];
@@ -462,7 +503,7 @@ __device__ __forceinline__ void globalize(BlockArgsH& a) {
 // XOUT: the output goes (back) into `xr`; it is stored only when `store_out` (something outside this wave reads it).
 constexpr int kLnLdsW1 = 272, kLnLdsN = 128;   // LDS copy of the LayerNorm vectors: stage-1 width (<= 256 + pad), block width
 
-template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN, bool PRE = false, bool LDSLN = false, bool PC = false>
+template <int N, bool SCLIN, bool XIN = false, bool XOUT = XIN, bool PRE = false, bool LDSLN = false, int PC = 0, int SK = 0>
 __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int tile, const int lane, f32x16 (*xr)[(N + 31) / 32] = nullptr,
                                                 float* xr_mean = nullptr, float* xr_m2 = nullptr, bool store_out = true,
                                                 const float* lnp = nullptr, int entry_pre = -1) {
@@ -522,7 +563,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         load_vec4<NT, NG>(vc2, a.c2, h);
         load_vec4<NT, NG>(vc3, a.c3, h);
     }
-    if (PRE || PC) {
+    if (PRE || PC == 1) {
         // PC (round 6, the LDS form of the narrow run): the block's condition embedding is a row-dependent stream from HBM (329 MB per step
         // over all blocks: nothing of it is cached) -- requested here, two stages before it is added
         if (tile >= a.uncond_tiles) {
@@ -543,6 +584,13 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         }
     }
 
+    // Round 6, the LDS form of the narrow run: SK = 1 requests the skip input of a 16-wide up block AHEAD of its two chains (at the block
+    // top for stage 1, under stage 3 for the shortcut) -- row-dependent reads that were issued right where the chains start.  The 32-wide
+    // up block has no 16 registers to spare (80 B of scratch, slower); for it a "Linear shortcut first, skip read once" order was built and
+    // measured: -7 % in the isolated block (tools/ubench/narrow_block.hip), +3 % in the kernel (profiles/r06_narrow_block_forms.txt): not kept.
+    constexpr bool SKP = SK == 1 && XIN && N == 16;
+    SegPre skp;
+    if (SKP && a.in1.groups) seg_prefetch<(N == 16 ? NG : 1)>(skp, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4);
     DSG_STAMP(XIN && tile == 0, 0x12);
     // ---- stage 1
     f32x16 acc1[NT];
@@ -562,7 +610,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         if (a.in1.groups)
             chain_from_mem_h<NT, true, (N <= 32 ? 2 : 0), (XIN && N <= 32 ? NG : 0)>(acc1, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
                                        ah.W1h + (size_t)ks0 * 128 + lane, nt_stride, gamma1 + 8 * a.in0.groups + 4 * h,
-                                       beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr);
+                                       beta1 + 8 * a.in0.groups + 4 * h, mean1, rstd1, PRE ? &p1b : nullptr, SKP ? &skp : nullptr);
         DSG_STAMP(XIN && tile == 0, 0x13);
         if (PRE) acc_unscale_add_reg<NT, NG>(acc1, inv1, vtb);
         else acc_unscale_add<NT, NG>(acc1, inv1, a.tbias + (size_t)entry * a.tb_stride, h);
@@ -578,6 +626,13 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
 
     // ---- stage 2
     f32x16 acc2[NT];
+    if (PC == 2) {      // the 32-wide blocks of the LDS form: no registers for the embedding during stage 1 -- requested here, one stage ahead
+        if (tile >= a.uncond_tiles) {
+            const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
+#pragma unroll
+            for (int G = 0; G < NG; ++G) vcp[G] = ld4(cp + (size_t)G * 256);
+        }
+    }
     {
         float mean, m2;
         acc_stats<N, NT>(acc1, h, mean, m2);
@@ -591,7 +646,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
         const float* cp = a.cond_pre + (size_t)ptile * NG * 256 + lane * 4;
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
-            const float4 cv = (PRE || PC) ? vcp[G] : ld4(cp + (size_t)G * 256);
+            const float4 cv = (PRE || PC != 0) ? vcp[G] : ld4(cp + (size_t)G * 256);
             acc2[G >> 2][4 * (G & 3) + 0] += cv.x; acc2[G >> 2][4 * (G & 3) + 1] += cv.y;
             acc2[G >> 2][4 * (G & 3) + 2] += cv.z; acc2[G >> 2][4 * (G & 3) + 3] += cv.w;
         }
@@ -607,6 +662,8 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
     DSG_STAMP(XIN && tile == 0, 0x16);
     // ---- stage 3 (+ shortcut in the same scaled accumulator)
     f32x16 (&acc3)[NT] = acc1;
+    if (SKP && SCLIN && a.in1.groups)       // the shortcut's read of the skip input: on its way under stage 3
+        seg_prefetch<(N == 16 ? NG : 1)>(skp, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4);
     {
         float mean, m2;
         acc_stats<N, NT>(acc2, h, mean, m2);
@@ -623,7 +680,7 @@ __device__ __forceinline__ void resblock_body_h(const BlockArgsH& ah, const int 
                                         nullptr, nullptr, 0.f, 1.f);
         if (a.in1.groups)
             chain_from_mem_h<NT, false, (N <= 32 ? 2 : 0), (XIN && N <= 32 ? NG : 0)>(acc3, a.in1.data + (size_t)seg_tile(a.in1, tile) * a.in1.groups * 256 + lane * 4, a.in1.groups,
-                                        ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f, PRE ? &psb : nullptr);
+                                        ah.Wsch + (size_t)ks0 * 128 + lane, nt_stride, nullptr, nullptr, 0.f, 1.f, PRE ? &psb : nullptr, SKP ? &skp : nullptr);
         if (PRE) acc_unscale_add_reg<NT, NG>(acc3, inv3, vc3);
         else acc_unscale_add<NT, NG>(acc3, inv3, a.c3, h);
     } else {
@@ -1819,17 +1876,17 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
             const int N = (V8NB > 0 && op.N < 16) ? 16 : op.N;
             if (op.sclin) {
                 switch (N) {
-                    case 4: if (V8NB == 0) resblock_body_h<4, true, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 8: if (V8NB == 0) resblock_body_h<8, true, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 16: resblock_body_h<16, true, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    default: resblock_body_h<32, true, true, true, false, false, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 4: if (V8NB == 0) resblock_body_h<4, true, true, true, false, false, 1>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, true, true, true, false, false, 1>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 16: resblock_body_h<16, true, true, true, false, false, 1, 1>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    default: resblock_body_h<32, true, true, true, false, false, 2, 0>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                 }
             } else {
                 switch (N) {
-                    case 4: if (V8NB == 0) resblock_body_h<4, false, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 8: if (V8NB == 0) resblock_body_h<8, false, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    case 16: resblock_body_h<16, false, true, true, false, false, true>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
-                    default: resblock_body_h<32, false, true, true, false, false, false>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 4: if (V8NB == 0) resblock_body_h<4, false, true, true, false, false, 1>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 8: if (V8NB == 0) resblock_body_h<8, false, true, true, false, false, 1>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    case 16: resblock_body_h<16, false, true, true, false, false, 1, 0>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
+                    default: resblock_body_h<32, false, true, true, false, false, 2, 0>(b, tile, lane, &x, &xmean, &xm2, st, nullptr, 0); break;
                 }
             }
         } else if (op.kind == 2) {

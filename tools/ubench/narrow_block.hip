@@ -18,8 +18,11 @@ using namespace dsg;
 #ifndef NB_WAVES
 #define NB_WAVES 16
 #endif
+#ifndef NB_SK
+#define NB_SK 0
+#endif
 #ifndef NB_PC
-#define NB_PC false
+#define NB_PC 0
 #endif
 constexpr int N = NB_N;
 constexpr bool SCLIN = NB_SCLIN != 0;
@@ -73,9 +76,9 @@ __global__ __launch_bounds__(1024, 4) void k_block(const BlockArgsH ah_in, const
         globalize_io(b.b);
 #endif
         #ifdef NB_STORE
-        resblock_body_h<N, SCLIN, true, true, false, false, NB_PC>(b, tile, lane, &x, &xmean, &xm2, true, nullptr, 0);
+        resblock_body_h<N, SCLIN, true, true, false, false, NB_PC, NB_SK>(b, tile, lane, &x, &xmean, &xm2, true, nullptr, 0);
 #else
-        resblock_body_h<N, SCLIN, true, true, false, false, NB_PC>(b, tile, lane, &x, &xmean, &xm2, false, nullptr, 0);
+        resblock_body_h<N, SCLIN, true, true, false, false, NB_PC, NB_SK>(b, tile, lane, &x, &xmean, &xm2, false, nullptr, 0);
 #endif
         // keep the values bounded: the block is a residual map
 #pragma unroll
