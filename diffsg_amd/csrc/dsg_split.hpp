@@ -1753,15 +1753,10 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
     float xmean = 0.f, xm2 = 0.f;
     bool have_x = false;
     const int lane_id = lane;
-    // the run's opening operator, when it is a Linear fed from memory: its input on the way before anything else
+    // the run's opening operator, when it is a Linear fed from memory: its input is requested before the first barrier
     LinPre pre;
     const int first = P.p[0].op_lo;
     const bool pre_lin = ops[first].kind == 1 && ops[first].l.l.in_groups <= kLinPreG && !(V8NB > 0 && P.p[0].v8_at == first);
-    if (pre_lin) {
-        LinArgs l0 = ops[first].l.l;
-        globalize_io(l0);
-        linear_mem_prefetch(pre, l0, tile, lane);
-    }
     // the phase's image: every thread copies 16-byte pieces, one piece in flight per thread.  More loads in flight per thread
     // are SLOWER here (same box, us per launch: 1 or 2 pieces 75.3, 4 pieces 80.7, all ten 84.3): 256 workgroups pull the same
     // 75-150 KiB from L2 at the same moment, and the burst costs more than the round trips it saves.
@@ -1771,6 +1766,11 @@ __global__ __launch_bounds__(1024, 4) void k_fused_narrow_lds(const FusedOpH* __
         for (unsigned i = threadIdx.x; i < ph.tb_u4; i += blockDim.x) lds[ph.n_u4 + i] = tbs[i];
     };
     stage(P.p[0]);
+    if (pre_lin) {      // behind the image's loads (in front of them the nine requests per lane doubled the staging time), under the barrier
+        LinArgs l0 = ops[first].l.l;
+        globalize_io(l0);
+        linear_mem_prefetch(pre, l0, tile, lane);
+    }
     __syncthreads();
     DSG_STAMP(tile_raw == 0, 0x401);
     int i_first = first;
