@@ -245,7 +245,7 @@ def configs_leg(dev, split=True):
     return out
 
 
-def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
+def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8, use_graph=True):
     """MSR-80c training throughput (BASELINE config 5 shape): per GPU `B` rows, T=20, Adam(lr 5e-3); one step =
     DDPM.forward (q_sample + denoiser forward + backward in libdiffsg_hip) + ONE all-reduce of the flat 6.6 MB gradient
     bucket (RCCL, world > 1) + Adam.step + re-pack of the updated weights."""
@@ -269,12 +269,24 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
         return loss
     for _ in range(warmup):
         one()
+    # one GPU: the whole step (draws, forward + backward, Adam, zero_grad, re-pack) replayed as ONE captured graph (train.StepGraph: the same
+    # kernels on the same operands, bit-identical to the eager loop); data parallel: the eager loop with its one all-reduce per step
+    sg = None
+    if use_graph and world == 1:
+        from diffsg_amd.train import StepGraph
+        sg = StepGraph(ddpm, opt, y, cond, warmup=2)
+        for _ in range(3):
+            sg.step()
+    step_fn = sg.step if sg is not None else one
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = one()
+        loss = step_fn()
+    t_host = time.perf_counter() - t0          # the host is done enqueueing here; the barrier below waits for the device
     barrier()
     dt = time.perf_counter() - t0
+    if sg is not None:
+        sg.close()
     from diffsg_amd import parallel as par
     ev = par.run_evidence(dev, dt, steps)            # ranks_seen, per-rank rates; the timed figure is the slowest rank's
     dt = ev["max_seconds"]
@@ -347,7 +359,10 @@ def train_leg(dev, dist, rank, world, B, steps, barrier, warmup=8):
             roof["step_traffic_bytes_listed_kernels"] = tt.get("bytes_per_step_listed_kernels")
             roof["traffic_source"] = "imported, not measured in this run: profiles/traffic_train.json <- " + tt.get("summary", "") + \
                                      " (mean k_wgrad_h launch, five per step; 2 x FETCH_SIZE + WRITE_SIZE, fabric side)"
-    return {"roofline": roof, "samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": B, "global_batch": world * B,
+    return {"roofline": roof, "samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "host_ms_per_step": t_host / steps * 1e3,
+            "graph": ("one captured HIP graph per step (train.StepGraph: draws + forward + backward + Adam + zero_grad + re-pack)" if sg is not None
+                      else "eager launches"),
+            "batch_per_gpu": B, "global_batch": world * B,
             "steps": steps, "T": 20, "final_loss": float(loss.detach()), "draws": "device Philox per rank (dsg_train_step_seeded, seed 1000 + rank)", "achieved_tflops": sps / world * f_train / 1e12,
             "frac_f32_mfma": sps / world * f_train / 1e12 / PEAK_F32_TFLOPS, "grad_bucket_bytes": int(ddpm.grad_bucket.numel()) * 4,
             "collective": ("none (1 GPU)" if world == 1 else
@@ -370,6 +385,7 @@ def main():
                     help="training rows per GPU: BASELINE config 4 is a global batch of 262144 over 8 GPUs")
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-train-graph", action="store_true", help="time the eager training loop instead of the captured step graph (one GPU)")
     ap.add_argument("--no-f32-exact", action="store_true", help="skip the exact-float32 re-run of the same K steps")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE config-2 sub-record (MSR-3c, 8192 rows, T = 1000)")
     ap.add_argument("--warm-seconds", type=float, default=0.3, help="untimed clock warm-up before the timed steps")
@@ -462,7 +478,7 @@ def main():
 
     train = None
     if not a.no_train:
-        train = train_leg(dev, dist, rank, world, a.train_batch, a.train_steps, barrier)
+        train = train_leg(dev, dist, rank, world, a.train_batch, a.train_steps, barrier, use_graph=not a.no_train_graph)
 
     if rank == 0:
         # roofline of the dominant kernel: eager re-run of the same K steps with HIP events around every launch

@@ -2478,9 +2478,32 @@ int dsg_train_draws(unsigned long long seed, unsigned long long call, int T, flo
     if (call >> 30) return fail("dsg_train_draws: call counter out of range (2^30)");
     const size_t blocks = (((size_t)B * D + 3) / 4 + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
-    hipLaunchKernelGGL(k_train_draws, dim3(grid), dim3(256), 0, (hipStream_t)stream, ts, noise, cond_mask, B, D, T, keep_prob, seed, (unsigned)call);
+    hipLaunchKernelGGL(k_train_draws, dim3(grid), dim3(256), 0, (hipStream_t)stream, ts, noise, cond_mask, B, D, T, keep_prob, seed, (unsigned)call,
+                       (const unsigned long long*)nullptr);
     HIPCK(hipGetLastError());
     return 0;
+}
+
+int dsg_train_step_seeded_dyn(dsg_handle* h, const float* y, const float* cond, unsigned long long seed, unsigned long long* call_dev,
+                              float keep_prob, const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat, float* loss_out,
+                              int B, void* stream) {
+    if (check_bound(h)) return 1;
+    if (B < 1 || T < 1) return fail("B and T must be >= 1");
+    if (!y || !cond || !call_dev || !sqrt_acp || !sqrt_1m_acp || !grads_flat || !loss_out) return fail("dsg_train_step_seeded_dyn: null pointer argument");
+    if (ensure_train_workspace(h, B, T)) return 1;
+    const int D = h->d.input_dim;
+    if (!h->tr_noise) {
+        HIPCK(hipMalloc(&h->tr_noise, (size_t)h->tr_rows * D * sizeof(float)));
+        HIPCK(hipMalloc(&h->tr_mask, (size_t)h->tr_rows * sizeof(float)));
+    }
+    const size_t blocks = (((size_t)B * D + 3) / 4 + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_train_draws, dim3(grid), dim3(256), 0, s, h->tr_ts, h->tr_noise, h->tr_mask, B, D, T, keep_prob, seed, 0u,
+                       (const unsigned long long*)call_dev);
+    hipLaunchKernelGGL(k_bump_u64, dim3(1), dim3(64), 0, s, call_dev);
+    HIPCK(hipGetLastError());
+    return train_step_impl(h, y, cond, h->tr_ts, h->tr_noise, h->tr_mask, sqrt_acp, sqrt_1m_acp, T, grads_flat, loss_out, B, s);
 }
 
 int dsg_train_step_seeded(dsg_handle* h, const float* y, const float* cond, unsigned long long seed, unsigned long long call,
@@ -2715,10 +2738,27 @@ int dsg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, l
     if ((reinterpret_cast<unsigned long long>(p) | reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(exp_avg) |
          reinterpret_cast<unsigned long long>(exp_avg_sq)) & 15ull)
         return fail("dsg_adam_step: the four buffers must be 16-byte aligned");
-    const AdamArgs a{p, g, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, weight_decay, eps, (float)step, maximize};
+    const AdamArgs a{p, g, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, weight_decay, eps, (float)step, maximize, nullptr, nullptr};
     const long long pieces = (n / 4 + 255) / 256;
     const unsigned blocks = (unsigned)(pieces < 1 ? 1 : (pieces < 2048 ? pieces : 2048));
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int dsg_adam_step_dyn(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, const double* lr_dev, double beta1, double beta2,
+                      double eps, double weight_decay, int maximize, float* step_dev, void* stream) {
+    if (!p || !g || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev || n < 0) return fail("dsg_adam_step_dyn: bad arguments");
+    if (n == 0) return 0;
+    if ((reinterpret_cast<unsigned long long>(p) | reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(exp_avg) |
+         reinterpret_cast<unsigned long long>(exp_avg_sq)) & 15ull)
+        return fail("dsg_adam_step_dyn: the four buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bump_f32, dim3(1), dim3(64), 0, s, step_dev);          // the count AFTER this update, as dsg_adam_step is handed it
+    const AdamArgs a{p, g, exp_avg, exp_avg_sq, (size_t)n, 0.0, beta1, beta2, weight_decay, eps, 0.f, maximize, lr_dev, step_dev};
+    const long long pieces = (n / 4 + 255) / 256;
+    const unsigned blocks = (unsigned)(pieces < 1 ? 1 : (pieces < 2048 ? pieces : 2048));
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, a);
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -1397,6 +1397,8 @@ struct AdamArgs {
     double lr, beta1, beta2, weight_decay, eps;
     float step;                 // the step count AFTER this update (1, 2, ...), as torch's float step tensor holds it
     int maximize;
+    // dsg_adam_step_dyn (the update inside a captured graph): learning rate and step count from device memory (null: the values above)
+    const double* lr_ptr; const float* step_ptr;
 };
 __device__ __forceinline__ void adam_one(float& param, float grad, float& exp_avg, float& exp_avg_sq, const AdamArgs& a, float bias_correction1,
                                          float bias_correction2_sqrt) {
@@ -1408,7 +1410,9 @@ __device__ __forceinline__ void adam_one(float& param, float grad, float& exp_av
     const float denom = (sqrtf(exp_avg_sq) / bias_correction2_sqrt) + a.eps;
     param -= step_size * exp_avg / denom;
 }
-__global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
+__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+    if (a.lr_ptr) a.lr = *a.lr_ptr;
+    if (a.step_ptr) a.step = *a.step_ptr;
     const double bc1 = 1 - pow(a.beta1, (double)a.step), bc2 = 1 - pow(a.beta2, (double)a.step);
     const float bias_correction1 = (float)bc1, bias_correction2_sqrt = (float)sqrt(bc2);
     const size_t n4 = a.n / 4;

@@ -43,8 +43,11 @@ __global__ void k_qsample(const float* __restrict__ y, const float* __restrict__
 // The step's three draws on the device (dsg_train_draws): Philox4x32-10 keyed by seed, counter word 2 = 4*call + kind so that the
 // three kinds and successive calls never share a counter.  noise: normal4 (Box-Muller, as the sampling loop's);
 // ts = floor(u * T), u on a 24-bit grid;  mask = u < keep_prob.
+// call_ptr (dsg_train_step_seeded_dyn: the step inside a captured graph): the call number is read from device memory -- a value baked into
+// the launch would repeat the same draws at every replay; k_bump_u64 moves it on behind this kernel.
 __global__ void k_train_draws(int* __restrict__ ts, float* __restrict__ noise, float* __restrict__ mask, int B, int D, int T, float keep,
-                              unsigned long long seed, unsigned call) {
+                              unsigned long long seed, unsigned call_v, const unsigned long long* __restrict__ call_ptr) {
+    const unsigned call = call_ptr ? (unsigned)*call_ptr : call_v;
     const size_t n = (size_t)B * D, n4 = (n + 3) / 4, b4 = ((size_t)B + 3) / 4;
     for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
         if (noise) {
@@ -66,6 +69,9 @@ __global__ void k_train_draws(int* __restrict__ ts, float* __restrict__ noise, f
         }
     }
 }
+
+__global__ void k_bump_u64(unsigned long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1ull; }
+__global__ void k_bump_f32(float* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1.0f; }
 
 // loss = mean((noise - eps_hat)^2) (F.mse_loss, MSR.py:112); d_eps = 2 (eps_hat - noise) / (B*D) in fragment layout.
 // Per-block float64 partial sums; k_loss_final reduces them in a fixed order.

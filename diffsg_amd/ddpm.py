@@ -404,9 +404,16 @@ class DDPMCore(nn.Module):
                                             _lib.ptr(mk[lo:hi]), sa, sb, self.T, _lib.ptr(wk), _lib.ptr(ls), hi - lo, _lib.stream_ptr()))
             loss = self._run_halves(launch, hd, B, dev, work, (y32, c32, ts32, nz, mk))
         else:
+            dyn = getattr(self, "_call_dev", None)      # train.StepGraph: the call number lives in device memory (a captured launch would repeat it)
+
             def launch(handle, lo, hi, wk, ls):
-                _lib.check(L.dsg_train_step_seeded(handle, _lib.ptr(y32[lo:hi]), _lib.ptr(c32[lo:hi]), seed, call, float(1.0 - self.uncond_prob),
-                                                   sa, sb, self.T, _lib.ptr(wk), _lib.ptr(ls), hi - lo, _lib.stream_ptr()))
+                if dyn is not None:
+                    _lib.check(L.dsg_train_step_seeded_dyn(handle, _lib.ptr(y32[lo:hi]), _lib.ptr(c32[lo:hi]), seed, _lib.ptr(dyn),
+                                                           float(1.0 - self.uncond_prob), sa, sb, self.T, _lib.ptr(wk), _lib.ptr(ls), hi - lo,
+                                                           _lib.stream_ptr()))
+                else:
+                    _lib.check(L.dsg_train_step_seeded(handle, _lib.ptr(y32[lo:hi]), _lib.ptr(c32[lo:hi]), seed, call, float(1.0 - self.uncond_prob),
+                                                       sa, sb, self.T, _lib.ptr(wk), _lib.ptr(ls), hi - lo, _lib.stream_ptr()))
             loss = self._run_halves(launch, hd, B, dev, work, (y32, c32))
         self._keepalive = (y32, c32)
         if not torch.is_grad_enabled():

@@ -70,11 +70,18 @@ class FlatAdam(torch.optim.Adam):
                 st["step"] = st["step"].detach().cpu()
             st["step"] += 1
             b1, b2 = group["betas"]
+            dyn = getattr(self, "_dyn", None)          # StepGraph: learning rate and step count in device memory
             with torch.cuda.device(self._flat.device):
-                _lib.check(_lib.lib().dsg_adam_step(_lib.ptr(self._flat), _lib.ptr(bucket), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
-                                                    self._flat.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                    float(group["weight_decay"]), int(bool(group.get("maximize"))), int(st["step"].item()),
-                                                    _lib.stream_ptr()))
+                if dyn is not None:
+                    _lib.check(_lib.lib().dsg_adam_step_dyn(_lib.ptr(self._flat), _lib.ptr(bucket), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
+                                                            self._flat.numel(), _lib.ptr(dyn["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                            float(group["weight_decay"]), int(bool(group.get("maximize"))), _lib.ptr(dyn["step"]),
+                                                            _lib.stream_ptr()))
+                else:
+                    _lib.check(_lib.lib().dsg_adam_step(_lib.ptr(self._flat), _lib.ptr(bucket), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
+                                                        self._flat.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                        float(group["weight_decay"]), int(bool(group.get("maximize"))), int(st["step"].item()),
+                                                        _lib.stream_ptr()))
             out = None
         self._ddpm.model.mark_weights_changed()   # in-place update through an alias: the per-parameter versions do not move
         return out
@@ -92,6 +99,81 @@ class FlatAdam(torch.optim.Adam):
             return
         for p in self._ddpm.model.param_list():
             p.grad = None
+
+
+class StepGraph:
+    """One whole training step -- device-side draws, q_sample + denoiser forward + backward (dsg_train_step_seeded_dyn), Adam
+    (dsg_adam_step_dyn), zero_grad, the re-pack of the updated weights -- captured ONCE as a HIP graph and replayed per step (reference
+    loop body: classifier_free_MSR.py:220-232, the same shape every step).  Per step the host then issues one graph launch instead of ~70
+    kernel launches, a dozen torch ops and the ctypes marshalling around them (0.87 ms of host time per 1.8 ms step before; VERDICT r5,
+    next 4).  What changes from step to step lives in DEVICE memory and is moved on by the graph itself: the Philox call number of the
+    draws and Adam's step count; the learning rate is a device scalar the host rewrites when a scheduler changes it.  The replayed
+    kernels are the eager step's, on the same operands: weights after k replays == weights after k eager steps, bit for bit
+    (tests/test_gpu_parity.py::test_graph_train_step_is_the_eager_step_bit_for_bit).
+
+    Contract: `y` and `cond` are STATIC buffers -- copy each batch into them (`graph.y.copy_(batch)`); single process (a captured RCCL
+    all-reduce is not used here: data-parallel runs keep the eager loop); requires `diffusion_model.device_draws` (the reference's torch
+    generator cannot be replayed from a graph) and a FlatAdam on its native path.  `loss` is the static loss tensor of the last replay."""
+
+    def __init__(self, diffusion_model, optimizer, y, cond, warmup=3):
+        if diffusion_model.device_draws is None:
+            raise ValueError("StepGraph needs device-side draws: set diffusion_model.device_draws = <seed>")
+        if not isinstance(optimizer, FlatAdam) or not FlatAdam.native_step:
+            raise ValueError("StepGraph needs a FlatAdam on its native path")
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise ValueError("StepGraph is single-process: the data-parallel loop stays eager (one all-reduce per step)")
+        self.ddpm, self.opt, self.y, self.cond = diffusion_model, optimizer, y, cond
+        dev = y.device
+        # eager warm-up on a side stream (workspaces, descriptor tables, the side streams of the fused step, Adam's state), as torch's
+        # capture rules ask; then the counters move to the device at their current values
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):
+                self._eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        st = optimizer.state[optimizer._flat]
+        group = optimizer.param_groups[0]
+        self._lr_host = float(group["lr"])
+        optimizer._dyn = {"lr": torch.tensor([self._lr_host], dtype=torch.float64, device=dev),
+                          "step": torch.tensor([float(st["step"].item())], dtype=torch.float32, device=dev)}
+        diffusion_model._call_dev = torch.tensor([int(diffusion_model._draw_calls)], dtype=torch.int64, device=dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._eager_step()
+        # the capture ran the bookkeeping of ONE step on the host (call number, step count) without executing it on the device: undo it
+        diffusion_model._draw_calls -= 1
+        st["step"] -= 1
+        self.replays = 0
+
+    def _eager_step(self):
+        loss = self.ddpm(self.y, self.cond)
+        loss.backward()
+        self.opt.step()
+        self.opt.zero_grad()
+        self.ddpm.model.native_handle()        # the re-pack of the updated weights belongs to the step (it would otherwise open the next one)
+        return loss
+
+    def step(self):
+        """Replay one training step; returns the (static) loss tensor.  The host mirrors of the two counters move with the device's."""
+        lr = float(self.opt.param_groups[0]["lr"])
+        if lr != self._lr_host:                # MultiStepLR moved it (once per milestone): a stream-ordered 8-byte write
+            self.opt._dyn["lr"].fill_(lr)
+            self._lr_host = lr
+        self.graph.replay()
+        self.ddpm._draw_calls += 1
+        self.opt.state[self.opt._flat]["step"] += 1
+        self.replays += 1
+        return self.loss
+
+    __call__ = step
+
+    def close(self):
+        """Back to the eager loop: the counters continue on the host where the graph left them."""
+        self.opt._dyn = None
+        self.ddpm._call_dev = None
 
 
 def dp_context(backend=None):

@@ -190,6 +190,17 @@ int dsg_train_profile(dsg_handle* h, float* ms5);
  * multi_tensor_apply launch, which gives the 1.6 M-element flat parameter vector to 26 workgroups. */
 int dsg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
                   double weight_decay, int maximize, long long step, void* stream);
+/* Graph-capturable forms of the two calls whose arguments change from step to step (round 6: a whole training step -- draws, forward,
+ * backward, Adam, re-pack -- replayed as ONE captured graph; diffsg_amd/train.py StepGraph).  The values a launch would otherwise bake in
+ * are read from DEVICE memory and moved on by the call itself:
+ *   dsg_train_step_seeded_dyn  = dsg_train_step_seeded with call = *call_dev, then *call_dev += 1
+ *   dsg_adam_step_dyn          = *step_dev += 1, then dsg_adam_step with lr = *lr_dev and step = *step_dev (the count after the update)
+ * Same kernels on the same operands: the results are those of the by-value calls bit for bit. */
+int dsg_train_step_seeded_dyn(dsg_handle* h, const float* y, const float* cond, unsigned long long seed, unsigned long long* call_dev,
+                              float keep_prob, const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat, float* loss_out,
+                              int B, void* stream);
+int dsg_adam_step_dyn(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, const double* lr_dev, double beta1, double beta2,
+                      double eps, double weight_decay, int maximize, float* step_dev, void* stream);
 
 /* avg = decay*avg + one_minus_decay*p over n floats   (ddpm_opt/ema.py:11-12). */
 int dsg_ema_update(float* avg, const float* p, float decay, float one_minus_decay, long long n, void* stream);

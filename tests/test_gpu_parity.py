@@ -1054,6 +1054,49 @@ def test_seeded_train_step_is_the_explicit_step_on_the_same_draws(name, B):
     assert losses[0] != losses[1]
 
 
+@pytest.mark.parametrize("name,B", [("nu3", 512), ("msr80", 32768)])
+def test_graph_train_step_is_the_eager_step_bit_for_bit(name, B):
+    """train.StepGraph: the whole training step -- device draws, fused forward + backward, Adam, zero_grad, re-pack --
+    captured once and replayed.  After 3 warm-up steps + k replays the weights, Adam's moments and the losses equal those of 3 + k eager
+    steps of an identical model BIT FOR BIT (the Philox call number and Adam's step count advance in device memory:
+    dsg_train_step_seeded_dyn / dsg_adam_step_dyn).  32 768 rows = the bench shape: the step runs on two streams there (early weight-gradient
+    parts, time path beside the tail) and the capture has to follow both.  Then the loop goes back to eager and still matches."""
+    from diffsg_amd.train import FlatAdam, StepGraph
+    T, k = 20, 3
+    cfg = CONFIGS[name]
+    g = torch.Generator().manual_seed(B)
+    y = (torch.rand(B, cfg["input_dim"], generator=g) * 0.25).cuda()
+    cond = torch.rand(B, cfg["cond_dim"], generator=g).cuda()
+
+    def fresh():
+        plan, p = synth_params(name, 5)
+        d = make_ddpm(name, p, T)
+        d.device_draws = 321
+        return d, FlatAdam(d, lr=5e-3)
+
+    def eager(d, opt):
+        loss = d(y, cond)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return float(loss.detach())
+
+    d0, o0 = fresh()
+    ref_losses = [eager(d0, o0) for _ in range(3 + k + 1)]
+    d1, o1 = fresh()
+    sg = StepGraph(d1, o1, y, cond, warmup=3)
+    got = [float(sg.step().detach()) for _ in range(k)]
+    assert got == ref_losses[3:3 + k], (got, ref_losses)
+    sg.close()
+    got_last = eager(d1, o1)                     # back on the eager path: the counters continue where the graph left them
+    assert got_last == ref_losses[3 + k]
+    torch.cuda.synchronize()
+    assert torch.equal(o0._flat.detach(), o1._flat.detach())
+    s0, s1 = o0.state[o0._flat], o1.state[o1._flat]
+    assert torch.equal(s0["exp_avg"], s1["exp_avg"]) and torch.equal(s0["exp_avg_sq"], s1["exp_avg_sq"])
+    assert float(s0["step"]) == float(s1["step"]) == 3 + k + 1 and d0._draw_calls == d1._draw_calls == 3 + k + 1
+
+
 def test_sampling_is_run_to_run_deterministic():
     """Same seed -> bit-identical samples (device Philox noise, fixed-order renorm reductions)."""
     name, T, B = "msr80", 20, 4096
