@@ -183,6 +183,7 @@ struct dsg_handle {
     void (*renorm_fn)(void*) = nullptr; void* renorm_user = nullptr;
     int device = 0;              // the device that was current in dsg_create: the settings / status entry points select it themselves
     int* range_flag = nullptr;   // device word: a raw split-path operand left fp16's range since the last dsg_range_status
+    int* range_pinned = nullptr; // pinned host word dsg_range_status_stream reads the flag through
     CallParams* call_dev = nullptr;
     hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream)
     std::vector<double> op_ms;   // DSG_SAMPLE_PROFILE: summed HIP-event time per op
@@ -1930,6 +1931,7 @@ void dsg_destroy(dsg_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto& e : h->ev_tail) if (e) (void)hipEventDestroy(e);
+    if (h->range_pinned) (void)hipHostFree(h->range_pinned);
     delete h;
 }
 
@@ -2208,13 +2210,14 @@ int dsg_range_status_stream(dsg_handle* h, int* exceeded, void* stream) {
     if (!h || !exceeded) return fail("dsg_range_status_stream: null argument");
     DeviceGuard dg(h);
     hipStream_t s = (hipStream_t)stream;
-    // the flag travels through a pinned word so that the copy is truly asynchronous and only `s` is waited for
-    static thread_local int* pinned = nullptr;
-    if (!pinned) HIPCK(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int), hipHostMallocDefault));
-    HIPCK(hipMemcpyAsync(pinned, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    // Read AND clear in one step, on `s`: a one-thread kernel exchanges the flag with 0 and writes what it found into a pinned word (ADVICE r5:
+    // "copy, then memset" lost a flag raised between the two by kernels of another stream -- twin handles, the side stream).  The pinned word
+    // belongs to the handle (freed in dsg_destroy); the copy is truly asynchronous and only `s` is waited for.
+    if (!h->range_pinned) HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->range_pinned), sizeof(int), hipHostMallocDefault));
+    hipLaunchKernelGGL(k_flag_take, dim3(1), dim3(64), 0, s, h->range_flag, h->range_pinned);
+    HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(s));
-    *exceeded = *pinned;
-    if (*exceeded) { HIPCK(hipMemsetAsync(h->range_flag, 0, sizeof(int), s)); HIPCK(hipStreamSynchronize(s)); }
+    *exceeded = *h->range_pinned;
     return 0;
 }
 
@@ -2526,6 +2529,12 @@ int dsg_train_step_seeded(dsg_handle* h, const float* y, const float* cond, unsi
 namespace {
 int train_step_impl(dsg_handle* h, const float* y, const float* cond, const int* ts, const float* noise, const float* cond_mask,
                     const float* sqrt_acp, const float* sqrt_1m_acp, int T, float* grads_flat, float* loss_out, int B, hipStream_t s) {
+    // every shape the backward kernels cannot take is refused HERE, before anything is enqueued (the same check in the middle of
+    // the enqueue left forked streams unjoined and the gradient bucket half written)
+    if (h->use_split)
+        for (const ResP& r : h->res)
+            if (r.N >= 64 && (r.in0 != r.N || (r.in1 != 0 && r.in1 != r.N)))
+                return fail("dsg_train_step: no backward kernel for a %d-wide block with inputs %d + %d wide", r.N, r.in0, r.in1);
     if (build_train_descs(h, B, T, s)) return 1;
     const int D = h->d.input_dim, C = h->d.cond_dim, CG = groups_of(C), DG = groups_of(D), tiles = cdiv(B, 32);
     const int td = h->td, half = h->d.proj_dim / 2;

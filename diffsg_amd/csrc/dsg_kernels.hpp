@@ -1391,6 +1391,15 @@ __global__ void k_ema(float* __restrict__ avg, const float* __restrict__ p, floa
 // double from pow(beta, step) and handed on as floats; step size, square root, quotient and the parameter update are float operations.
 // torch's kernel gives a block 65 536 elements of a tensor: the 1.6 M-element flat parameter vector runs on 26 of 256 CUs (45 us); this
 // one is a plain grid-stride loop over 16-byte pieces (memory-bound: 4 reads + 3 writes per element).
+// dsg_range_status_stream: take the flag (read and clear in ONE atomic step) and hand it to the host through a pinned word
+__global__ void k_flag_take(int* __restrict__ flag, int* __restrict__ host_word) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int v = atomicExch(flag, 0);
+        __atomic_store_n(host_word, v, __ATOMIC_RELAXED);
+        __threadfence_system();
+    }
+}
+
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
     size_t n;

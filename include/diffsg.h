@@ -129,7 +129,10 @@ int dsg_unet_forward(dsg_handle* h, const float* x, const float* t, const float*
  *         T = 20 is five graph launches; the step index is a device counter, so the graphs do not depend on T). */
 #define DSG_SAMPLE_NO_GRAPH 1
 /*         DSG_SAMPLE_PROFILE: eager launch with one HIP-event pair around every operator launch on `stream`
- *         (synchronises once per step); read the totals back with dsg_op_profile. */
+ *         (synchronises once per step); read the totals back with dsg_op_profile.  The profile walks the operator list one launch per
+ *         operator (the fused narrow run and the split path's block + Linear pairs booked on their first operator): launches small enough
+ *         for the one-launch-per-pass form (DSG_OPT_TILE_STEP, <= coop_max_tiles tiles) and the exact path's block + Linear pairs
+ *         (DSG_OPT_F32_PAIR) are timed in their per-operator forms -- same arithmetic, not the launches the default path issues there. */
 #define DSG_SAMPLE_PROFILE 2
 int dsg_sample(dsg_handle* h, const float* cond, const float* y_T, const float* noise, unsigned long long seed,
                float omega, const float* coef, int T, float* out, int B, int flags, void* stream);
