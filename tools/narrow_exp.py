@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Round-6 experiment harness for the narrow run: per-operator event times of the reverse step at B rows (default 65536).
-   python tools/narrow_exp.py [rows] [T]   (env: DSG_DBG_NBLOCK, DSG_DBG_STAGGER read by the library)"""
+"""Round-6 experiment harness for the narrow run: step time and per-operator event times of the reverse step at B rows (default 65536), with a
+checksum of the samples (a bit-identical kernel form keeps it).   python tools/narrow_exp.py [rows] [T]
+(the DSG_DBG_* variables it prints were read by experiment builds of the library -- wave stagger, workgroup size; profiles/r06_narrow_block_forms.txt)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
