@@ -579,6 +579,12 @@ def main():
         rl["step_frac_fp32_roof"] = out["step_roofline"]["frac_f32_equiv"]
         rl["step_traffic_bytes"] = step_bytes
         rl["step_frac_hbm_traffic"] = out["step_roofline"]["frac_hbm_traffic"]
+        # the same traffic against what THIS box moves in a plain device copy (dsg_box_calibrate, read + written bytes per second): the step's large
+        # kernels stream 33 x the algorithmic bytes (every block's activations round-trip memory) and sit at ~0.75 of that rate
+        copy_gbs = (box.get("copy_gbs") if isinstance(box, dict) else None)
+        rl["box_copy_gbs"] = copy_gbs
+        rl["step_traffic_gbs"] = out["step_roofline"]["traffic_gbs"]
+        rl["step_frac_box_copy_bw"] = (out["step_roofline"]["traffic_gbs"] / copy_gbs) if (copy_gbs and out["step_roofline"]["traffic_gbs"]) else None
         fp32_roof_steps = PEAK_F32_TFLOPS * 1e12 / (F_ALG_SURVEY * B)        # 973 steps/s at 65 536 rows (cond GEMMs counted)
         rl["fp32_roof_steps_per_s"] = fp32_roof_steps
         rl["split_frac_fp32_roof"] = (K / dt) / fp32_roof_steps
