@@ -113,7 +113,9 @@ class StepGraph:
 
     Contract: `y` and `cond` are STATIC buffers -- copy each batch into them (`graph.y.copy_(batch)`); single process (a captured RCCL
     all-reduce is not used here: data-parallel runs keep the eager loop); requires `diffusion_model.device_draws` (the reference's torch
-    generator cannot be replayed from a graph) and a FlatAdam on its native path.  `loss` is the static loss tensor of the last replay."""
+    generator cannot be replayed from a graph) and a FlatAdam on its native path; batches below `DDPM.train_split_min_rows`.  `loss` is the
+    static loss tensor of the last replay.  The EMA update of the reference loop (ema.py, gated off in every shipped script) stays outside:
+    call `ema.update_parameters` between replays if it is on."""
 
     def __init__(self, diffusion_model, optimizer, y, cond, warmup=3):
         if diffusion_model.device_draws is None:
@@ -123,6 +125,9 @@ class StepGraph:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             raise ValueError("StepGraph is single-process: the data-parallel loop stays eager (one all-reduce per step)")
+        if diffusion_model._splits(y.shape[0]):
+            raise ValueError(f"StepGraph: a batch of {y.shape[0]} rows runs as two halves on two handles (DDPM.train_split_min_rows): "
+                             "capture batches below that threshold")
         self.ddpm, self.opt, self.y, self.cond = diffusion_model, optimizer, y, cond
         dev = y.device
         # eager warm-up on a side stream (workspaces, descriptor tables, the side streams of the fused step, Adam's state), as torch's
